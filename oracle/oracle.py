@@ -1,0 +1,83 @@
+"""ctypes binding of oracle/libcbc_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see the header of oracle/cbc_oracle.c).  The product package cbc_amd never does.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcbc_oracle.so")
+
+
+class OracleStats(ctypes.Structure):
+    _fields_ = [
+        ("n_records", ctypes.c_uint64),
+        ("n_bases", ctypes.c_uint64),
+        ("n_symbols", ctypes.c_uint64),
+        ("read_length", ctypes.c_uint32),
+        ("err", ctypes.c_int32),
+    ]
+
+
+def build(force=False):
+    """Compile the restatement with gcc (seconds)."""
+    src = os.path.join(_HERE, "cbc_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libcbc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.cbc_oracle_encode.restype = ctypes.c_int64
+        L.cbc_oracle_encode.argtypes = [
+            ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(OracleStats)]
+        L.cbc_oracle_decode.restype = ctypes.c_int64
+        L.cbc_oracle_decode.argtypes = [
+            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+            ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+        L.cbc_oracle_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+_ERR = {-2: "reference assert would fire", -3: "output capacity", -4: "malformed input", -5: "out of memory"}
+
+
+def encode(sam: bytes, fasta: bytes, var_length: bool = False, return_stats: bool = False):
+    """Whole-file encode: the bytes `program -c 1 in.sam out ref.fa` (-DDEBUG build) writes."""
+    L = lib()
+    cap = 4096 + len(sam)  # the stream is far smaller than the SAM text
+    out = ctypes.create_string_buffer(cap)
+    st = OracleStats()
+    n = L.cbc_oracle_encode(sam, len(sam), fasta, len(fasta), out, cap, int(var_length), ctypes.byref(st))
+    if n < 0:
+        raise OracleError("oracle encode failed: %s (%d)" % (_ERR.get(n, "?"), n))
+    data = out.raw[:n]
+    return (data, st) if return_stats else data
+
+
+def decode(stream: bytes, fasta: bytes, max_out: int = None):
+    """Whole-file decode: the text `program -x in.cbc out.txt ref.fa` writes (one read per line)."""
+    L = lib()
+    cap = max_out if max_out is not None else max(1 << 20, len(stream) * 400)
+    out = ctypes.create_string_buffer(cap)
+    nr = ctypes.c_uint64(0)
+    buf = ctypes.create_string_buffer(stream, len(stream))
+    n = L.cbc_oracle_decode(buf, len(stream), fasta, len(fasta), out, cap, ctypes.byref(nr))
+    if n < 0:
+        raise OracleError("oracle decode failed: %s (%d)" % (_ERR.get(n, "?"), n))
+    return out.raw[:n], nr.value
