@@ -1,0 +1,680 @@
+/*
+ * cbc_encode_body.h -- one arithmetic stream per wavefront: the per-read encode loop of the
+ * reference (compress_line .. encoder_last_step) as wave-cooperative code.
+ *
+ * Template parameter W supplies the 64-lane primitives (cbc_wave_gpu.h on the GPU).  Every
+ * branch below is wave-uniform; per-lane data only flows through W::select / ballot / reduce_add /
+ * readlane and masked loads and stores.
+ *
+ * What is serial (wave-uniform scalars): the range-coder recurrence (l, u, scale3), the bit
+ * accumulator, all model totals.  What the 64 lanes share inside ONE symbol:
+ *   - read-vs-reference compare: 4 bases per lane, one ballot            (read_compression.c:291-296)
+ *   - cumulative-frequency lookup: masked gather of the sparse/dense table + wave sum
+ *                                                                         (stream_model.c:64-69)
+ *   - POS-delta alphabet search: 64 candidates per compare + ballot       (read_compression.c:130)
+ *   - var-context statistics: ballot + popcount over the block's var events
+ *   - snpInRef window: a 256-bit sliding bitmap, first-set search         (read_compression.c:703-718)
+ *   - output: 64 big-endian words staged in a VGPR, one coalesced 256-byte store per 2048 bits
+ *
+ * Model tables are kept SPARSE and exact (SURVEY.md section 7 hard part 2): every symbol of the
+ * big models starts at count 1 and rescaling maps 1 -> (1>>1)+1 = 1, so with e[s] = count[s]-1:
+ *     cum(x) = x + sum_{s<x} e[s],   n = card + sum e[s],   rescale: e' = (1+e)>>1.
+ */
+#ifndef CBC_ENCODE_BODY_H
+#define CBC_ENCODE_BODY_H
+
+#include <stdint.h>
+#include "../../include/cbc_gpu.h"
+
+#define CBC_AWORD     26u
+#define CBC_M26       ((1u << 26) - 1u)
+#define CBC_M25       ((1u << 25) - 1u)
+#define CBC_RESCALE   (1u << 20)
+#define CBC_NVARCTX   0xffffu
+#define CBC_NOMEMO    0xffffffffu
+
+/* lane map of the register-resident small models (one VGPR, `small`) */
+#define CBC_LT_MATCH   0u     /* 4 ctx x 2                 sam_models.c:204-241 */
+#define CBC_LT_SAMEREF 8u     /* 1 x 2                     sam_models.c:617     */
+#define CBC_LT_CHARS   16u    /* 6 rows x 5, stride 8      sam_models.c:350-411 */
+
+/* LDS words in front of the two variable-size tables */
+#define CBC_LDS_RLEN    0u                         /* 256: rlength[0] excess            */
+#define CBC_LDS_SNPS    256u                       /* 256: snps excess                  */
+#define CBC_LDS_INDELS  512u                       /* 256: indels excess                */
+#define CBC_LDS_RNKEY   768u                       /* CBC_CAP_NAME: (ctx<<8)|char       */
+#define CBC_LDS_RNEXC   (768u + CBC_CAP_NAME)      /* CBC_CAP_NAME                      */
+#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME)
+/* then pos_val[cap_pos], pos_cnt[cap_pos], var_ev[cap_var] */
+
+struct cbc_enc_args {
+    const cbc_read_rec   *recs;
+    const uint8_t        *seq;
+    const uint32_t       *tok;
+    const uint8_t        *names;
+    const cbc_block_desc *blocks;
+    const uint8_t        *ref;
+    uint8_t              *out;
+    cbc_block_result     *results;
+    uint64_t ref_bytes, out_bytes, seq_bytes, n_tok, n_recs;
+    uint32_t n_blocks, cap_pos, cap_var, names_bytes;
+};
+
+template <class W>
+struct CbcEnc {
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+
+    /* ---- range coder + bit writer (Arithmetic_stream.c:155-194, 274-371) ---- */
+    uint32_t l, u, scale3;
+    uint64_t acc; uint32_t nacc;
+    V32 stage; uint32_t nwords; uint32_t *out32; uint32_t cap_words;
+    uint32_t status, nsym, fail_read, cur_read;
+
+    /* ---- models ---- */
+    V32 small;                              /* match / same_ref / chars lane table            */
+    V32 fkey, fexc; uint32_t fcount, fn;    /* flag: sparse, one entry per lane                */
+    V32 hkey, hexc; uint32_t hcount[4], hn[4];   /* codebook ctx 0..3: sparse, 8 lanes per ctx */
+    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_cnt, *var_ev;
+    uint32_t rlen_n, rlen_memo_x, rlen_memo_lo, rlen_memo_cnt;
+    uint32_t rl123_c0, rl123_n;             /* rlength[1..3]: only symbol 0 is ever coded (Q1)  */
+    uint32_t snps_n, indels_n;
+    uint32_t rn_count;
+    uint32_t pos_card, pos_n, cap_pos;
+    uint32_t nev, cap_var;
+    uint32_t L0;
+
+    /* ---- cross-read state (T7/T8 of SURVEY.md) ---- */
+    uint32_t prevPos, prevM, prevChar;
+    uint64_t win[4];                        /* snpInRef[cumsumP-1 .. +255] as a bitmap          */
+
+    /* ======================================================================================= */
+    CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
+
+    CBC_MFN void emit_word(uint32_t w)
+    {
+        V32 ln = W::lane();
+        stage = W::select(ln == (nwords & 63u), W::splat(W::bswap32(w)), stage);
+        nwords++;
+        if ((nwords & 63u) == 0u) {
+            if (nwords <= cap_words) W::store32(out32, ln + (nwords - 64u), stage, W::all());
+            else fail(CBC_ST_OUT_FULL);
+        }
+    }
+    CBC_MFN void put(uint32_t v, uint32_t n)          /* n <= 32 bits, MSB first */
+    {
+        if (n == 0) return;
+        acc = (acc << n) | (uint64_t)v; nacc += n;
+        if (nacc >= 32u) { nacc -= 32u; emit_word((uint32_t)(acc >> nacc)); }
+    }
+    CBC_MFN void put_run(uint32_t bit, uint32_t n)    /* n copies of bit */
+    {
+        uint32_t pat = bit ? 0xffffffffu : 0u;
+        while (n >= 32u) { put(pat, 32u); n -= 32u; }
+        if (n) put(pat >> (32u - n), n);
+    }
+
+    /* arithmetic_encoder_step, Arithmetic_stream.c:274-345, with the E1/E2 and E3 loops in
+     * closed form: within one step all E1/E2 iterations come first (they strip the common
+     * leading bits of l and u), then all E3 iterations (they strip the run of positions below
+     * the MSB where l has 1 and u has 0); E3 leaves msb(l)=0, msb(u)=1, so E1/E2 cannot recur. */
+    CBC_MFN void encode(uint32_t lo, uint32_t cnt, uint32_t n)
+    {
+        if (cnt == 0u || n == 0u) { fail(CBC_ST_ASSERT); return; }      /* assert(cumCountX_1 < cumCountX) */
+        nsym++;
+        uint32_t range = u - l + 1u;
+        double inv = W::recip(n);
+        uint32_t qh = W::muldiv(range, lo + cnt, n, inv);
+        uint32_t ql = W::muldiv(range, lo, n, inv);
+        u = l + qh - 1u;
+        l = l + ql;
+        uint32_t x = l ^ u;
+        uint32_t k1 = x ? (W::clz32(x) - 6u) : 26u;
+        if (k1) {
+            uint32_t bits = l >> (26u - k1);
+            if (scale3 == 0u) put(bits, k1);
+            else {
+                uint32_t b0 = bits >> (k1 - 1u);
+                put(b0, 1u); put_run(b0 ^ 1u, scale3); scale3 = 0u;
+                put(bits & ((1u << (k1 - 1u)) - 1u), k1 - 1u);
+            }
+            l = (uint32_t)(((uint64_t)l << k1) & CBC_M26);
+            u = (uint32_t)((((uint64_t)u << k1) & CBC_M26) | ((1ull << k1) - 1ull));
+        }
+        uint32_t y = ((l & ~u) & CBC_M25) << 7;
+        uint32_t k3 = W::clz32(~y);                           /* ~y != 0: its low 7 bits are set */
+        if (k3) {
+            scale3 += k3;
+            l = (l << k3) & CBC_M25;
+            u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
+        }
+    }
+    CBC_MFN uint32_t finish()                        /* encoder_last_step :348-363 + stream_finish_byte */
+    {
+        uint32_t msb = l >> 25;
+        put(msb, 1u); put_run(msb ^ 1u, scale3); scale3 = 0u;
+        put(l & CBC_M25, 25u);
+        uint32_t total_bits = nwords * 32u + nacc;
+        uint32_t nbytes = (total_bits >> 3) + 1u;            /* +1: partial byte, or the extra 0x00 */
+        emit_word(nacc ? (uint32_t)(acc << (32u - nacc)) : 0u);
+        nacc = 0;
+        uint32_t rem = nwords & 63u;
+        if (rem) {
+            uint32_t base = nwords - rem;
+            V32 ln = W::lane();
+            if (nwords <= cap_words) W::store32(out32, ln + base, stage, ln < rem);
+            else fail(CBC_ST_OUT_FULL);
+        }
+        return nbytes;
+    }
+
+    /* ---- register-resident sparse model (flag, codebook): entries at lanes [base, base+count) ---- */
+    CBC_MFN void regsparse_code(V32 &key, V32 &exc, uint32_t base, uint32_t cap, uint32_t &count, uint32_t &n,
+                               uint32_t card, uint32_t step, uint32_t x, uint32_t cap_status)
+    {
+        V32 ln = W::lane();
+        Mask live = (ln >= base) & (ln < base + count);
+        uint32_t lo = x + W::reduce_add(W::select(live & (key < x), exc, W::splat(0u)));
+        uint64_t eq = W::ballot(live & (key == x));
+        uint32_t idx = 0, cnt = 1u;
+        if (eq) { idx = W::ctz64(eq); cnt = 1u + W::readlane(exc, idx); }
+        if (x >= card) { fail(CBC_ST_ASSERT); return; }
+        encode(lo, cnt, n);
+        if (eq) exc = W::select(ln == idx, exc + step, exc);
+        else {
+            if (count >= cap) { fail(cap_status); return; }
+            idx = base + count;
+            key = W::select(ln == idx, W::splat(x), key);
+            exc = W::select(ln == idx, W::splat(step), exc);
+            count++;
+        }
+        n += step;
+        if (n >= CBC_RESCALE) {                               /* update_model stream_model.c:41-48 */
+            live = (ln >= base) & (ln < base + count);
+            exc = W::select(live, (exc + 1u) >> 1, exc);
+            n = card + W::reduce_add(W::select(live, exc, W::splat(0u)));
+        }
+    }
+
+    /* ---- LDS dense-excess model (rlength[0], snps, indels) ---- */
+    CBC_MFN void dense_lookup(const uint32_t *exc, uint32_t x, uint32_t &lo, uint32_t &cnt)
+    {
+        V32 ln = W::lane();
+        V32 a = W::splat(0u);
+        for (uint32_t b = 0; b < x; b += 64u) { V32 i = ln + b; a = a + W::load32(exc, i, i < x, 0u); }
+        lo = x + W::reduce_add(a);
+        cnt = 1u + W::read_uni(exc, x);
+    }
+    CBC_MFN void dense_update(uint32_t *exc, uint32_t card, uint32_t step, uint32_t x, uint32_t &n)
+    {
+        W::write_uni(exc, x, W::read_uni(exc, x) + step);
+        n += step;
+        if (n >= CBC_RESCALE) {
+            V32 ln = W::lane();
+            V32 a = W::splat(0u);
+            for (uint32_t b = 0; b < card; b += 64u) {
+                V32 i = ln + b; Mask m = i < card;
+                V32 e = (W::load32(exc, i, m, 0u) + 1u) >> 1;
+                W::store32(exc, i, e, m);
+                a = a + W::select(m, e, W::splat(0u));
+            }
+            n = card + W::reduce_add(a);
+        }
+    }
+    CBC_MFN void dense_code(uint32_t *exc, uint32_t card, uint32_t step, uint32_t x, uint32_t &n)
+    {
+        if (x >= card) { fail(CBC_ST_ASSERT); return; }       /* assert(x < alphabetCard) stream_model.c:62 */
+        uint32_t lo, cnt;
+        dense_lookup(exc, x, lo, cnt);
+        encode(lo, cnt, n);
+        dense_update(exc, card, step, x, n);
+    }
+
+    /* ---- lane-table literal-count models (match, same_ref, chars); step/rescale literal ---- */
+    CBC_MFN void small_code(uint32_t base, uint32_t card, uint32_t step, uint32_t x)
+    {
+        uint32_t lo = 0, n = 0, cnt = 0;
+        for (uint32_t j = 0; j < card; j++) {
+            uint32_t c = W::readlane(small, base + j);
+            if (j < x) lo += c;
+            if (j == x) cnt = c;
+            n += c;
+        }
+        encode(lo, cnt, n);
+        V32 ln = W::lane();
+        small = W::select(ln == base + x, small + step, small);
+        if (n + step >= CBC_RESCALE) {
+            Mask m = (ln >= base) & (ln < base + card);
+            small = W::select(m, (small >> 1) + 1u, small);
+        }
+    }
+
+    /* ---- rname: 256 contexts x 256, sparse (ctx,char)->excess list in LDS (id_compression.c:39-65) ---- */
+    CBC_MFN void rname_code(uint32_t ctx, uint32_t sym)
+    {
+        V32 ln = W::lane();
+        V32 an = W::splat(0u), alo = W::splat(0u);
+        uint32_t key = (ctx << 8) | sym, found = CBC_NOMEMO;
+        for (uint32_t b = 0; b < rn_count; b += 64u) {
+            V32 i = ln + b; Mask m = i < rn_count;
+            V32 k = W::load32(rname_key, i, m, 0xffffffffu);
+            V32 e = W::load32(rname_exc, i, m, 0u);
+            Mask inctx = m & ((k >> 8) == ctx);
+            an = an + W::select(inctx, e, W::splat(0u));
+            alo = alo + W::select(inctx & ((k & 0xffu) < sym), e, W::splat(0u));
+            uint64_t eq = W::ballot(m & (k == key));
+            if (eq) found = b + W::ctz64(eq);
+        }
+        uint32_t n = 256u + W::reduce_add(an);
+        uint32_t lo = sym + W::reduce_add(alo);
+        uint32_t cnt = 1u + (found != CBC_NOMEMO ? W::read_uni(rname_exc, found) : 0u);
+        if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return; }   /* unreachable within the name cap */
+        encode(lo, cnt, n);
+        if (found != CBC_NOMEMO) W::write_uni(rname_exc, found, cnt - 1u + 10u);
+        else {
+            if (rn_count >= CBC_CAP_NAME) { fail(CBC_ST_CAP_NAME); return; }
+            W::write_uni(rname_key, rn_count, key);
+            W::write_uni(rname_exc, rn_count, 10u);
+            rn_count++;
+        }
+    }
+
+    /* ---- pos (read_compression.c:113-159): dynamic alphabet, literal counts ---- */
+    CBC_MFN void pos_update(uint32_t idx)
+    {
+        W::write_uni(pos_cnt, idx, W::read_uni(pos_cnt, idx) + 10u);
+        pos_n += 10u;
+        if (pos_n >= CBC_RESCALE) {
+            V32 ln = W::lane();
+            V32 a = W::splat(0u);
+            for (uint32_t b = 0; b < pos_card; b += 64u) {
+                V32 i = ln + b; Mask m = i < pos_card;
+                V32 c = (W::load32(pos_cnt, i, m, 0u) >> 1) + 1u;
+                W::store32(pos_cnt, i, c, m);
+                a = a + W::select(m, c, W::splat(0u));
+            }
+            pos_n = W::reduce_add(a);
+        }
+    }
+    /* one byte of compress_pos_alpha (:75-108).  The four 256-symbol models only ever see the
+     * bytes of the values already registered in pos_val[1..card), so their state is recomputed
+     * from that array: count(b) = 1 + 10 * #{registered v : byte_k(v) == b}. */
+    CBC_MFN void pos_alpha_byte(uint32_t shift, uint32_t byte)
+    {
+        V32 ln = W::lane();
+        uint32_t lt = 0, eq = 0;
+        for (uint32_t b = 1; b < pos_card; b += 64u) {
+            V32 i = ln + b; Mask m = i < pos_card;
+            V32 v = (W::load32(pos_val, i, m, 0u) >> shift) & 0xffu;
+            lt += W::popc64(W::ballot(m & (v < byte)));
+            eq += W::popc64(W::ballot(m & (v == byte)));
+        }
+        uint32_t n = 256u + 10u * (pos_card - 1u);
+        if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return; }
+        encode(byte + 10u * lt, 1u + 10u * eq, n);
+    }
+    CBC_MFN void pos_code(uint32_t x)
+    {
+        V32 ln = W::lane();
+        V32 a = W::splat(0u);
+        uint32_t found = 0;
+        for (uint32_t b = 0; b < pos_card && !found; b += 64u) {
+            V32 i = ln + b; Mask m = i < pos_card;
+            V32 v = W::load32(pos_val, i, m, 0u);
+            V32 c = W::load32(pos_cnt, i, m, 0u);
+            uint64_t eq = W::ballot(m & (v == x) & (i != 0u));
+            if (eq) {
+                uint32_t fl = W::ctz64(eq);
+                found = b + fl;
+                a = a + W::select(ln < fl, c, W::splat(0u));
+            } else a = a + c;
+        }
+        if (found) {
+            uint32_t lo = W::reduce_add(a);
+            encode(lo, W::read_uni(pos_cnt, found), pos_n);
+            pos_update(found);
+        } else {
+            encode(0u, W::read_uni(pos_cnt, 0u), pos_n);       /* escape symbol 0 */
+            pos_update(0u);
+            pos_alpha_byte(24u, x >> 24);
+            pos_alpha_byte(16u, (x >> 16) & 0xffu);
+            pos_alpha_byte(8u, (x >> 8) & 0xffu);
+            pos_alpha_byte(0u, x & 0xffu);
+            if (pos_card >= cap_pos) { fail(CBC_ST_CAP_POS); return; }
+            W::write_uni(pos_val, pos_card, x);
+            W::write_uni(pos_cnt, pos_card, 0u);
+            pos_card++;                                        /* update_model(P, alphabetCard++) :153 */
+            pos_update(pos_card - 1u);
+        }
+    }
+
+    /* ---- var (read_compression.c:230-245): 65535 contexts x L0, kept as the list of events ---- */
+    CBC_MFN void var_code(uint32_t ctx, uint32_t sym)
+    {
+        if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
+        V32 ln = W::lane();
+        uint32_t cn = 0, clo = 0, ceq = 0, key = (ctx << 8) | sym;
+        for (uint32_t b = 0; b < nev; b += 64u) {
+            V32 i = ln + b; Mask m = i < nev;
+            V32 e = W::load32(var_ev, i, m, 0xffffffffu);
+            Mask inctx = m & ((e >> 8) == ctx);
+            uint64_t bn = W::ballot(inctx);
+            if (bn) {
+                cn += W::popc64(bn);
+                clo += W::popc64(W::ballot(inctx & ((e & 0xffu) < sym)));
+                ceq += W::popc64(W::ballot(inctx & (e == key)));
+            }
+        }
+        encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
+        if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
+        W::write_uni(var_ev, nev, key);
+        nev++;
+    }
+
+    /* ---- snpInRef window ---- */
+    CBC_MFN void win_shift(uint32_t d)
+    {
+        if (d >= 256u) { win[0] = win[1] = win[2] = win[3] = 0; return; }
+        uint32_t wsh = d >> 6, bsh = d & 63u;
+        uint64_t t[4];
+        for (uint32_t i = 0; i < 4; i++) {
+            uint32_t s = i + wsh;
+            uint64_t lo = s < 4 ? win[s] : 0, hi = s + 1 < 4 ? win[s + 1] : 0;
+            t[i] = bsh ? ((lo >> bsh) | (hi << (64u - bsh))) : lo;
+        }
+        for (uint32_t i = 0; i < 4; i++) win[i] = t[i];
+    }
+    /* compute_delta_to_first_snp, read_compression.c:703-718 */
+    CBC_MFN uint32_t win_first(uint32_t p, uint32_t rl)
+    {
+        uint32_t out = rl + 2u;
+        if (p >= rl) return out;
+        for (uint32_t i = p >> 6; i < 4; i++) {
+            uint64_t w = win[i];
+            if (i == (p >> 6)) w &= ~0ull << (p & 63u);
+            if (w) { uint32_t pos = i * 64u + W::ctz64(w); if (pos < rl) out = pos - p; break; }
+        }
+        return out;
+    }
+    CBC_MFN void win_set(uint32_t k) { if (k < 256u) win[k >> 6] |= 1ull << (k & 63u); }
+};
+
+/* bytes readable from offset `off` of a buffer with `total` bytes, clamped to 32 bits */
+CBC_FN uint32_t cbc_avail32(uint64_t total, uint32_t off)
+{
+    uint64_t a = total > off ? total - off : 0;
+    return a > 0xffffffffull ? 0xffffffffu : (uint32_t)a;
+}
+CBC_FN uint32_t cbc_basepair(uint32_t c)            /* char2basepair sam_models.c:11-21 */
+{
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+/* ===========================================================================================
+ * cbc_encode_stream: code block `blk` completely.  `lds` = this wavefront's table memory
+ * (cbc_gpu_lds_bytes() bytes).
+ * =========================================================================================== */
+template <class W>
+CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds)
+{
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+    const V32 ln = W::lane();
+    const cbc_block_desc *bd = A.blocks + blk;
+    CbcEnc<W> E;
+
+    /* ---- block descriptor (uniform) ---- */
+    const uint64_t rec_base = bd->rec_base, seq_base = bd->seq_base, tok_base = bd->tok_base;
+    const uint64_t ref_off = bd->ref_off, out_off = bd->out_off;
+    const uint32_t out_cap = bd->out_cap, n_reads = bd->n_reads, name_off = bd->name_off;
+    const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
+
+    E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
+    E.l = 0; E.u = CBC_M26; E.scale3 = 0; E.acc = 0; E.nacc = 0; E.nwords = 0;
+    E.stage = W::splat(0u);
+    E.out32 = (uint32_t *)(A.out + out_off);
+    E.cap_words = out_cap >> 2;
+    bool args_ok = (out_off + out_cap <= A.out_bytes) && ((out_off & 3u) == 0) &&
+                   (rec_base + n_reads <= A.n_recs) && (tok_base + n_tok_blk <= A.n_tok) &&
+                   (L0 >= 1u && L0 <= 256u) && (name_off < A.names_bytes);
+    if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
+
+    /* ---- model initialisation (alloc_read_models_t sam_models.c:562-586 etc.) ---- */
+    E.L0 = L0;
+    E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
+    E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
+    E.pos_val = lds + CBC_LDS_FIXED; E.pos_cnt = E.pos_val + A.cap_pos; E.var_ev = E.pos_cnt + A.cap_pos;
+    E.cap_pos = A.cap_pos; E.cap_var = A.cap_var;
+    for (uint32_t b = 0; b < 768u; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
+    E.rlen_n = 255u; E.rlen_memo_x = CBC_NOMEMO; E.rlen_memo_lo = 0; E.rlen_memo_cnt = 0;
+    E.rl123_c0 = 1u; E.rl123_n = 255u;
+    E.snps_n = L0; E.indels_n = L0;
+    E.rn_count = 0;
+    E.pos_card = 1u; E.pos_n = 1u;                           /* initialize_stream_model_pos :132-162 */
+    W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_cnt, 0u, 1u);
+    E.nev = 0;
+    E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0; E.fn = 65536u;
+    E.hkey = W::splat(0u); E.hexc = W::splat(0u);
+    for (int i = 0; i < 4; i++) { E.hcount[i] = 0; E.hn[i] = 256u; }
+    {   /* lane table: match 1,1 (n=2); same_ref 1,1; chars rows (sam_models.c:372-401) */
+        V32 s = W::splat(0u);
+        s = W::select(ln < 10u, W::splat(1u), s);
+        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
+        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
+        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
+        /* +8 on two entries per row: A:{C,G} C:{A,T} G:{A,T} T:{C,G} */
+        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
+                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
+        cv = W::select(bump, cv + 8u, cv);
+        s = W::select(inch, cv, s);
+        E.small = s;
+    }
+    E.prevPos = 0; E.prevM = 0; E.prevChar = 0;
+    E.win[0] = E.win[1] = E.win[2] = E.win[3] = 0;
+
+    /* ---- stream header: int(L0), 32 x int(WELL), int(LOSSLESS=8)  (sam_file_allocation.c:371,
+     *      392-403; compression.c:139; compress_int qv_codebook.c:14-50) ---- */
+    for (uint32_t k = 0; k < 34u && E.status == CBC_ST_OK; k++) {
+        uint32_t v = (k == 0u) ? L0 : (k == 33u) ? 8u : CBC_WELL_SEED;
+        E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hcount[0], E.hn[0], 256u, 1u, v >> 24, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hcount[1], E.hn[1], 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hcount[2], E.hn[2], 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hcount[3], E.hn[3], 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
+    }
+
+    /* ---- records ---- */
+    const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
+    const uint8_t *seqb = A.seq + seq_base;
+    const uint32_t *tokb = A.tok + tok_base;
+    const uint8_t *refb = A.ref + ref_off;
+    const uint64_t seq_avail = A.seq_bytes > seq_base ? A.seq_bytes - seq_base : 0;
+    const uint64_t ref_avail = A.ref_bytes > ref_off ? A.ref_bytes - ref_off : 0;
+
+    for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
+        V32 r_pos, r_fl, r_seq, r_tok;
+        W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
+        uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
+
+        /* software prefetch of record j's bases, reference window and tokens one record ahead */
+        V32 nx_seq = W::splat(0u), nx_ref = W::splat(0u), nx_tok = W::splat(0u);
+        {
+            uint32_t pos = W::readlane(r_pos, 0u), fl = W::readlane(r_fl, 0u);
+            uint32_t so = W::readlane(r_seq, 0u), to = W::readlane(r_tok, 0u), rl = fl >> 16;
+            V32 bo = ln * 4u;
+            uint32_t slim = cbc_avail32(seq_avail, so), rlim = pos ? cbc_avail32(ref_avail, pos - 1u) : 0u;
+            nx_seq = W::load32_bytes(seqb + so, bo, (bo < rl) & (bo + 4u <= slim));
+            nx_ref = W::load32_bytes(refb + (pos ? pos - 1u : 0u), bo, (bo < rl) & (bo + 4u <= rlim));
+            nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
+        }
+        for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
+            E.cur_read = c0 + j;
+            const uint32_t pos = W::readlane(r_pos, j), flw = W::readlane(r_fl, j);
+            const uint32_t flag = flw & 0xffffu, rl = flw >> 16;
+            const uint32_t tok_off = W::readlane(r_tok, j);
+            const V32 seqv = nx_seq, refv = nx_ref, tokv = nx_tok;
+            if (j + 1u < cn) {
+                uint32_t npos = W::readlane(r_pos, j + 1u), nfl = W::readlane(r_fl, j + 1u);
+                uint32_t so = W::readlane(r_seq, j + 1u), to = W::readlane(r_tok, j + 1u), nrl = nfl >> 16;
+                V32 bo = ln * 4u;
+                uint32_t slim = cbc_avail32(seq_avail, so), rlim = npos ? cbc_avail32(ref_avail, npos - 1u) : 0u;
+                nx_seq = W::load32_bytes(seqb + so, bo, (bo < nrl) & (bo + 4u <= slim));
+                nx_ref = W::load32_bytes(refb + (npos ? npos - 1u : 0u), bo, (bo < nrl) & (bo + 4u <= rlim));
+                nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
+            }
+            if (rl == 0u || rl > CBC_MAX_READ_LEN || pos == 0u) { E.fail(CBC_ST_ASSERT); break; }
+
+            /* -- compress_rname (id_compression.c:39-65); a block holds one contig -- */
+            const bool first = (c0 + j) == 0u;
+            if (!first) E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
+            else {
+                E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+                for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
+                    uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
+                    E.rname_code(E.prevChar, ch);
+                    if (ch == 0u) break;
+                    E.prevChar = ch;
+                }
+                E.prevPos = 0;                                /* chr_change: compress_pos :123-124 */
+                E.win[0] = E.win[1] = E.win[2] = E.win[3] = 0;    /* compression.c:62-63 */
+            }
+
+            /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1) -- */
+            {
+                uint32_t x = rl & 0xffu;
+                if (x >= 255u) { E.fail(CBC_ST_ASSERT); break; }
+                uint32_t lo, cnt;
+                if (x == E.rlen_memo_x) { lo = E.rlen_memo_lo; cnt = E.rlen_memo_cnt; }
+                else { E.dense_lookup(E.rlen_exc, x, lo, cnt); E.rlen_memo_x = x; E.rlen_memo_lo = lo; }
+                E.encode(lo, cnt, E.rlen_n);
+                const uint32_t nb = E.rlen_n;
+                E.dense_update(E.rlen_exc, 255u, 10u, x, E.rlen_n);
+                E.rlen_memo_cnt = cnt + 10u;
+                if (E.rlen_n != nb + 10u) E.rlen_memo_x = CBC_NOMEMO;     /* rescaled: memo is stale */
+                for (int k = 1; k < 4; k++) {
+                    /* the three contexts evolve identically, but symbols interleave: k=1 sees the
+                     * state before this read's update, so code all three, then update once */
+                    E.encode(0u, E.rl123_c0, E.rl123_n);
+                }
+                E.rl123_c0 += 10u; E.rl123_n += 10u;
+                if (E.rl123_n >= CBC_RESCALE) { E.rl123_c0 = (E.rl123_c0 >> 1) + 1u; E.rl123_n = 254u + E.rl123_c0; }
+            }
+
+            /* -- compress_pos -- */
+            const int32_t dx = (int32_t)(pos - E.prevPos) + 1;
+            if (dx < 1 || (uint32_t)dx >= 5000000u) { E.fail(CBC_ST_ASSERT); break; }   /* MAX_ALPHA sam_block.h:54 */
+            E.win_shift(first ? 256u : (uint32_t)(dx - 1));
+            E.pos_code((uint32_t)dx);
+            E.prevPos = pos;
+
+            /* -- compress_flag (read_compression.c:50-70) -- */
+            E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, E.fn, 65536u, 8u, flag, CBC_ST_CAP_FLAG);
+            const uint32_t strand = (flag >> 4) & 1u;
+
+            /* -- match test (read_compression.c:291-296) -- */
+            V32 bo = ln * 4u;
+            V32 bmask = W::select(bo + 4u <= rl, W::splat(0xffffffffu),
+                                  W::select(bo < rl, (W::splat(1u) << ((W::splat(rl) - bo) * 8u)) - 1u, W::splat(0u)));
+            uint64_t neq = W::ballot(((seqv ^ refv) & bmask) != 0u);
+            uint32_t match = neq ? 0u : 1u;
+            E.small_code(CBC_LT_MATCH + (((dx == 1) ? 2u : 0u) | E.prevM) * 2u, 2u, 1u, match);
+            E.prevM = match;
+            if (match || E.status != CBC_ST_OK) continue;
+
+            /* -- compress_edits for an imperfect read (read_compression.c:308-600) -- */
+            const uint32_t hdr = W::readlane(tokv, 0u);
+            const uint32_t n_cig = hdr & 0xffffu, n_md = hdr >> 16;
+            if (tok_off + 1u + n_cig + n_md > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
+#define CBC_TOK(i) ((i) < 64u ? W::readlane(tokv, (i)) : W::read_uni(tokb + tok_off, (i)))
+#define CBC_READ_BYTE(i) ((i) < rl ? ((W::readlane(seqv, (i) >> 2) >> (((i) & 3u) * 8u)) & 0xffu) : 0u)
+            uint32_t nSnp = 0, nDel = 0, nIns = 0;
+            for (int pass = 0; pass < 4 && E.status == CBC_ST_OK; pass++) {
+                /* pass 0 counts; 1 deletions; 2 SNPs; 3 insertions (emission order :568-600) */
+                if (pass == 1) {
+                    if ((nDel | nIns) == 0u) E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
+                    else {
+                        E.dense_code(E.snps_exc, L0, 10u, 0u, E.snps_n);
+                        E.dense_code(E.indels_exc, L0, 16u, nSnp & 0xffu, E.indels_n);
+                        E.dense_code(E.indels_exc, L0, 16u, nDel & 0xffu, E.indels_n);
+                        E.dense_code(E.indels_exc, L0, 16u, nIns & 0xffu, E.indels_n);
+                    }
+                    if (nDel == 0u) continue;
+                }
+                if (pass == 2 && nSnp == 0u) continue;
+                if (pass == 3 && nIns == 0u) continue;
+                uint32_t Mc = 0, ins = 0, prevI = 0, prevD = 0, p = 0;
+                uint32_t k = 0, cum = 0; bool more = true;          /* add_snps_to_array statics */
+                for (uint32_t o = 0; o <= n_cig && E.status == CBC_ST_OK; o++) {
+                    uint32_t op, len;
+                    if (o < n_cig) { uint32_t t = CBC_TOK(1u + o); op = t & 15u; len = t >> 4; }
+                    else { op = 99u; len = 1u; }                     /* final pull with limit rl+1 :551 */
+                    if (op == CBC_OP_M) { Mc += len; continue; }
+                    if (op == CBC_OP_STAR || (op == CBC_OP_S && o == 0u)) { E.fail(CBC_ST_UNSUPPORTED); break; }
+                    if (op == CBC_OP_D) {
+                        if (pass == 0) nDel += len;
+                        else if (pass == 1)
+                            for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) {
+                                uint32_t g = Mc - prevD;
+                                E.var_code((p << 1) | strand, g);
+                                p += g; prevD = Mc;
+                            }
+                        continue;
+                    }
+                    /* I, trailing S, or the final pull */
+                    for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) {
+                        if ((op == CBC_OP_I || op == 99u) && more && (pass == 0 || pass == 2)) {
+                            uint32_t limit = (op == 99u) ? rl + 1u : Mc + ins;
+                            more = false;
+                            while (k < n_md) {
+                                uint32_t t = CBC_TOK(1u + n_cig + k);
+                                uint32_t g = t >> 8, letter = t & 0xffu;
+                                if (cum + g >= limit) { cum++; more = true; break; }
+                                cum += g;
+                                if (pass == 0) nSnp++;
+                                else {
+                                    uint32_t d = E.win_first(p, rl);
+                                    E.var_code(((((d << 7) + p) << 1) | strand), g);
+                                    p += g + 1u;
+                                    E.win_set(p - 1u);               /* snpInRef[cumsumP+prev_pos-2] = 1 */
+                                    uint32_t alt = cbc_basepair(CBC_READ_BYTE(cum));
+                                    E.small_code(CBC_LT_CHARS + cbc_basepair(letter) * 8u, 5u, 8u, alt);
+                                    if (E.status != CBC_ST_OK) break;
+                                }
+                                cum++; k++;
+                            }
+                        }
+                        if (op == 99u) break;
+                        if (pass == 0) nIns++;
+                        else if (pass == 3) {
+                            uint32_t g = Mc - prevI;
+                            uint32_t base = cbc_basepair(CBC_READ_BYTE(Mc + ins));
+                            E.var_code((p << 1) | strand, g);
+                            p += g;
+                            E.small_code(CBC_LT_CHARS + 5u * 8u, 5u, 8u, base);
+                            prevI = Mc;
+                        }
+                        ins++;
+                    }
+                }
+                if (pass == 0 && (nSnp >= 1024u || nDel >= 1024u || nIns >= 1024u)) E.fail(CBC_ST_ASSERT);
+            }
+#undef CBC_TOK
+#undef CBC_READ_BYTE
+        }
+    }
+
+    /* ---- end-of-stream sentinel compress_rname("\n") (compression.c:152) + flush ---- */
+    uint32_t nbytes = 0;
+    if (E.status == CBC_ST_OK) {
+        E.cur_read = n_reads;
+        E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+        E.rname_code(E.prevChar, (uint32_t)'\n');
+        E.rname_code((uint32_t)'\n', 0u);
+    }
+    if (E.status == CBC_ST_OK) nbytes = E.finish();
+    if (E.status != CBC_ST_OK) nbytes = 0;
+    V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),
+               W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
+    W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);
+}
+
+#endif /* CBC_ENCODE_BODY_H */

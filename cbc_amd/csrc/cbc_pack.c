@@ -1,0 +1,613 @@
+/*
+ * cbc_pack.c -- host packer: SAM text + FASTA text -> packed record blocks for the HIP encoder.
+ *
+ * Restates, for the product, the parsing rules of the reference's record loader and FASTA loader
+ * (they decide which bytes the models see, so they are load-bearing for bit-exactness):
+ *   load_sam_line()              src/sam_file_allocation.c:437-529
+ *   get_read_length()            src/sam_file_allocation.c:26-79
+ *   store_reference_in_memory()  src/read_decompression.c:17-53
+ *   CIGAR scan of compress_edits()      src/read_compression.c:308-352,469-484
+ *   MD scan of add_snps_to_array()      src/read_compression.c:613-701
+ * and cuts the record stream into independent blocks (hard part 1): one
+ * contig per block, POS rebased so that the block's first record has POS 1, at most
+ * opts.block_reads records, and never more distinct POS deltas / var symbols / FLAG values than
+ * the kernel's LDS tables hold.
+ *
+ * No arithmetic coding happens here.
+ */
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/cbc_host.h"
+
+#define LINE_BUF 1024              /* fgets(buffer, 1024, ...) in the reference */
+#define API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+static int grow(void **p, uint64_t *cap, uint64_t need, size_t elt)
+{
+    if (need <= *cap) return 0;
+    uint64_t nc = *cap ? *cap : 1024;
+    while (nc < need) nc += nc / 2 + 1024;
+    void *q = realloc(*p, (size_t)(nc * elt));
+    if (!q) return CBC_E_NOMEM;
+    *p = q; *cap = nc;
+    return 0;
+}
+static int grow32(void **p, uint32_t *cap, uint64_t need, size_t elt)
+{
+    uint64_t c = *cap; int rc = grow(p, &c, need, elt);
+    *cap = (uint32_t)c; return rc;
+}
+static uint32_t num_digits(uint32_t x)             /* compute_num_digits read_compression.c:720-743 */
+{
+    if (x < 10) return 1; if (x < 100) return 2; if (x < 1000) return 3; if (x < 10000) return 4;
+    if (x < 100000) return 5; if (x < 1000000) return 6; if (x < 10000000) return 7;
+    if (x < 100000000) return 8; return 9;
+}
+
+typedef struct {
+    cbc_packed *P;
+    cbc_pack_opts o;
+    char *err; size_t errlen;
+    /* current contig / block */
+    char prev_name[LINE_BUF];
+    int have_contig;
+    uint32_t contig;               /* index of current contig */
+    uint32_t n_fasta;              /* contigs available in ref */
+    int blk_open;
+    uint64_t blk_first_pos;        /* absolute POS of the block's first record */
+    uint32_t blk_prev_pos;         /* absolute POS of the previous record in the block */
+    uint32_t blk_reads, blk_var, blk_nflags, blk_ndelta;
+    uint64_t blk_bases;
+    uint16_t blk_flags[CBC_CAP_FLAG];
+    uint32_t *dset; uint32_t *dstamp; uint32_t dmask, depoch;   /* distinct-delta hash set */
+    char edits[2 * LINE_BUF];      /* persists across records like read_line_t.edits */
+    uint32_t tokbuf[4 * LINE_BUF];
+} packer_t;
+
+static int fail(packer_t *S, int code, const char *fmt, const char *a, long long b)
+{
+    if (S->err && S->errlen) snprintf(S->err, S->errlen, fmt, a ? a : "", b);
+    return code;
+}
+
+/* FASTA: every record, in file order (the reference consumes the NEXT record at each RNAME change
+ * and ignores the FASTA header text, read_decompression.c:28-42). */
+static int load_fasta(packer_t *S, const char *fa, size_t len)
+{
+    cbc_packed *P = S->P;
+    size_t off = 0;
+    int first_line = 1, in_contig = 0;
+    uint64_t start = 0;
+    S->n_fasta = 0;
+    while (off < len) {
+        size_t e = off; while (e < len && fa[e] != '\n') e++;
+        size_t ll = e - off;
+        if (ll >= LINE_BUF - 1) return fail(S, CBC_E_INPUT, "FASTA line longer than %s1022 bytes at offset %lld (reference loader limit)", "", (long long)off);
+        int is_hdr = (ll > 0 && fa[off] == '>') || (first_line && off == 0);
+        if (is_hdr) {
+            if (in_contig) {                            /* a '>' line ends the record being read */
+                if (grow((void **)&P->ref, &P->cap_ref, P->ref_bytes + CBC_REF_PAD, 1)) return CBC_E_NOMEM;
+                memset(P->ref + P->ref_bytes, 0, CBC_REF_PAD);
+                if (grow32((void **)&P->contigs, &P->cap_contigs, (uint64_t)S->n_fasta + 1, sizeof(cbc_contig_info))) return CBC_E_NOMEM;
+                P->contigs[S->n_fasta].ref_off = start; P->contigs[S->n_fasta].length = P->ref_bytes - start;
+                P->contigs[S->n_fasta].name_off = 0; P->contigs[S->n_fasta].reserved = 0;
+                P->ref_bytes += CBC_REF_PAD; S->n_fasta++;
+            }
+            in_contig = 1; start = P->ref_bytes;
+        } else {
+            if (!in_contig) { in_contig = 1; start = P->ref_bytes; }
+            if (grow((void **)&P->ref, &P->cap_ref, P->ref_bytes + ll, 1)) return CBC_E_NOMEM;
+            for (size_t i = 0; i < ll; i++) P->ref[P->ref_bytes + i] = (uint8_t)toupper((unsigned char)fa[off + i]);
+            P->ref_bytes += ll;
+        }
+        first_line = 0;
+        off = e + 1;
+    }
+    if (in_contig) {
+        if (grow((void **)&P->ref, &P->cap_ref, P->ref_bytes + CBC_REF_PAD, 1)) return CBC_E_NOMEM;
+        memset(P->ref + P->ref_bytes, 0, CBC_REF_PAD);
+        if (grow32((void **)&P->contigs, &P->cap_contigs, (uint64_t)S->n_fasta + 1, sizeof(cbc_contig_info))) return CBC_E_NOMEM;
+        P->contigs[S->n_fasta].ref_off = start; P->contigs[S->n_fasta].length = P->ref_bytes - start;
+        P->contigs[S->n_fasta].name_off = 0; P->contigs[S->n_fasta].reserved = 0;
+        P->ref_bytes += CBC_REF_PAD; S->n_fasta++;
+    }
+    return 0;
+}
+
+static void close_block(packer_t *S)
+{
+    cbc_packed *P = S->P;
+    if (!S->blk_open) return;
+    cbc_block_desc *bd = &P->blocks[P->n_blocks];
+    cbc_block_info *bi = &P->info[P->n_blocks];
+    bd->n_reads = S->blk_reads;
+    bd->n_tok = (uint32_t)(P->n_tok - bd->tok_base);
+    bi->n_reads = S->blk_reads; bi->n_bases = S->blk_bases;
+    uint32_t need_pos = S->blk_ndelta + 2, need_var = S->blk_var + 1;
+    if (need_pos > P->caps.cap_pos) P->caps.cap_pos = need_pos;
+    if (need_var > P->caps.cap_var) P->caps.cap_var = need_var;
+    P->n_blocks++;
+    S->blk_open = 0;
+}
+
+static int open_block(packer_t *S, uint32_t pos)
+{
+    cbc_packed *P = S->P;
+    if (grow32((void **)&P->blocks, &P->cap_blocks, (uint64_t)P->n_blocks + 1, sizeof(cbc_block_desc))) return CBC_E_NOMEM;
+    {   /* info array shares the block capacity */
+        cbc_block_info *ni = (cbc_block_info *)realloc(P->info, sizeof(cbc_block_info) * (size_t)P->cap_blocks);
+        if (!ni) return CBC_E_NOMEM;
+        P->info = ni;
+    }
+    cbc_block_desc *bd = &P->blocks[P->n_blocks];
+    cbc_block_info *bi = &P->info[P->n_blocks];
+    memset(bd, 0, sizeof *bd); memset(bi, 0, sizeof *bi);
+    const cbc_contig_info *c = &P->contigs[S->contig];
+    bd->rec_base = P->n_recs; bd->seq_base = P->seq_bytes; bd->tok_base = P->n_tok;
+    bd->ref_off = c->ref_off + (uint64_t)(pos - 1);
+    bd->name_off = c->name_off; bd->read_length = P->read_length;
+    bi->contig = S->contig; bi->window_start = (uint64_t)(pos - 1);
+    S->blk_open = 1; S->blk_first_pos = pos; S->blk_prev_pos = 0;
+    S->blk_reads = 0; S->blk_var = 0; S->blk_nflags = 0; S->blk_ndelta = 0; S->blk_bases = 0;
+    S->depoch++;
+    if (S->depoch == 0) { memset(S->dstamp, 0, sizeof(uint32_t) * (S->dmask + 1)); S->depoch = 1; }
+    return 0;
+}
+
+static int delta_seen(packer_t *S, uint32_t x, int insert)
+{
+    uint32_t h = (x * 2654435761u) & S->dmask;
+    for (;;) {
+        if (S->dstamp[h] != S->depoch) {
+            if (insert) { S->dstamp[h] = S->depoch; S->dset[h] = x; }
+            return 0;
+        }
+        if (S->dset[h] == x) return 1;
+        h = (h + 1) & S->dmask;
+    }
+}
+
+/* One mapped record, fields exactly as load_sam_line leaves them in read_line_t. */
+static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos_i, const char *cigar,
+                      const char *seq, const char *edits)
+{
+    cbc_packed *P = S->P;
+    size_t rl = strlen(seq);
+    if (rl == 0 || rl > CBC_MAX_READ_LEN)
+        return fail(S, CBC_E_INPUT, "read length %s%lld outside 1..252 (var-context limit of the reference, sam_models.c:317)", "", (long long)rl);
+    if (pos_i < 1) return fail(S, CBC_E_INPUT, "POS %s%lld < 1", "", pos_i);
+    uint32_t pos = (uint32_t)pos_i;
+
+    /* ---- contig change (compress_rname strcmp, id_compression.c:46) ---- */
+    if (!S->have_contig || strcmp(rname, S->prev_name) != 0) {
+        close_block(S);
+        uint32_t ci = S->have_contig ? S->contig + 1 : 0;
+        if (ci >= S->n_fasta) return fail(S, CBC_E_INPUT, "RNAME %s is contig #%lld of the SAM but the FASTA has fewer records (contigs are consumed in FASTA order)", rname, (long long)ci + 1);
+        size_t nl = strlen(rname);
+        if (nl + 3 > CBC_CAP_NAME) return fail(S, CBC_E_INPUT, "RNAME %s longer than %lld characters", rname, (long long)CBC_CAP_NAME - 3);
+        if (grow32((void **)&P->names, &P->cap_names, (uint64_t)P->names_bytes + nl + 1, 1)) return CBC_E_NOMEM;
+        memcpy(P->names + P->names_bytes, rname, nl + 1);
+        P->contigs[ci].name_off = P->names_bytes;
+        P->names_bytes += (uint32_t)nl + 1;
+        S->contig = ci; S->have_contig = 1;
+        if (P->n_contigs < ci + 1) P->n_contigs = ci + 1;
+        strcpy(S->prev_name, rname);
+    }
+    const cbc_contig_info *ctg = &P->contigs[S->contig];
+    if ((uint64_t)pos - 1 + rl > ctg->length + CBC_REF_PAD - 8)
+        return fail(S, CBC_E_INPUT, "record at %s POS %lld runs past the contig end + pad", rname, pos);
+
+    /* ---- tokens: CIGAR ---- */
+    uint32_t *tk = S->tokbuf; uint32_t nt = 1, n_cig = 0, n_md = 0;
+    uint32_t ev = 0;                                    /* upper bound on var symbols of this record */
+    {
+        const char *seg = cigar; int i = 0;
+        while (*seg != 0) {                             /* read_compression.c:308-549 scanning rule */
+            char ch = seg[i];
+            if (ch == 0) break;
+            if (!isdigit((unsigned char)ch)) {
+                uint32_t op = 0xff;
+                if (ch == 'M') op = CBC_OP_M; else if (ch == 'I') op = CBC_OP_I; else if (ch == 'D') op = CBC_OP_D;
+                else if (ch == 'S') op = CBC_OP_S; else if (ch == '*') op = CBC_OP_STAR;
+                if (op != 0xff) {
+                    long v = atoi(seg);                 /* atoi(cigar) of the unconsumed segment */
+                    if (v < 0 || v > 0x0fffffff) return fail(S, CBC_E_INPUT, "CIGAR %s: bad length %lld", cigar, v);
+                    if (nt >= 2 * LINE_BUF) return fail(S, CBC_E_INPUT, "CIGAR %s too long%lld", cigar, 0);
+                    tk[nt++] = ((uint32_t)v << 4) | op; n_cig++;
+                    if (op == CBC_OP_STAR) return fail(S, CBC_E_INPUT, "CIGAR '*' on a mapped record at %s:%lld (the reference aborts on it)", rname, pos);
+                    if (op == CBC_OP_S && n_cig == 1)
+                        return fail(S, CBC_E_INPUT, "leading soft clip at %s:%lld is not supported (reference rebuilds MD in place, quirk Q6)", rname, pos);
+                    if (op != CBC_OP_M) ev += (uint32_t)v;
+                    seg = seg + i + 1; i = -1;
+                }
+            }
+            i++;
+        }
+    }
+    /* ---- tokens: MD (add_snps_to_array scanning rule, consumption branch :661-695) ---- */
+    {
+        const char *p = edits;
+        while (*p != 0) {
+            uint32_t gap = (uint32_t)atoi(p);
+            p += num_digits(gap);
+            char ch = *p; if (ch) p++;
+            int ended = 0;
+            while (ch == '^') {
+                while (*p && !isdigit((unsigned char)*p)) p++;
+                if (!*p) { ended = 1; break; }
+                uint32_t v = (uint32_t)atoi(p);
+                gap += v; p += num_digits(v);
+                ch = *p; if (ch) p++;
+            }
+            if (ended || ch == 0) break;
+            if (gap > 0x00ffffff) return fail(S, CBC_E_INPUT, "MD %s: gap %lld too large", edits, gap);
+            if (nt >= 4 * LINE_BUF - 1) return fail(S, CBC_E_INPUT, "MD %s too long%lld", edits, 0);
+            tk[nt++] = (gap << 8) | (uint8_t)ch; n_md++;
+            if (*p == 0) break;
+        }
+    }
+    if (n_cig > 0xffff || n_md > 0xffff) return fail(S, CBC_E_INPUT, "too many CIGAR/MD tokens%s%lld", "", 0);
+    tk[0] = n_cig | (n_md << 16);
+    ev += n_md;
+    if (ev + 1 > S->o.max_cap_var) return fail(S, CBC_E_INPUT, "record at %s:%lld has more edits than max_cap_var", rname, pos);
+
+    /* ---- block cut decision ---- */
+    int need_new = !S->blk_open;
+    uint32_t x = 0;
+    if (S->blk_open) {
+        if (pos < S->blk_prev_pos) return fail(S, CBC_E_INPUT, "SAM is not sorted by position at %s:%lld", rname, pos);
+        x = pos - S->blk_prev_pos + 1;
+        int newflag = 1;
+        for (uint32_t i = 0; i < S->blk_nflags; i++) if (S->blk_flags[i] == (uint16_t)flag) { newflag = 0; break; }
+        int newdelta = !delta_seen(S, x, 0);
+        if (S->blk_reads >= S->o.block_reads) need_new = 1;
+        else if (x >= 5000000u) need_new = 1;                                   /* MAX_ALPHA sam_block.h:54 */
+        else if (newdelta && S->blk_ndelta + 3 > S->o.max_cap_pos) need_new = 1;
+        else if (S->blk_var + ev + 1 > S->o.max_cap_var) need_new = 1;
+        else if (newflag && S->blk_nflags >= CBC_CAP_FLAG) need_new = 1;
+        else if ((uint64_t)pos - S->blk_first_pos > 0xfff00000ull) need_new = 1;
+    }
+    if (need_new) {
+        close_block(S);
+        int rc = open_block(S, pos);
+        if (rc) return rc;
+        x = 2;                                          /* local POS 1, prevPos 0 */
+    }
+    if (!delta_seen(S, x, 1)) S->blk_ndelta++;
+    {
+        int newflag = 1;
+        for (uint32_t i = 0; i < S->blk_nflags; i++) if (S->blk_flags[i] == (uint16_t)flag) { newflag = 0; break; }
+        if (newflag) S->blk_flags[S->blk_nflags++] = (uint16_t)flag;
+    }
+    S->blk_var += ev;
+
+    /* ---- append ---- */
+    cbc_block_desc *bd = &P->blocks[P->n_blocks];
+    if (grow((void **)&P->recs, &P->cap_recs, P->n_recs + 1, sizeof(cbc_read_rec))) return CBC_E_NOMEM;
+    if (grow((void **)&P->seq, &P->cap_seq, P->seq_bytes + rl + 8, 1)) return CBC_E_NOMEM;
+    if (grow((void **)&P->tok, &P->cap_tok, P->n_tok + nt, sizeof(uint32_t))) return CBC_E_NOMEM;
+    cbc_read_rec *r = &P->recs[P->n_recs++];
+    r->pos = (uint32_t)((uint64_t)pos - S->blk_first_pos + 1);
+    r->flag = (uint16_t)flag; r->rlen = (uint16_t)rl;
+    r->seq_off = (uint32_t)(P->seq_bytes - bd->seq_base);
+    r->tok_off = (uint32_t)(P->n_tok - bd->tok_base);
+    memcpy(P->seq + P->seq_bytes, seq, rl); P->seq_bytes += rl;
+    memcpy(P->tok + P->n_tok, tk, sizeof(uint32_t) * nt); P->n_tok += nt;
+    S->blk_reads++; S->blk_bases += rl; S->blk_prev_pos = pos;
+    P->n_bases += rl;
+    return 0;
+}
+
+static int finish_pack(packer_t *S)
+{
+    cbc_packed *P = S->P;
+    close_block(S);
+    if (grow((void **)&P->seq, &P->cap_seq, P->seq_bytes + 8, 1)) return CBC_E_NOMEM;
+    memset(P->seq + P->seq_bytes, 0, 8); P->seq_bytes += 8;          /* the kernel reads whole dwords */
+    if (P->caps.cap_pos < 64) P->caps.cap_pos = 64;
+    if (P->caps.cap_var < 64) P->caps.cap_var = 64;
+    P->caps.cap_pos = (P->caps.cap_pos + 63u) & ~63u;
+    P->caps.cap_var = (P->caps.cap_var + 63u) & ~63u;
+    if (P->n_tok == 0) { if (grow((void **)&P->tok, &P->cap_tok, 1, sizeof(uint32_t))) return CBC_E_NOMEM; P->tok[0] = 0; }
+    return 0;
+}
+
+static int packer_init(packer_t *S, const cbc_pack_opts *opts, char *errbuf, size_t errlen)
+{
+    memset(S, 0, sizeof *S);
+    if (opts) S->o = *opts; else cbc_pack_default_opts(&S->o);
+    if (S->o.block_reads == 0) S->o.block_reads = 4096;
+    if (S->o.block_reads > CBC_MAX_BLOCK_READS) S->o.block_reads = CBC_MAX_BLOCK_READS;
+    if (S->o.max_cap_pos < 64) S->o.max_cap_pos = 2048;
+    if (S->o.max_cap_var < 64) S->o.max_cap_var = 8192;
+    if (S->o.max_cap_pos > 4096) S->o.max_cap_pos = 4096;
+    if (S->o.max_cap_var > 32768) S->o.max_cap_var = 32768;       /* keeps L0 + 10*uses < 2^20 */
+    S->err = errbuf; S->errlen = errlen;
+    if (errbuf && errlen) errbuf[0] = 0;
+    S->P = (cbc_packed *)calloc(1, sizeof(cbc_packed));
+    if (!S->P) return CBC_E_NOMEM;
+    uint32_t sz = 1; while (sz < 4 * S->o.max_cap_pos) sz <<= 1;
+    S->dmask = sz - 1;
+    S->dset = (uint32_t *)calloc(sz, sizeof(uint32_t));
+    S->dstamp = (uint32_t *)calloc(sz, sizeof(uint32_t));
+    if (!S->dset || !S->dstamp) return CBC_E_NOMEM;
+    return 0;
+}
+static void packer_release(packer_t *S) { free(S->dset); free(S->dstamp); }
+
+API void cbc_pack_default_opts(cbc_pack_opts *o)
+{
+    o->block_reads = 4096; o->max_cap_pos = 2048; o->max_cap_var = 8192; o->var_length = 0;
+}
+
+API void cbc_packed_free(cbc_packed *p)
+{
+    if (!p) return;
+    free(p->recs); free(p->seq); free(p->tok); free(p->names); free(p->blocks); free(p->info);
+    free(p->contigs); free(p->ref); free(p);
+}
+API void cbc_free(void *p) { free(p); }
+
+/* get_read_length (sam_file_allocation.c:26-79): skip '@' lines, skip the first record line, take
+ * the 10th whitespace-separated field of what follows; a file with a single record makes the
+ * reference's fscanf fail and it returns strlen() of that first line. */
+static uint32_t header_read_length(const char *sam, size_t len, size_t *body_off, int var_length)
+{
+    size_t off = 0;
+    while (off < len && sam[off] == '@') { while (off < len && sam[off] != '\n') off++; if (off < len) off++; }
+    *body_off = off;
+    size_t e = off; while (e < len && sam[e] != '\n') e++;
+    size_t first_len = (e < len ? e + 1 : e) - off; if (first_len > 4095) first_len = 4095;
+    size_t q = e < len ? e + 1 : e;
+    uint32_t result = 0; int got = 0;
+    for (;;) {
+        int field = 0; size_t s = q, t = q; int ok = 0;
+        while (s < len) {
+            while (s < len && isspace((unsigned char)sam[s])) s++;
+            if (s >= len) break;
+            t = s; while (t < len && !isspace((unsigned char)sam[t])) t++;
+            if (++field == 10) { ok = 1; break; }
+            s = t;
+        }
+        if (!ok) break;
+        uint32_t l = (uint32_t)(t - s);
+        if (!var_length) { result = l; got = 1; break; }
+        if (l > result) result = l;
+        got = 1;
+        while (t < len && sam[t] != '\n') t++;
+        if (t >= len) break;
+        q = t + 1;
+    }
+    if (!got && !var_length) return (uint32_t)first_len;
+    return result;
+}
+
+API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t fasta_len,
+                     const cbc_pack_opts *opts, cbc_packed **out, char *errbuf, size_t errlen)
+{
+    if (!sam || !fasta || !out) return CBC_E_ARG;
+    packer_t *S = (packer_t *)malloc(sizeof(packer_t));
+    if (!S) return CBC_E_NOMEM;
+    int rc = packer_init(S, opts, errbuf, errlen);
+    if (rc) goto done;
+    rc = load_fasta(S, fasta, fasta_len);
+    if (rc) goto done;
+    size_t off = 0;
+    S->P->read_length = header_read_length(sam, sam_len, &off, (int)S->o.var_length);
+    if (S->P->read_length < 1 || S->P->read_length > 256) {
+        rc = fail(S, CBC_E_INPUT, "header read length %s%lld outside 1..256", "", S->P->read_length); goto done;
+    }
+    char buffer[LINE_BUF];
+    while (off < sam_len) {
+        size_t e = off; while (e < sam_len && sam[e] != '\n') e++;
+        size_t ll = (e < sam_len ? e + 1 : e) - off;           /* includes the '\n' like fgets */
+        if (ll > LINE_BUF - 1) { rc = fail(S, CBC_E_INPUT, "SAM line longer than %s1023 bytes at offset %lld (reference fgets limit)", "", (long long)off); goto done; }
+        memcpy(buffer, sam + off, ll); buffer[ll] = 0;
+        off += ll;
+        char *save = NULL, *f[11]; int nf = 0;
+        while (nf < 11) {                              /* the 11 compulsory columns, strtok("\t") */
+            char *t = strtok_r(nf ? NULL : buffer, "\t", &save);
+            if (!t) break;
+            f[nf++] = t;
+        }
+        if (nf == 0) continue;
+        if (nf < 11) { rc = fail(S, CBC_E_INPUT, "SAM record with fewer than 11 columns near offset %s%lld", "", (long long)off); goto done; }
+        uint32_t flag = (uint16_t)atoi(f[1]);
+        int32_t pos = atoi(f[3]);
+        int auxCnt = 0;
+        for (char *t = strtok_r(NULL, "\t", &save); t; t = strtok_r(NULL, "\t", &save)) {
+            if ((t[0] == 'M' || t[0] == 'X') && t[1] == 'D') {
+                size_t tl = strlen(t);
+                strcpy(S->edits, tl >= 5 ? t + 5 : "");
+            } else { auxCnt++; if (auxCnt == 20) break; }
+        }
+        if ((flag & 4) == 4) { S->P->n_skipped_unmapped++; continue; }      /* compression.c:50-52 */
+        rc = add_record(S, f[2], flag, pos, f[5], f[9], S->edits);
+        if (rc) goto done;
+    }
+    rc = finish_pack(S);
+done:
+    packer_release(S);
+    if (rc) { cbc_packed_free(S->P); *out = NULL; } else *out = S->P;
+    free(S);
+    return rc;
+}
+
+/* ================================= synthetic workload ===================================== */
+typedef struct { uint64_t s[4]; } rng_t;
+static uint64_t splitmix64(uint64_t *x) { uint64_t z = (*x += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint64_t rng_next(rng_t *r)          /* xoshiro256** */
+{
+    uint64_t *s = r->s, res = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return res;
+}
+static inline double rng_unit(rng_t *r) { return (double)(rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+static inline uint64_t rng_below(rng_t *r, uint64_t n) { return (uint64_t)(rng_unit(r) * (double)n); }
+static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+
+API int cbc_synth_packed(const cbc_synth_opts *so, const cbc_pack_opts *po, cbc_packed **out,
+                         char **sam_out, size_t *sam_len, char **fasta_out, size_t *fasta_len,
+                         char *errbuf, size_t errlen)
+{
+    if (!so || !out || so->read_len < 30 || so->read_len > CBC_MAX_READ_LEN || so->contig_len < (uint64_t)so->read_len + 64 ||
+        so->contig_len > 0xf0000000ull) return CBC_E_ARG;
+    static const char ACGT[4] = { 'A', 'C', 'G', 'T' };
+    const char *name = so->name ? so->name : "chr1";
+    const uint32_t L = so->read_len;
+    packer_t *S = (packer_t *)malloc(sizeof(packer_t));
+    if (!S) return CBC_E_NOMEM;
+    uint32_t *starts = NULL; char *sam = NULL; size_t samcap = 0, samn = 0;
+    int rc = packer_init(S, po, errbuf, errlen);
+    if (rc) goto done;
+    cbc_packed *P = S->P;
+    rng_t R; uint64_t sd = so->seed;
+    for (int i = 0; i < 4; i++) R.s[i] = splitmix64(&sd);
+    /* contig */
+    if (grow((void **)&P->ref, &P->cap_ref, so->contig_len + CBC_REF_PAD, 1)) { rc = CBC_E_NOMEM; goto done; }
+    for (uint64_t i = 0; i < so->contig_len; i += 32) {
+        uint64_t w = rng_next(&R);
+        for (int k = 0; k < 32 && i + k < so->contig_len; k++) { P->ref[i + k] = (uint8_t)ACGT[w & 3]; w >>= 2; }
+    }
+    memset(P->ref + so->contig_len, 0, CBC_REF_PAD);
+    P->ref_bytes = so->contig_len + CBC_REF_PAD;
+    if (grow32((void **)&P->contigs, &P->cap_contigs, 1, sizeof(cbc_contig_info))) { rc = CBC_E_NOMEM; goto done; }
+    P->contigs[0].ref_off = 0; P->contigs[0].length = so->contig_len; P->contigs[0].name_off = 0; P->contigs[0].reserved = 0;
+    S->n_fasta = 1;
+    P->read_length = L;
+    /* sorted start positions */
+    starts = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(so->n_reads ? so->n_reads : 1));
+    if (!starts) { rc = CBC_E_NOMEM; goto done; }
+    uint64_t span = so->contig_len - L - 8;
+    for (uint64_t i = 0; i < so->n_reads; i++) starts[i] = (uint32_t)rng_below(&R, span);
+    qsort(starts, (size_t)so->n_reads, sizeof(uint32_t), cmp_u32);
+    char seq[LINE_BUF], cigar[64], md[4 * LINE_BUF], qual[LINE_BUF];
+    memset(qual, 'I', L); qual[L] = 0;
+    for (uint64_t i = 0; i < so->n_reads; i++) {
+        const uint8_t *ref = P->ref + starts[i];
+        uint32_t flag = (rng_next(&R) & 1) ? 16u : 0u;
+        int has_indel = rng_unit(&R) < so->indel_frac;
+        uint32_t o = 0, k = 0; int is_ins = 0;
+        if (has_indel) { k = 1 + (uint32_t)rng_below(&R, 3); o = 10 + (uint32_t)rng_below(&R, L - 20 - k); is_ins = (int)(rng_next(&R) & 1); }
+        /* assemble read and the per-base reference it aligns to (0 = inserted base) */
+        uint8_t rb[LINE_BUF]; uint32_t q = 0, rp = 0, nm = 0;
+        if (!has_indel) { memcpy(seq, ref, L); memcpy(rb, ref, L); }
+        else if (is_ins) {
+            for (q = 0; q < o; q++) { seq[q] = (char)ref[rp]; rb[q] = ref[rp++]; }
+            for (uint32_t c = 0; c < k; c++, q++) { seq[q] = ACGT[rng_next(&R) & 3]; rb[q] = 0; }
+            for (; q < L; q++) { seq[q] = (char)ref[rp]; rb[q] = ref[rp++]; }
+        } else {
+            for (q = 0; q < o; q++) { seq[q] = (char)ref[rp]; rb[q] = ref[rp++]; }
+            rp += k;
+            for (; q < L; q++) { seq[q] = (char)ref[rp]; rb[q] = ref[rp++]; }
+        }
+        seq[L] = 0;
+        /* substitutions on aligned bases */
+        int nsub = 0;
+        if (so->sub_rate > 0) {
+            for (uint32_t b = 0; b < L; b++) {
+                if (rb[b] && rng_unit(&R) < so->sub_rate) {
+                    char old = seq[b]; char alt;
+                    do { alt = ACGT[rng_next(&R) & 3]; } while (alt == old);
+                    seq[b] = alt; nsub++;
+                }
+            }
+        }
+        /* CIGAR + MD */
+        if (!has_indel) snprintf(cigar, sizeof cigar, "%uM", L);
+        else if (is_ins) snprintf(cigar, sizeof cigar, "%uM%uI%uM", o, k, L - o - k);
+        else snprintf(cigar, sizeof cigar, "%uM%uD%uM", o, k, L - o);
+        {
+            char *m = md; uint32_t run = 0;
+            for (uint32_t b = 0; b < L; b++) {
+                if (has_indel && !is_ins && b == o) {
+                    m += sprintf(m, "%u^", run); run = 0;
+                    for (uint32_t c = 0; c < k; c++) *m++ = (char)ref[o + c];
+                    nm += k;
+                }
+                if (!rb[b]) { nm++; continue; }
+                if ((uint8_t)seq[b] == rb[b]) run++;
+                else { m += sprintf(m, "%u%c", run, (char)rb[b]); run = 0; nm++; }
+            }
+            m += sprintf(m, "%u", run);
+            *m = 0;
+        }
+        rc = add_record(S, name, flag, (int32_t)starts[i] + 1, cigar, seq, md);
+        if (rc) goto done;
+        if (sam_out) {
+            if (samn + 2 * LINE_BUF > samcap) {
+                size_t nc = samcap ? samcap * 2 : (1u << 20);
+                char *ns = (char *)realloc(sam, nc); if (!ns) { rc = CBC_E_NOMEM; goto done; }
+                sam = ns; samcap = nc;
+            }
+            samn += (size_t)sprintf(sam + samn, "r%llu\t%u\t%s\t%u\t60\t%s\t*\t0\t0\t%s\t%s\tMD:Z:%s\tNM:i:%u\n",
+                                    (unsigned long long)i, flag, name, starts[i] + 1, cigar, seq, qual, md, nm);
+        }
+    }
+    rc = finish_pack(S);
+    if (rc) goto done;
+    if (sam_out) {
+        if (!sam) { sam = (char *)malloc(1); if (!sam) { rc = CBC_E_NOMEM; goto done; } }
+        *sam_out = sam; *sam_len = samn; sam = NULL;
+    }
+    if (fasta_out) {
+        uint64_t nlines = (so->contig_len + 59) / 60;
+        size_t cap = (size_t)(so->contig_len + nlines + strlen(name) + 8);
+        char *fa = (char *)malloc(cap); if (!fa) { rc = CBC_E_NOMEM; goto done; }
+        size_t n = (size_t)sprintf(fa, ">%s\n", name);
+        for (uint64_t i = 0; i < so->contig_len; i += 60) {
+            uint64_t c = so->contig_len - i < 60 ? so->contig_len - i : 60;
+            memcpy(fa + n, P->ref + i, (size_t)c); n += (size_t)c; fa[n++] = '\n';
+        }
+        *fasta_out = fa; *fasta_len = n;
+    }
+done:
+    free(starts); free(sam);
+    packer_release(S);
+    if (rc) { cbc_packed_free(S->P); *out = NULL; } else *out = S->P;
+    free(S);
+    return rc;
+}
+
+/* ================================= block container ======================================== */
+/* layout (little-endian):
+ *   u32 magic "CBCB", u32 version, u32 read_length, u32 n_contigs, u32 n_blocks, u32 names_bytes
+ *   names blob, padded to 4
+ *   n_contigs x { u32 name_off, u32 reserved, u64 length }
+ *   n_blocks  x { u32 contig, u32 n_reads, u64 window_start, u64 payload_off, u32 payload_bytes, u32 reserved }
+ *   payloads, concatenated in block order
+ */
+static uint64_t container_header_bytes(const cbc_packed *p)
+{
+    return 24ull + ((p->names_bytes + 3u) & ~3u) + 16ull * p->n_contigs + 32ull * p->n_blocks;
+}
+API int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets)
+{
+    if (!p || !out_offsets) return CBC_E_ARG;
+    return (int64_t)(container_header_bytes(p) + out_offsets[p->n_blocks]);
+}
+static void w32(uint8_t **d, uint32_t v) { memcpy(*d, &v, 4); *d += 4; }
+static void w64(uint8_t **d, uint64_t v) { memcpy(*d, &v, 8); *d += 8; }
+API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
+                                uint8_t *dst, uint64_t dst_cap)
+{
+    if (!p || !payloads || !out_offsets || !dst) return CBC_E_ARG;
+    uint64_t hb = container_header_bytes(p), total = hb + out_offsets[p->n_blocks];
+    if (dst_cap < total) return CBC_E_ARG;
+    uint8_t *d = dst;
+    w32(&d, CBC_CONTAINER_MAGIC); w32(&d, CBC_CONTAINER_VERSION); w32(&d, p->read_length);
+    w32(&d, p->n_contigs); w32(&d, p->n_blocks); w32(&d, p->names_bytes);
+    uint32_t nb = (p->names_bytes + 3u) & ~3u;
+    memset(d, 0, nb); memcpy(d, p->names, p->names_bytes); d += nb;
+    for (uint32_t i = 0; i < p->n_contigs; i++) { w32(&d, p->contigs[i].name_off); w32(&d, 0); w64(&d, p->contigs[i].length); }
+    for (uint32_t b = 0; b < p->n_blocks; b++) {
+        w32(&d, p->info[b].contig); w32(&d, p->info[b].n_reads); w64(&d, p->info[b].window_start);
+        w64(&d, out_offsets[b]); w32(&d, (uint32_t)(out_offsets[b + 1] - out_offsets[b])); w32(&d, 0);
+    }
+    memcpy(d, payloads, (size_t)out_offsets[p->n_blocks]);
+    return (int64_t)total;
+}

@@ -1,0 +1,47 @@
+/*
+ * cbc_plan.h -- host-side sizing helpers shared by the C ABI implementation (cbc_gpu.hip) and the
+ * test emulation driver: LDS bytes per wavefront and the worst-case payload area per block.
+ */
+#ifndef CBC_PLAN_H
+#define CBC_PLAN_H
+
+#include <stdint.h>
+#include <string.h>
+#include "../../include/cbc_gpu.h"
+
+/* must match CBC_LDS_FIXED in cbc_encode_body.h */
+#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME)
+
+static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
+{
+    return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 2u * caps->cap_pos + caps->cap_var);
+}
+
+/* Upper bound on the payload of a block.  Every model total stays below 2^20, so one coded symbol
+ * costs < 20 bits; 3 bytes per symbol leaves slack for the 26-bit flush.  Symbols per record:
+ * same_ref 1 + rlength 4 + pos <=5 + flag 1 + match 1 = 12, plus for an imperfect read <= 4 count
+ * symbols and 2 per edit (var + chars); stream header 136, contig name + sentinel <= 2*CAP_NAME. */
+static inline uint64_t cbc_plan_output(cbc_block_desc *blocks, uint32_t n_blocks,
+                                       const cbc_read_rec *recs, const uint32_t *tok)
+{
+    uint64_t off = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        cbc_block_desc *bd = &blocks[b];
+        uint64_t nsym = 136u + 2u * CBC_CAP_NAME + 16ull * bd->n_reads;
+        for (uint32_t r = 0; r < bd->n_reads; r++) {
+            const cbc_read_rec *rr = &recs[bd->rec_base + r];
+            const uint32_t *t = tok + bd->tok_base + rr->tok_off;
+            uint32_t n_cig = t[0] & 0xffffu, n_md = t[0] >> 16;
+            uint64_t ev = n_md;
+            for (uint32_t k = 0; k < n_cig; k++) if ((t[1 + k] & 15u) != CBC_OP_M) ev += t[1 + k] >> 4;
+            nsym += 2 * ev;
+        }
+        uint64_t cap = (3 * nsym + 256 + 255) & ~255ull;
+        if (cap > 0xffffff00ull) cap = 0xffffff00ull;
+        bd->out_off = off; bd->out_cap = (uint32_t)cap;
+        off += cap;
+    }
+    return off;
+}
+
+#endif

@@ -1,0 +1,85 @@
+/*
+ * cbc_wave_gpu.h -- the 64-lane wavefront primitives the codec body is written against, gfx950.
+ *
+ * The codec body (cbc_encode_body.h) is a template over a "wave" policy W so that the exact same
+ * control flow can be single-stepped on a CPU lock-step emulation in tests/emu (debugging aid
+ * only: the product has no CPU path).  On the GPU a per-lane value is a plain uint32_t held in a
+ * VGPR, wave-uniform values are plain scalars the compiler keeps in SGPRs, and every branch in
+ * the body is wave-uniform.
+ */
+#ifndef CBC_WAVE_GPU_H
+#define CBC_WAVE_GPU_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CBC_FN __device__ __forceinline__
+#define CBC_MFN __device__ __forceinline__
+
+struct WaveGPU {
+    typedef uint32_t V32;   /* one 32-bit value per lane  */
+    typedef bool     Mask;  /* one predicate per lane     */
+
+    static CBC_FN V32 lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+    static CBC_FN V32 splat(uint32_t x) { return x; }
+    static CBC_FN Mask all() { return true; }
+    static CBC_FN V32 select(Mask m, V32 a, V32 b) { return m ? a : b; }
+    static CBC_FN uint64_t ballot(Mask m) { return __ballot(m); }
+    /* make a value the compiler cannot prove uniform a scalar (it IS uniform by construction) */
+    static CBC_FN uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    static CBC_FN uint32_t readlane(V32 v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni(k)); }
+
+    /* sum over the 64 lanes: inclusive DPP scan inside each row of 16, then row_bcast15 /
+     * row_bcast31 carry the row totals up; lane 63 ends with the wave total. */
+    static CBC_FN uint32_t reduce_add(V32 v)
+    {
+        int x = (int)v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   /* row_shr:1 */
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   /* row_shr:2 */
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   /* row_shr:4 */
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   /* row_shr:8 */
+        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   /* row_bcast:15 -> rows 1,3 */
+        x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   /* row_bcast:31 -> rows 2,3 */
+        return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+    }
+
+    /* per-lane gathers / scatters; `m` false = lane does not touch memory */
+    static CBC_FN V32 load32(const uint32_t *p, V32 idx, Mask m, uint32_t other) { return m ? p[idx] : other; }
+    static CBC_FN void store32(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) p[idx] = val; }
+    /* 4 bytes at an arbitrary byte offset (global memory handles unaligned dwords) */
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    static CBC_FN V32 load32_bytes(const uint8_t *p, V32 byteoff, Mask m)
+    {
+        return m ? *(const u32_unaligned *)(p + byteoff) : 0u;
+    }
+    /* 16-byte record gather (cbc_read_rec) */
+    static CBC_FN void load_rec(const uint4 *p, V32 idx, Mask m, V32 &a, V32 &b, V32 &c, V32 &d)
+    {
+        uint4 r = m ? p[idx] : make_uint4(0, 0, 0, 0);
+        a = r.x; b = r.y; c = r.z; d = r.w;
+    }
+    /* wave-uniform reads (same address in every lane) */
+    static CBC_FN uint32_t read_uni(const uint32_t *p, uint32_t idx) { return uni(p[idx]); }
+    static CBC_FN uint32_t read_uni8(const uint8_t *p, uint32_t idx) { return uni((uint32_t)p[idx]); }
+    /* wave-uniform write: one lane stores */
+    static CBC_FN void write_uni(uint32_t *p, uint32_t idx, uint32_t val) { if (lane() == 0) p[idx] = val; }
+
+    /* floor(range * c / n) for range <= 2^26, c <= n < 2^20 + 2^16.  One IEEE double reciprocal
+     * estimate can only truncate one below the true quotient (|error| < 2^-25 on a quotient that
+     * is either an integer or at least 2^-20 away from one), so a single upward fix-up is exact. */
+    static CBC_FN uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, double inv_n)
+    {
+        uint64_t p = (uint64_t)range * c;
+        uint32_t q = (uint32_t)((double)p * inv_n);
+        uint64_t r = p - (uint64_t)q * n;
+        return r >= n ? q + 1 : q;
+    }
+    static CBC_FN double recip(uint32_t n) { return 1.0 / (double)n; }
+
+    static CBC_FN uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }       /* x != 0 */
+    static CBC_FN uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }     /* x != 0 */
+    static CBC_FN uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+    static CBC_FN uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+};
+
+#endif

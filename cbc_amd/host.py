@@ -1,0 +1,244 @@
+"""ctypes view of libcbc_host.so (the plain-C host side: packer, container, synthetic workload).
+
+Mirrors, for the hot path only, the reference's record loader / FASTA loader seam
+(src/sam_file_allocation.c:437-529, src/read_decompression.c:17-53): text in, packed blocks out.
+Python is plumbing here; the work is done by cbc_amd/csrc/cbc_pack.c.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+HOST_LIB = os.path.join(_CSRC, "libcbc_host.so")
+
+CBC_CAP_FLAG = 64
+CBC_CAP_NAME = 128
+CBC_REF_PAD = 512
+CBC_MAX_READ_LEN = 252
+
+
+class ReadRec(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_uint32), ("flag", ctypes.c_uint16), ("rlen", ctypes.c_uint16),
+                ("seq_off", ctypes.c_uint32), ("tok_off", ctypes.c_uint32)]
+
+
+class BlockDesc(ctypes.Structure):
+    _fields_ = [("rec_base", ctypes.c_uint64), ("seq_base", ctypes.c_uint64), ("tok_base", ctypes.c_uint64),
+                ("ref_off", ctypes.c_uint64), ("out_off", ctypes.c_uint64), ("out_cap", ctypes.c_uint32),
+                ("n_reads", ctypes.c_uint32), ("name_off", ctypes.c_uint32), ("read_length", ctypes.c_uint32),
+                ("n_tok", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class BlockResult(ctypes.Structure):
+    _fields_ = [("nbytes", ctypes.c_uint32), ("status", ctypes.c_uint32), ("n_symbols", ctypes.c_uint32),
+                ("fail_read", ctypes.c_uint32)]
+
+
+class BlockInfo(ctypes.Structure):
+    _fields_ = [("contig", ctypes.c_uint32), ("n_reads", ctypes.c_uint32), ("window_start", ctypes.c_uint64),
+                ("n_bases", ctypes.c_uint64)]
+
+
+class ContigInfo(ctypes.Structure):
+    _fields_ = [("ref_off", ctypes.c_uint64), ("length", ctypes.c_uint64), ("name_off", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+class LdsCaps(ctypes.Structure):
+    _fields_ = [("cap_pos", ctypes.c_uint32), ("cap_var", ctypes.c_uint32)]
+
+
+class Packed(ctypes.Structure):
+    _fields_ = [
+        ("recs", ctypes.POINTER(ReadRec)), ("n_recs", ctypes.c_uint64),
+        ("seq", ctypes.POINTER(ctypes.c_uint8)), ("seq_bytes", ctypes.c_uint64),
+        ("tok", ctypes.POINTER(ctypes.c_uint32)), ("n_tok", ctypes.c_uint64),
+        ("names", ctypes.POINTER(ctypes.c_uint8)), ("names_bytes", ctypes.c_uint32),
+        ("blocks", ctypes.POINTER(BlockDesc)), ("n_blocks", ctypes.c_uint32),
+        ("info", ctypes.POINTER(BlockInfo)),
+        ("contigs", ctypes.POINTER(ContigInfo)), ("n_contigs", ctypes.c_uint32),
+        ("ref", ctypes.POINTER(ctypes.c_uint8)), ("ref_bytes", ctypes.c_uint64),
+        ("caps", LdsCaps),
+        ("read_length", ctypes.c_uint32),
+        ("n_bases", ctypes.c_uint64),
+        ("n_skipped_unmapped", ctypes.c_uint64),
+        ("cap_recs", ctypes.c_uint64), ("cap_seq", ctypes.c_uint64), ("cap_tok", ctypes.c_uint64),
+        ("cap_ref", ctypes.c_uint64), ("cap_names", ctypes.c_uint32), ("cap_blocks", ctypes.c_uint32),
+        ("cap_contigs", ctypes.c_uint32),
+    ]
+
+
+class PackOpts(ctypes.Structure):
+    _fields_ = [("block_reads", ctypes.c_uint32), ("max_cap_pos", ctypes.c_uint32),
+                ("max_cap_var", ctypes.c_uint32), ("var_length", ctypes.c_uint32)]
+
+
+class SynthOpts(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("contig_len", ctypes.c_uint64), ("n_reads", ctypes.c_uint64),
+                ("read_len", ctypes.c_uint32), ("sub_rate", ctypes.c_double), ("indel_frac", ctypes.c_double),
+                ("name", ctypes.c_char_p)]
+
+
+class CbcInputError(ValueError):
+    """The input violates a limit of the reference format (message from the packer)."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError("libcbc_host.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C cbc_amd/csrc`")
+        L = ctypes.CDLL(HOST_LIB)
+        L.cbc_pack_default_opts.argtypes = [ctypes.POINTER(PackOpts)]
+        L.cbc_pack_sam.restype = ctypes.c_int
+        L.cbc_pack_sam.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                   ctypes.POINTER(PackOpts), ctypes.POINTER(ctypes.POINTER(Packed)),
+                                   ctypes.c_char_p, ctypes.c_size_t]
+        L.cbc_packed_free.argtypes = [ctypes.POINTER(Packed)]
+        L.cbc_synth_packed.restype = ctypes.c_int
+        L.cbc_synth_packed.argtypes = [ctypes.POINTER(SynthOpts), ctypes.POINTER(PackOpts),
+                                       ctypes.POINTER(ctypes.POINTER(Packed)),
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                       ctypes.c_char_p, ctypes.c_size_t]
+        L.cbc_free.argtypes = [ctypes.c_void_p]
+        L.cbc_container_size.restype = ctypes.c_int64
+        L.cbc_container_size.argtypes = [ctypes.POINTER(Packed), ctypes.POINTER(ctypes.c_uint64)]
+        L.cbc_container_write.restype = ctypes.c_int64
+        L.cbc_container_write.argtypes = [ctypes.POINTER(Packed), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
+                                          ctypes.c_void_p, ctypes.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False):
+    o = PackOpts()
+    lib().cbc_pack_default_opts(ctypes.byref(o))
+    if block_reads is not None:
+        o.block_reads = block_reads
+    if max_cap_pos is not None:
+        o.max_cap_pos = max_cap_pos
+    if max_cap_var is not None:
+        o.max_cap_var = max_cap_var
+    o.var_length = 1 if var_length else 0
+    return o
+
+
+def _np_view(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    addr = ctypes.addressof(ptr.contents)
+    nbytes = int(n) * np.dtype(dtype).itemsize
+    buf = (ctypes.c_uint8 * nbytes).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+REC_DTYPE = np.dtype([("pos", "<u4"), ("flag", "<u2"), ("rlen", "<u2"), ("seq_off", "<u4"), ("tok_off", "<u4")])
+BLOCK_DTYPE = np.dtype([("rec_base", "<u8"), ("seq_base", "<u8"), ("tok_base", "<u8"), ("ref_off", "<u8"),
+                        ("out_off", "<u8"), ("out_cap", "<u4"), ("n_reads", "<u4"), ("name_off", "<u4"),
+                        ("read_length", "<u4"), ("n_tok", "<u4"), ("reserved", "<u4")])
+RESULT_DTYPE = np.dtype([("nbytes", "<u4"), ("status", "<u4"), ("n_symbols", "<u4"), ("fail_read", "<u4")])
+INFO_DTYPE = np.dtype([("contig", "<u4"), ("n_reads", "<u4"), ("window_start", "<u8"), ("n_bases", "<u8")])
+CONTIG_DTYPE = np.dtype([("ref_off", "<u8"), ("length", "<u8"), ("name_off", "<u4"), ("reserved", "<u4")])
+assert REC_DTYPE.itemsize == 16 and BLOCK_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
+
+
+class PackedBatch:
+    """Owns a cbc_packed* and exposes its arrays as numpy views (zero copy)."""
+
+    def __init__(self, ptr):
+        self._ptr = ptr
+        p = ptr.contents
+        self.recs = _np_view(p.recs, p.n_recs, REC_DTYPE)
+        self.seq = _np_view(p.seq, p.seq_bytes, np.uint8)
+        self.tok = _np_view(p.tok, max(int(p.n_tok), 1), np.uint32)
+        self.names = _np_view(p.names, p.names_bytes, np.uint8)
+        self.blocks = _np_view(p.blocks, p.n_blocks, BLOCK_DTYPE)
+        self.info = _np_view(p.info, p.n_blocks, INFO_DTYPE)
+        self.contigs = _np_view(p.contigs, p.n_contigs, CONTIG_DTYPE)
+        self.ref = _np_view(p.ref, p.ref_bytes, np.uint8)
+        self.cap_pos = int(p.caps.cap_pos)
+        self.cap_var = int(p.caps.cap_var)
+        self.read_length = int(p.read_length)
+        self.n_bases = int(p.n_bases)
+        self.n_recs = int(p.n_recs)
+        self.n_tok = int(p.n_tok)
+        self.n_blocks = int(p.n_blocks)
+        self.n_skipped_unmapped = int(p.n_skipped_unmapped)
+
+    @property
+    def c_ptr(self):
+        return self._ptr
+
+    def contig_name(self, ci):
+        off = int(self.contigs[ci]["name_off"])
+        raw = self.names[off:].tobytes()
+        return raw[:raw.index(b"\0")]
+
+    def container(self, payloads: np.ndarray, out_offsets: np.ndarray) -> bytes:
+        offs = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        po = offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+        n = lib().cbc_container_size(self._ptr, po)
+        if n < 0:
+            raise RuntimeError("cbc_container_size failed: %d" % n)
+        dst = np.zeros(int(n), dtype=np.uint8)
+        pl = np.ascontiguousarray(payloads, dtype=np.uint8)
+        w = lib().cbc_container_write(self._ptr, pl.ctypes.data, po, dst.ctypes.data, int(n))
+        if w != n:
+            raise RuntimeError("cbc_container_write failed: %d" % w)
+        return dst.tobytes()
+
+    def close(self):
+        if self._ptr is not None:
+            # drop the numpy views before the C memory goes away
+            for k in ("recs", "seq", "tok", "names", "blocks", "info", "contigs", "ref"):
+                setattr(self, k, None)
+            lib().cbc_packed_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_sam(sam: bytes, fasta: bytes, **kw) -> PackedBatch:
+    """SAM text + FASTA text -> packed blocks (the load_sam_line / store_reference_in_memory seam)."""
+    o = _opts(**kw)
+    out = ctypes.POINTER(Packed)()
+    err = ctypes.create_string_buffer(512)
+    rc = lib().cbc_pack_sam(sam, len(sam), fasta, len(fasta), ctypes.byref(o), ctypes.byref(out), err, 512)
+    if rc != 0:
+        raise CbcInputError("cbc_pack_sam failed (%d): %s" % (rc, err.value.decode(errors="replace")))
+    return PackedBatch(out)
+
+
+def synth(seed, contig_len, n_reads, read_len=150, sub_rate=0.003, indel_frac=0.02, name=b"chr1",
+          want_text=False, **kw):
+    """Seeded synthetic workload.  Returns PackedBatch, or (PackedBatch, sam, fasta)."""
+    so = SynthOpts(seed, contig_len, n_reads, read_len, sub_rate, indel_frac, name)
+    o = _opts(**kw)
+    out = ctypes.POINTER(Packed)()
+    err = ctypes.create_string_buffer(512)
+    sam_p, fa_p = ctypes.c_void_p(), ctypes.c_void_p()
+    sam_n, fa_n = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = lib().cbc_synth_packed(ctypes.byref(so), ctypes.byref(o), ctypes.byref(out),
+                                ctypes.byref(sam_p) if want_text else None, ctypes.byref(sam_n),
+                                ctypes.byref(fa_p) if want_text else None, ctypes.byref(fa_n), err, 512)
+    if rc != 0:
+        raise CbcInputError("cbc_synth_packed failed (%d): %s" % (rc, err.value.decode(errors="replace")))
+    pb = PackedBatch(out)
+    if not want_text:
+        return pb
+    sam = ctypes.string_at(sam_p, sam_n.value)
+    fa = ctypes.string_at(fa_p, fa_n.value)
+    lib().cbc_free(sam_p)
+    lib().cbc_free(fa_p)
+    return pb, sam, fa

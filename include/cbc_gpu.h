@@ -1,0 +1,187 @@
+/*
+ * cbc_gpu.h -- C ABI of the MI355X-native cbc hot path (libcbc_gpu.so, built from cbc_amd/csrc).
+ *
+ * The reference (1mishra/cbc) has no plugin/FFI seam: its hot path sits behind a CLI and a file
+ * format.  The entry points below are what a maintainer would bind in
+ * place of the per-file encode loop
+ *      compress()              src/compression.c:112-170
+ *        compress_line()       src/compression.c:42-69
+ *          compress_rname()    src/id_compression.c:39-65
+ *          compress_read()     src/read_compression.c:15-44   (pos/flag/match/edits/var/chars)
+ *            send_value_to_as  src/stream_model.c:53-76  + update_model :31-51
+ *            arithmetic_encoder_step  src/Arithmetic_stream.c:274-345
+ *        encoder_last_step()   src/Arithmetic_stream.c:348-371
+ * operating on *packed* records (the output of the load_sam_line() tokeniser,
+ * src/sam_file_allocation.c:437-529) instead of SAM text.
+ *
+ * Unit of work: a BLOCK = up to N consecutive records of one contig, with POS rebased so that
+ * the block's first record has POS 1.  The payload produced for a block is byte-identical to the
+ * file the reference encoder (built with -DDEBUG, i.e. constant WELL seed) writes when it is run
+ * on that block alone: a SAM holding just those records with the rebased POS and a one-contig
+ * FASTA holding the reference window that starts at the block's first base.  One block is one
+ * independent arithmetic stream and is coded by one wavefront.
+ *
+ * Plain C: pointers and sizes only, caller owns every buffer, no global state, every function
+ * returns 0 on success or a negative CBC_E_* code.  One host thread per context.
+ */
+#ifndef CBC_GPU_H
+#define CBC_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBC_ABI_VERSION 1
+
+/* ---- error / status codes ---------------------------------------------------------------- */
+#define CBC_OK              0
+#define CBC_E_ARG          -1   /* bad argument                                                */
+#define CBC_E_NODEV        -2   /* no HIP device / HIP runtime error (see cbc_gpu_last_error)   */
+#define CBC_E_NOMEM        -3
+#define CBC_E_BLOCK        -4   /* at least one block finished with status != CBC_ST_OK         */
+#define CBC_E_INPUT        -5   /* input violates a reference limit (message in last_error)     */
+#define CBC_E_IO           -6
+
+/* per-block status written by the kernel (cbc_block_result.status) */
+#define CBC_ST_OK           0
+#define CBC_ST_OUT_FULL     1   /* out_cap too small                                            */
+#define CBC_ST_ASSERT       2   /* the reference would abort here: zero-count symbol, symbol >= */
+                                /* alphabet, unsorted POS, var context >= 65535 ...             */
+#define CBC_ST_CAP_POS      3   /* more distinct POS deltas than lds.cap_pos                    */
+#define CBC_ST_CAP_FLAG     4   /* more than CBC_CAP_FLAG distinct FLAG values                  */
+#define CBC_ST_CAP_VAR      5   /* more var symbols than lds.cap_var                            */
+#define CBC_ST_CAP_NAME     6   /* contig name longer than CBC_CAP_NAME-3                       */
+#define CBC_ST_UNSUPPORTED  7   /* leading soft clip / '*' CIGAR           */
+
+/* ---- packed record layout (device and host share it) ---------------------------------------- */
+
+/* One per mapped record, 16 bytes, array-of-structs so a wavefront loads 64 records with one
+ * 16-byte-per-lane coalesced access.  Mirrors struct read_line_t (include/sam_block.h:177-185). */
+typedef struct cbc_read_rec {
+    uint32_t pos;       /* POS, 1-based, relative to the block's reference window               */
+    uint16_t flag;      /* SAM FLAG (read_line_t.invFlag)                                       */
+    uint16_t rlen;      /* strlen(SEQ), <= CBC_MAX_READ_LEN                                     */
+    uint32_t seq_off;   /* byte offset of SEQ in seq[], relative to the block's seq_base        */
+    uint32_t tok_off;   /* word offset of the CIGAR/MD tokens in tok[], relative to tok_base    */
+} cbc_read_rec;
+
+/* Token stream of one record at tok[tok_base + tok_off]:
+ *   word 0            : n_cigar | (n_md << 16)
+ *   n_cigar words     : (len << 4) | op      op: CBC_OP_M/I/D/S/STAR; len = atoi() of the CIGAR
+ *                       segment exactly as compress_edits() reads it (read_compression.c:308-352)
+ *   n_md words        : (gap << 8) | letter  one per mismatch letter of MD:Z, gap = matched bases
+ *                       since the previous mismatch (numbers on both sides of a '^' run add up,
+ *                       add_snps_to_array read_compression.c:613-701); letter is the raw byte,
+ *                       so the trailing '\n' of an MD that is the last column survives (quirk Q2)
+ */
+#define CBC_OP_M    0u
+#define CBC_OP_I    1u
+#define CBC_OP_D    2u
+#define CBC_OP_S    3u
+#define CBC_OP_STAR 4u
+
+/* One per block, 64 bytes. */
+typedef struct cbc_block_desc {
+    uint64_t rec_base;     /* index of the block's first cbc_read_rec                           */
+    uint64_t seq_base;     /* byte offset of the block's bases in seq[]                         */
+    uint64_t tok_base;     /* word offset of the block's tokens in tok[]                        */
+    uint64_t ref_off;      /* byte offset in the device reference of the base that is POS 1     */
+    uint64_t out_off;      /* byte offset of this block's payload area in out[] (4-aligned)     */
+    uint32_t out_cap;      /* bytes available at out_off (multiple of 256)                      */
+    uint32_t n_reads;
+    uint32_t name_off;     /* offset in names[] of the NUL-terminated contig name               */
+    uint32_t read_length;  /* header read length L0 (get_read_length, sam_file_allocation.c:26) */
+    uint32_t n_tok;        /* words of tok[] owned by this block (bounds the token prefetch)    */
+    uint32_t reserved;
+} cbc_block_desc;
+
+typedef struct cbc_block_result {
+    uint32_t nbytes;       /* payload bytes written at out_off                                  */
+    uint32_t status;       /* CBC_ST_*                                                          */
+    uint32_t n_symbols;    /* arithmetic-coder steps taken                                      */
+    uint32_t fail_read;    /* block-local index of the record being coded when status was set   */
+} cbc_block_result;
+
+/* limits of the LDS-resident model tables; the packer cuts blocks so that they hold */
+#define CBC_MAX_READ_LEN   252u    /* var context (((L+2)<<7)+L)*2+1 must stay < 65535 (sam_models.c:317) */
+#define CBC_CAP_FLAG       64u     /* distinct FLAG values per block                              */
+#define CBC_CAP_NAME       128u    /* (context,char) pairs of the contig-name model               */
+#define CBC_MAX_BLOCK_READS 16384u /* keeps every adaptive total below the 2^20 rescale point     */
+#define CBC_REF_PAD        512u    /* zero bytes the caller appends after every contig            */
+#define CBC_WELL_SEED      0x55555555u  /* sam_file_allocation.c:399, the -DDEBUG constant         */
+
+typedef struct cbc_lds_caps {
+    uint32_t cap_pos;      /* entries of the POS-delta alphabet (>= max distinct deltas + 1)     */
+    uint32_t cap_var;      /* var-symbol events (>= max var symbols per block)                   */
+} cbc_lds_caps;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+typedef struct cbc_gpu_ctx cbc_gpu_ctx;
+
+int  cbc_gpu_abi_version(void);
+int  cbc_gpu_device_count(void);
+int  cbc_gpu_init(int device_ordinal, cbc_gpu_ctx **ctx);
+int  cbc_gpu_shutdown(cbc_gpu_ctx *ctx);
+const char *cbc_gpu_last_error(cbc_gpu_ctx *ctx);
+
+/* Upload the reference the blocks' ref_off point into: upper-cased contig bases, one byte per
+ * base, each contig followed by CBC_REF_PAD zero bytes (what store_reference_in_memory,
+ * src/read_decompression.c:17-53, keeps in `reference[]`, for all contigs at once). */
+int  cbc_gpu_upload_reference(cbc_gpu_ctx *ctx, const uint8_t *bases, uint64_t nbytes);
+
+/* Host-buffer entry point: copies the batch to the device, codes every block, copies the payloads
+ * back *compacted*: block b's payload is out[out_offsets[b] .. out_offsets[b+1]).  `blocks[].out_off`
+ * and `.out_cap` are filled in by the library.  results may be NULL. */
+typedef struct cbc_host_batch {
+    const cbc_read_rec   *recs;   uint64_t n_recs;
+    const uint8_t        *seq;    uint64_t seq_bytes;
+    const uint32_t       *tok;    uint64_t n_tok;
+    const uint8_t        *names;  uint32_t names_bytes;
+    cbc_block_desc       *blocks; uint32_t n_blocks;
+    cbc_lds_caps          caps;
+} cbc_host_batch;
+
+int  cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *batch,
+                           uint8_t *out, uint64_t out_cap, uint64_t *out_offsets /* n_blocks+1 */,
+                           cbc_block_result *results /* n_blocks or NULL */);
+
+/* Device-pointer entry point (what bench.py and the multi-GPU host use): every pointer is a
+ * device address, the launch is asynchronous on `hip_stream` (a hipStream_t, NULL = the context's
+ * own stream).  out_off/out_cap in d_blocks must already be set (cbc_gpu_plan_output). */
+typedef struct cbc_device_batch {
+    const cbc_read_rec   *d_recs;
+    const uint8_t        *d_seq;
+    const uint32_t       *d_tok;
+    const uint8_t        *d_names;
+    const cbc_block_desc *d_blocks;  uint32_t n_blocks;
+    const uint8_t        *d_ref;     uint64_t ref_bytes;
+    uint8_t              *d_out;     uint64_t out_bytes;
+    cbc_block_result     *d_results;
+    uint64_t              seq_bytes;
+    uint64_t              n_tok;
+    uint64_t              n_recs;
+    cbc_lds_caps          caps;
+} cbc_device_batch;
+
+int  cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *batch, void *hip_stream);
+
+/* Fills blocks[b].out_off / out_cap with a worst-case bound (every coded symbol costs at most 20
+ * bits because every model total stays below 2^20) and returns the scratch bytes needed. */
+uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks,
+                             const cbc_read_rec *recs, const uint32_t *tok);
+
+/* Dynamic LDS bytes one wavefront needs for `caps` (occupancy = 160 KiB / this). */
+uint32_t cbc_gpu_lds_bytes(const cbc_lds_caps *caps);
+
+/* Timing of the most recent encode launch made through this context, measured with HIP events
+ * recorded on the launch stream around the kernel (valid after the stream has been synchronised). */
+int  cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms);
+int  cbc_gpu_synchronize(cbc_gpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBC_GPU_H */

@@ -1,0 +1,100 @@
+/*
+ * cbc_host.h -- host side of the cbc hot path (libcbc_host.so, plain C): the record packer that
+ * stands where the reference's tokeniser and FASTA loader stand, the block container, and the
+ * seeded synthetic workload generator used by bench.py and the parity tests.
+ *
+ *   load_sam_line()              src/sam_file_allocation.c:437-529  -> cbc_pack_sam()
+ *   get_read_length()            src/sam_file_allocation.c:26-79    -> cbc_packed.read_length
+ *   store_reference_in_memory()  src/read_decompression.c:17-53     -> cbc_packed.ref
+ *
+ * No arithmetic coding happens on the host: payload bytes only ever come from the HIP kernels.
+ */
+#ifndef CBC_HOST_H
+#define CBC_HOST_H
+
+#include "cbc_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cbc_block_info {
+    uint32_t contig;        /* index of the contig (order of appearance = FASTA record order)   */
+    uint32_t n_reads;
+    uint64_t window_start;  /* 0-based offset in the contig of the base that is local POS 1      */
+    uint64_t n_bases;       /* sum of SEQ lengths                                                */
+} cbc_block_info;
+
+typedef struct cbc_contig_info {
+    uint64_t ref_off;       /* offset of the contig's first base in cbc_packed.ref               */
+    uint64_t length;
+    uint32_t name_off;      /* offset of its NUL-terminated SAM RNAME in cbc_packed.names        */
+    uint32_t reserved;
+} cbc_contig_info;
+
+typedef struct cbc_packed {
+    cbc_read_rec    *recs;    uint64_t n_recs;
+    uint8_t         *seq;     uint64_t seq_bytes;     /* includes 8 trailing pad bytes            */
+    uint32_t        *tok;     uint64_t n_tok;
+    uint8_t         *names;   uint32_t names_bytes;
+    cbc_block_desc  *blocks;  uint32_t n_blocks;
+    cbc_block_info  *info;
+    cbc_contig_info *contigs; uint32_t n_contigs;
+    uint8_t         *ref;     uint64_t ref_bytes;     /* contigs, each + CBC_REF_PAD zero bytes   */
+    cbc_lds_caps     caps;
+    uint32_t         read_length;                     /* header read length L0                    */
+    uint64_t         n_bases;
+    uint64_t         n_skipped_unmapped;
+    /* allocation bookkeeping (private) */
+    uint64_t cap_recs, cap_seq, cap_tok, cap_ref; uint32_t cap_names, cap_blocks, cap_contigs;
+} cbc_packed;
+
+typedef struct cbc_pack_opts {
+    uint32_t block_reads;   /* records per block (default 4096, max CBC_MAX_BLOCK_READS)          */
+    uint32_t max_cap_pos;   /* cut a block before it needs more POS-delta entries (default 2048)  */
+    uint32_t max_cap_var;   /* cut a block before it can hold more var symbols (default 8192)     */
+    uint32_t var_length;    /* reference's -l: header read length = max over the file             */
+} cbc_pack_opts;
+
+void cbc_pack_default_opts(cbc_pack_opts *o);
+
+/* Tokenise SAM text + FASTA text into packed blocks.  errbuf receives a message on failure. */
+int  cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t fasta_len,
+                  const cbc_pack_opts *opts, cbc_packed **out, char *errbuf, size_t errlen);
+void cbc_packed_free(cbc_packed *p);
+
+/* Seeded synthetic workload: one uniform-ACGT contig of `contig_len`
+ * bases named `name`, `n_reads` reads of `read_len` bases at sorted uniform positions, FLAG in
+ * {0,16}, per-base substitution rate `sub_rate`, `indel_frac` of reads with one 1..3-base
+ * insertion or deletion >= 10 bases from either end, CIGAR M/I/D, MD:Z then NM:i.
+ * Records go through the same path as cbc_pack_sam().  If sam_out/fasta_out are non-NULL the
+ * equivalent SAM and FASTA text is returned too (malloc'ed, caller frees with cbc_free). */
+typedef struct cbc_synth_opts {
+    uint64_t seed;
+    uint64_t contig_len;
+    uint64_t n_reads;
+    uint32_t read_len;
+    double   sub_rate;
+    double   indel_frac;
+    const char *name;
+} cbc_synth_opts;
+
+int  cbc_synth_packed(const cbc_synth_opts *so, const cbc_pack_opts *po, cbc_packed **out,
+                      char **sam_out, size_t *sam_len, char **fasta_out, size_t *fasta_len,
+                      char *errbuf, size_t errlen);
+void cbc_free(void *p);
+
+/* ---- block container (block mode of the CLI) ----------------------------------------------
+ * magic "CBCB", version, header read length, contig table, block index, then the payloads.
+ * Every payload follows the reference's stream grammar byte for byte. */
+#define CBC_CONTAINER_MAGIC 0x42434243u   /* "CBCB" little-endian */
+#define CBC_CONTAINER_VERSION 1u
+
+int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets);
+int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
+                            uint8_t *dst, uint64_t dst_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

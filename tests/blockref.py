@@ -1,0 +1,99 @@
+"""Helpers shared by the parity tests: run a packed batch through an encoder back end and build,
+for every block, the "block alone" SAM + FASTA the reference would be run on, so the oracle can
+produce the expected payload (SURVEY.md section 7 hard part 1: payload == reference on that block)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from cbc_amd import host
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_EMU_DIR = os.path.join(_HERE, "emu")
+
+
+class DeviceBatch(ctypes.Structure):
+    _fields_ = [
+        ("d_recs", ctypes.c_void_p), ("d_seq", ctypes.c_void_p), ("d_tok", ctypes.c_void_p),
+        ("d_names", ctypes.c_void_p), ("d_blocks", ctypes.c_void_p), ("n_blocks", ctypes.c_uint32),
+        ("d_ref", ctypes.c_void_p), ("ref_bytes", ctypes.c_uint64),
+        ("d_out", ctypes.c_void_p), ("out_bytes", ctypes.c_uint64),
+        ("d_results", ctypes.c_void_p),
+        ("seq_bytes", ctypes.c_uint64), ("n_tok", ctypes.c_uint64), ("n_recs", ctypes.c_uint64),
+        ("caps", host.LdsCaps),
+    ]
+
+
+_emu = None
+
+
+def emu_lib():
+    global _emu
+    if _emu is None:
+        subprocess.check_call(["make", "-C", _EMU_DIR, "libcbc_emu.so"], stdout=subprocess.DEVNULL)
+        L = ctypes.CDLL(os.path.join(_EMU_DIR, "libcbc_emu.so"))
+        L.emu_encode_blocks.restype = ctypes.c_int
+        L.emu_encode_blocks.argtypes = [ctypes.POINTER(DeviceBatch)]
+        L.emu_plan_output.restype = ctypes.c_uint64
+        L.emu_plan_output.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        _emu = L
+    return _emu
+
+
+def emu_encode(pb):
+    """Run the kernel body on the CPU wave emulation.  Returns (payload list, results array)."""
+    L = emu_lib()
+    blocks = pb.blocks.copy()
+    total = L.emu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data)
+    out = np.full(int(total), 0xAA, dtype=np.uint8)
+    res = np.zeros(pb.n_blocks, dtype=host.RESULT_DTYPE)
+    db = DeviceBatch(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data,
+                     blocks.ctypes.data, pb.n_blocks, pb.ref.ctypes.data, len(pb.ref), out.ctypes.data, int(total),
+                     res.ctypes.data, len(pb.seq), pb.n_tok, pb.n_recs, host.LdsCaps(pb.cap_pos, pb.cap_var))
+    rc = L.emu_encode_blocks(ctypes.byref(db))
+    if rc != 0:
+        raise RuntimeError("emulation reported an invariant violation (rc=%d)" % rc)
+    payloads = []
+    for b in range(pb.n_blocks):
+        o = int(blocks[b]["out_off"])
+        payloads.append(out[o:o + int(res[b]["nbytes"])].tobytes())
+    return payloads, res
+
+
+def block_alone_inputs(pb, sam_lines, b):
+    """SAM + FASTA text of block b alone: its records with POS rebased to the block window, and the
+    window (from the block's first base to the end of the contig, capped) as a one-contig FASTA."""
+    info = pb.info[b]
+    bd = pb.blocks[b]
+    ci = int(info["contig"])
+    w0 = int(info["window_start"])
+    first = int(bd["rec_base"])
+    n = int(bd["n_reads"])
+    c = pb.contigs[ci]
+    coff, clen = int(c["ref_off"]), int(c["length"])
+    last_pos = int(pb.recs[first + n - 1]["pos"])
+    wend = min(clen, w0 + last_pos + 2 * 256 + 64)
+    window = pb.ref[coff + w0: coff + wend].tobytes()
+    fa = [b">blk\n"]
+    for i in range(0, len(window), 60):
+        fa.append(window[i:i + 60] + b"\n")
+    lines = []
+    for k in range(n):
+        f = sam_lines[first + k].split(b"\t")
+        f[3] = b"%d" % (int(f[3]) - w0)
+        lines.append(b"\t".join(f))
+    return b"".join(lines), b"".join(fa)
+
+
+def mapped_sam_lines(sam: bytes):
+    """Record lines (with their newline) of mapped reads, in file order."""
+    out = []
+    for ln in sam.splitlines(keepends=True):
+        if ln.startswith(b"@") or not ln.strip():
+            continue
+        f = ln.split(b"\t")
+        if int(f[1]) & 4:
+            continue
+        out.append(ln)
+    return out

@@ -1,0 +1,34 @@
+/*
+ * emu_encode.cpp -- runs the HIP kernel BODY (cbc_amd/csrc/cbc_encode_body.h) on the CPU through
+ * the lock-step wave emulation.  DEBUGGING / TEST AID ONLY (see wave_emu.h): it exists so that the
+ * kernel's indexing and control flow can be checked under ASan/UBSan and against the oracle before
+ * anything is launched on a real GPU.  The product never links or loads this.
+ */
+#include <vector>
+#include "wave_emu.h"
+#include "../../cbc_amd/csrc/cbc_encode_body.h"
+#include "../../cbc_amd/csrc/cbc_plan.h"
+
+static int g_emu_errors = 0;
+extern "C" void emu_oob(const char *what) { fprintf(stderr, "[emu] invariant violated: %s\n", what); g_emu_errors++; }
+
+extern "C" __attribute__((visibility("default")))
+int emu_encode_blocks(const cbc_device_batch *b)
+{
+    cbc_enc_args A;
+    A.recs = b->d_recs; A.seq = b->d_seq; A.tok = b->d_tok; A.names = b->d_names; A.blocks = b->d_blocks;
+    A.ref = b->d_ref; A.out = b->d_out; A.results = b->d_results;
+    A.ref_bytes = b->ref_bytes; A.out_bytes = b->out_bytes; A.seq_bytes = b->seq_bytes; A.n_tok = b->n_tok;
+    A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    A.names_bytes = 0x7fffffffu;
+    g_emu_errors = 0;
+    uint32_t words = cbc_plan_lds_bytes(&b->caps) / 4;
+    for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
+        std::vector<uint32_t> lds(words, 0xdeadbeefu);      /* LDS is not zero-initialised on the GPU either */
+        cbc_encode_stream<WaveEmu>(A, blk, lds.data());
+    }
+    return g_emu_errors ? -100 : 0;
+}
+extern "C" __attribute__((visibility("default")))
+uint64_t emu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_read_rec *recs, const uint32_t *tok)
+{ return cbc_plan_output(blocks, n_blocks, recs, tok); }

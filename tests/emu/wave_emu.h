@@ -1,0 +1,102 @@
+/*
+ * wave_emu.h -- 64-lane lock-step emulation of the wave policy used by cbc_amd/csrc (the _body.h files).
+ *
+ * DEBUGGING / TEST AID ONLY.  It lets the kernel body be single-stepped, bounds-checked
+ * (ASan/UBSan) and compared with the oracle on a machine without a GPU, so that a kernel is not
+ * launched on real hardware before its indexing is known to be in range.  It is never built into
+ * the product library and never stands in for the HIP path: cbc_amd fails loudly without a GPU.
+ */
+#ifndef CBC_WAVE_EMU_H
+#define CBC_WAVE_EMU_H
+
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CBC_FN static inline
+#define CBC_MFN inline
+
+struct uint4 { uint32_t x, y, z, w; };
+
+struct EmuMask {
+    bool b[64];
+    EmuMask operator&(const EmuMask &o) const { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = b[i] && o.b[i]; return r; }
+    EmuMask operator|(const EmuMask &o) const { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = b[i] || o.b[i]; return r; }
+    EmuMask operator!() const { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = !b[i]; return r; }
+    EmuMask operator&(bool o) const { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = b[i] && o; return r; }
+};
+
+struct EmuV32 {
+    uint32_t v[64];
+};
+
+#define EMU_BINOP(op)                                                                                   \
+    static inline EmuV32 operator op(const EmuV32 &a, const EmuV32 &b) { EmuV32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b.v[i]; return r; } \
+    static inline EmuV32 operator op(const EmuV32 &a, uint32_t b) { EmuV32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b; return r; }          \
+    static inline EmuV32 operator op(uint32_t a, const EmuV32 &b) { EmuV32 r; for (int i = 0; i < 64; i++) r.v[i] = a op b.v[i]; return r; }
+EMU_BINOP(+) EMU_BINOP(-) EMU_BINOP(*) EMU_BINOP(&) EMU_BINOP(|) EMU_BINOP(^)
+#undef EMU_BINOP
+/* shifts use the low 5 bits of the count, like v_lshlrev_b32 / v_lshrrev_b32 */
+static inline EmuV32 operator<<(const EmuV32 &a, const EmuV32 &b) { EmuV32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] << (b.v[i] & 31u); return r; }
+static inline EmuV32 operator<<(const EmuV32 &a, uint32_t b) { EmuV32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] << (b & 31u); return r; }
+static inline EmuV32 operator>>(const EmuV32 &a, const EmuV32 &b) { EmuV32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] >> (b.v[i] & 31u); return r; }
+static inline EmuV32 operator>>(const EmuV32 &a, uint32_t b) { EmuV32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] >> (b & 31u); return r; }
+
+#define EMU_CMP(op)                                                                                     \
+    static inline EmuMask operator op(const EmuV32 &a, const EmuV32 &b) { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = a.v[i] op b.v[i]; return r; } \
+    static inline EmuMask operator op(const EmuV32 &a, uint32_t b) { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = a.v[i] op b; return r; }
+EMU_CMP(==) EMU_CMP(!=) EMU_CMP(<) EMU_CMP(<=) EMU_CMP(>) EMU_CMP(>=)
+#undef EMU_CMP
+
+extern "C" void emu_oob(const char *what);
+
+struct WaveEmu {
+    typedef EmuV32 V32;
+    typedef EmuMask Mask;
+
+    static V32 lane() { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
+    static V32 splat(uint32_t x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x; return r; }
+    static Mask all() { Mask m; for (int i = 0; i < 64; i++) m.b[i] = true; return m; }
+    static V32 select(const Mask &m, const V32 &a, const V32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? a.v[i] : b.v[i]; return r; }
+    static uint64_t ballot(const Mask &m) { uint64_t r = 0; for (int i = 0; i < 64; i++) if (m.b[i]) r |= 1ull << i; return r; }
+    static uint32_t uni(uint32_t x) { return x; }
+    static uint32_t readlane(const V32 &v, uint32_t k) { if (k >= 64) { emu_oob("readlane index"); return 0; } return v.v[k]; }
+    static uint32_t reduce_add(const V32 &v) { uint32_t s = 0; for (int i = 0; i < 64; i++) s += v.v[i]; return s; }
+
+    static V32 load32(const uint32_t *p, const V32 &idx, const Mask &m, uint32_t other)
+    { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? p[idx.v[i]] : other; return r; }
+    static void store32(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m)
+    { for (int i = 0; i < 64; i++) if (m.b[i]) p[idx.v[i]] = val.v[i]; }
+    static V32 load32_bytes(const uint8_t *p, const V32 &off, const Mask &m)
+    { V32 r; for (int i = 0; i < 64; i++) { uint32_t t = 0; if (m.b[i]) memcpy(&t, p + off.v[i], 4); r.v[i] = t; } return r; }
+    static void load_rec(const uint4 *p, const V32 &idx, const Mask &m, V32 &a, V32 &b, V32 &c, V32 &d)
+    {
+        for (int i = 0; i < 64; i++) {
+            uint4 r = {0, 0, 0, 0};
+            if (m.b[i]) r = p[idx.v[i]];
+            a.v[i] = r.x; b.v[i] = r.y; c.v[i] = r.z; d.v[i] = r.w;
+        }
+    }
+    static uint32_t read_uni(const uint32_t *p, uint32_t idx) { return p[idx]; }
+    static uint32_t read_uni8(const uint8_t *p, uint32_t idx) { return p[idx]; }
+    static void write_uni(uint32_t *p, uint32_t idx, uint32_t val) { p[idx] = val; }
+
+    /* same double-reciprocal formula as the GPU policy, cross-checked against exact integers */
+    static uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, double inv_n)
+    {
+        uint64_t p = (uint64_t)range * c;
+        uint32_t q = (uint32_t)((double)p * inv_n);
+        uint64_t r = p - (uint64_t)q * n;
+        uint32_t res = r >= n ? q + 1 : q;
+        if (res != (uint32_t)(p / n)) emu_oob("muldiv double-reciprocal mismatch");
+        return res;
+    }
+    static double recip(uint32_t n) { return 1.0 / (double)n; }
+    static uint32_t clz32(uint32_t x) { if (!x) emu_oob("clz32(0)"); return (uint32_t)__builtin_clz(x); }
+    static uint32_t ctz64(uint64_t x) { if (!x) emu_oob("ctz64(0)"); return (uint32_t)__builtin_ctzll(x); }
+    static uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+    static uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+};
+
+#endif
