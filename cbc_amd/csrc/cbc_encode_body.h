@@ -74,7 +74,7 @@ struct CbcEnc {
     /* ---- models ---- */
     V32 small;                              /* match / same_ref / chars lane table            */
     V32 fkey, fexc; uint32_t fcount, fn;    /* flag: sparse, one entry per lane                */
-    V32 hkey, hexc; uint32_t hcount[4], hn[4];   /* codebook ctx 0..3: sparse, 8 lanes per ctx */
+    V32 hkey, hexc; uint32_t hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;   /* codebook ctx 0..3: sparse, 8 lanes each */
     uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_cnt, *var_ev;
     uint32_t rlen_n, rlen_memo_x, rlen_memo_lo, rlen_memo_cnt;
     uint32_t rl123_c0, rl123_n;             /* rlength[1..3]: only symbol 0 is ever coded (Q1)  */
@@ -86,7 +86,7 @@ struct CbcEnc {
 
     /* ---- cross-read state (T7/T8 of SURVEY.md) ---- */
     uint32_t prevPos, prevM, prevChar;
-    uint64_t win[4];                        /* snpInRef[cumsumP-1 .. +255] as a bitmap          */
+    uint64_t w0, w1, w2, w3;                /* snpInRef[cumsumP-1 .. +255] as a 256-bit bitmap   */
 
     /* ======================================================================================= */
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
@@ -371,32 +371,47 @@ struct CbcEnc {
         nev++;
     }
 
-    /* ---- snpInRef window ---- */
+    /* ---- snpInRef window: 256 bits in four scalars, no runtime-indexed arrays ---- */
+    CBC_MFN void win_clear() { w0 = w1 = w2 = w3 = 0; }
     CBC_MFN void win_shift(uint32_t d)
     {
-        if (d >= 256u) { win[0] = win[1] = win[2] = win[3] = 0; return; }
+        if (d == 0u) return;
+        if (d >= 256u) { win_clear(); return; }
         uint32_t wsh = d >> 6, bsh = d & 63u;
-        uint64_t t[4];
-        for (uint32_t i = 0; i < 4; i++) {
-            uint32_t s = i + wsh;
-            uint64_t lo = s < 4 ? win[s] : 0, hi = s + 1 < 4 ? win[s + 1] : 0;
-            t[i] = bsh ? ((lo >> bsh) | (hi << (64u - bsh))) : lo;
+        if (wsh == 1u) { w0 = w1; w1 = w2; w2 = w3; w3 = 0; }
+        else if (wsh == 2u) { w0 = w2; w1 = w3; w2 = 0; w3 = 0; }
+        else if (wsh == 3u) { w0 = w3; w1 = 0; w2 = 0; w3 = 0; }
+        if (bsh) {
+            uint32_t inv = 64u - bsh;
+            w0 = (w0 >> bsh) | (w1 << inv);
+            w1 = (w1 >> bsh) | (w2 << inv);
+            w2 = (w2 >> bsh) | (w3 << inv);
+            w3 = w3 >> bsh;
         }
-        for (uint32_t i = 0; i < 4; i++) win[i] = t[i];
     }
     /* compute_delta_to_first_snp, read_compression.c:703-718 */
     CBC_MFN uint32_t win_first(uint32_t p, uint32_t rl)
     {
         uint32_t out = rl + 2u;
         if (p >= rl) return out;
-        for (uint32_t i = p >> 6; i < 4; i++) {
-            uint64_t w = win[i];
-            if (i == (p >> 6)) w &= ~0ull << (p & 63u);
-            if (w) { uint32_t pos = i * 64u + W::ctz64(w); if (pos < rl) out = pos - p; break; }
-        }
+        uint32_t pw = p >> 6; uint64_t pm = ~0ull << (p & 63u);
+        uint64_t a0 = pw == 0u ? (w0 & pm) : 0ull;
+        uint64_t a1 = pw == 1u ? (w1 & pm) : (pw < 1u ? w1 : 0ull);
+        uint64_t a2 = pw == 2u ? (w2 & pm) : (pw < 2u ? w2 : 0ull);
+        uint64_t a3 = pw == 3u ? (w3 & pm) : w3;
+        uint32_t pos = 0xffffffffu;
+        if (a0) pos = W::ctz64(a0);
+        else if (a1) pos = 64u + W::ctz64(a1);
+        else if (a2) pos = 128u + W::ctz64(a2);
+        else if (a3) pos = 192u + W::ctz64(a3);
+        if (pos < rl) out = pos - p;
         return out;
     }
-    CBC_MFN void win_set(uint32_t k) { if (k < 256u) win[k >> 6] |= 1ull << (k & 63u); }
+    CBC_MFN void win_set(uint32_t k)
+    {
+        uint64_t bit = 1ull << (k & 63u); uint32_t kw = k >> 6;
+        if (kw == 0u) w0 |= bit; else if (kw == 1u) w1 |= bit; else if (kw == 2u) w2 |= bit; else if (kw == 3u) w3 |= bit;
+    }
 };
 
 /* bytes readable from offset `off` of a buffer with `total` bytes, clamped to 32 bits */
@@ -455,7 +470,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.nev = 0;
     E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0; E.fn = 65536u;
     E.hkey = W::splat(0u); E.hexc = W::splat(0u);
-    for (int i = 0; i < 4; i++) { E.hcount[i] = 0; E.hn[i] = 256u; }
+    E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
     {   /* lane table: match 1,1 (n=2); same_ref 1,1; chars rows (sam_models.c:372-401) */
         V32 s = W::splat(0u);
         s = W::select(ln < 10u, W::splat(1u), s);
@@ -470,16 +485,16 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         E.small = s;
     }
     E.prevPos = 0; E.prevM = 0; E.prevChar = 0;
-    E.win[0] = E.win[1] = E.win[2] = E.win[3] = 0;
+    E.win_clear();
 
     /* ---- stream header: int(L0), 32 x int(WELL), int(LOSSLESS=8)  (sam_file_allocation.c:371,
      *      392-403; compression.c:139; compress_int qv_codebook.c:14-50) ---- */
     for (uint32_t k = 0; k < 34u && E.status == CBC_ST_OK; k++) {
         uint32_t v = (k == 0u) ? L0 : (k == 33u) ? 8u : CBC_WELL_SEED;
-        E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hcount[0], E.hn[0], 256u, 1u, v >> 24, CBC_ST_ASSERT);
-        E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hcount[1], E.hn[1], 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
-        E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hcount[2], E.hn[2], 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
-        E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hcount[3], E.hn[3], 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
     }
 
     /* ---- records ---- */
@@ -535,7 +550,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                     E.prevChar = ch;
                 }
                 E.prevPos = 0;                                /* chr_change: compress_pos :123-124 */
-                E.win[0] = E.win[1] = E.win[2] = E.win[3] = 0;    /* compression.c:62-63 */
+                E.win_clear();                                /* compression.c:62-63 */
             }
 
             /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1) -- */

@@ -1,0 +1,282 @@
+/*
+ * cbc_gpu.hip -- libcbc_gpu.so: the HIP kernels and the C ABI of include/cbc_gpu.h (gfx950 only).
+ *
+ * Launch shape: one wavefront (64 threads) per block = per arithmetic stream; the wavefront's
+ * model tables live in dynamic LDS (cbc_gpu_lds_bytes()), so occupancy is 160 KiB / that.  The
+ * grid is the number of blocks (thousands), i.e. >> 256 CUs x waves per CU.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/cbc_gpu.h"
+#include "cbc_wave_gpu.h"
+#include "cbc_encode_body.h"
+#include "cbc_plan.h"
+
+#define API extern "C" __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------
+ * kernels
+ * ---------------------------------------------------------------------------------------------- */
+extern __shared__ uint32_t cbc_lds[];
+
+__global__ void __launch_bounds__(64)
+cbc_encode_blocks_kernel(cbc_enc_args A)
+{
+    /* Workgroups are dealt round-robin to the 8 XCDs; blocks of one contig are neighbours in the
+     * batch and share nothing but read-only reference lines, so the identity map is kept and the
+     * per-XCD L2s each see a strided slice of the record stream. */
+    uint32_t blk = blockIdx.x;
+    if (blk >= A.n_blocks) return;
+    cbc_encode_stream<WaveGPU>(A, blk, cbc_lds);
+}
+
+/* exclusive scan of the per-block payload sizes -> offsets[n_blocks+1]; one workgroup */
+__global__ void __launch_bounds__(1024)
+cbc_scan_sizes_kernel(const cbc_block_result *__restrict__ results, uint64_t *__restrict__ offsets, uint32_t n_blocks)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t b0 = t * per, b1 = min(n_blocks, b0 + per);
+    uint64_t s = 0;
+    for (uint32_t b = b0; b < b1; b++) s += results[b].status == CBC_ST_OK ? results[b].nbytes : 0u;
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        uint64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = part[t] - s;
+    for (uint32_t b = b0; b < b1; b++) { offsets[b] = run; run += results[b].status == CBC_ST_OK ? results[b].nbytes : 0u; }
+    if (t == 1023u) offsets[n_blocks] = part[1023];
+}
+
+/* gather the per-block payload areas into one compacted buffer, 16 bytes per lane where aligned */
+__global__ void __launch_bounds__(256)
+cbc_compact_kernel(const uint8_t *__restrict__ scratch, const cbc_block_desc *__restrict__ blocks,
+                   const uint64_t *__restrict__ dst_off, uint8_t *__restrict__ dst, uint64_t dst_cap, uint32_t n_blocks)
+{
+    uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const uint64_t so = blocks[b].out_off, d0 = dst_off[b];
+    uint64_t n = dst_off[b + 1] - d0;
+    if (d0 + n > dst_cap) return;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) dst[d0 + i] = scratch[so + i];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * context
+ * ---------------------------------------------------------------------------------------------- */
+struct cbc_gpu_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    int have_timing;
+    uint8_t *d_ref; uint64_t ref_bytes;
+    char err[512];
+};
+
+static int set_err(cbc_gpu_ctx *c, int code, const char *what, hipError_t e)
+{
+    if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, e == hipSuccess ? "" : hipGetErrorString(e));
+    return code;
+}
+#define HIPCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(ctx, CBC_E_NODEV, what, e_); } while (0)
+
+API int cbc_gpu_abi_version(void) { return CBC_ABI_VERSION; }
+
+API int cbc_gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+API int cbc_gpu_init(int device_ordinal, cbc_gpu_ctx **out)
+{
+    if (!out) return CBC_E_ARG;
+    *out = NULL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return CBC_E_NODEV;
+    cbc_gpu_ctx *ctx = new (std::nothrow) cbc_gpu_ctx();
+    if (!ctx) return CBC_E_NOMEM;
+    memset(ctx, 0, sizeof *ctx);
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx; return CBC_E_NODEV;
+    }
+    /* the kernel's dynamic LDS can exceed the 64 KiB default */
+    (void)hipFuncSetAttribute((const void *)cbc_encode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = ctx;
+    return CBC_OK;
+}
+
+API int cbc_gpu_shutdown(cbc_gpu_ctx *ctx)
+{
+    if (!ctx) return CBC_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CBC_OK;
+}
+
+API const char *cbc_gpu_last_error(cbc_gpu_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+API int cbc_gpu_upload_reference(cbc_gpu_ctx *ctx, const uint8_t *bases, uint64_t nbytes)
+{
+    if (!ctx || !bases || nbytes == 0) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->d_ref) { (void)hipFree(ctx->d_ref); ctx->d_ref = NULL; ctx->ref_bytes = 0; }
+    HIPCHK(hipMalloc((void **)&ctx->d_ref, nbytes), "hipMalloc(reference)");
+    HIPCHK(hipMemcpy(ctx->d_ref, bases, nbytes, hipMemcpyHostToDevice), "hipMemcpy(reference)");
+    ctx->ref_bytes = nbytes;
+    return CBC_OK;
+}
+
+API uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_read_rec *recs, const uint32_t *tok)
+{
+    return cbc_plan_output(blocks, n_blocks, recs, tok);
+}
+API uint32_t cbc_gpu_lds_bytes(const cbc_lds_caps *caps) { return caps ? cbc_plan_lds_bytes(caps) : 0; }
+
+API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b, void *hip_stream)
+{
+    if (!ctx || !b) return CBC_E_ARG;
+    if (b->n_blocks == 0) return CBC_OK;
+    if (!b->d_recs || !b->d_seq || !b->d_tok || !b->d_names || !b->d_blocks || !b->d_ref || !b->d_out || !b->d_results)
+        return set_err(ctx, CBC_E_ARG, "null device pointer in cbc_device_batch", hipSuccess);
+    if (b->caps.cap_pos < 2 || b->caps.cap_pos > 8192 || b->caps.cap_var < 1 || b->caps.cap_var > 32768)
+        return set_err(ctx, CBC_E_ARG, "lds caps out of range", hipSuccess);
+    const uint32_t lds = cbc_plan_lds_bytes(&b->caps);
+    if (lds > 160u * 1024u) return set_err(ctx, CBC_E_ARG, "lds caps need more than 160 KiB", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    cbc_enc_args A;
+    A.recs = b->d_recs; A.seq = b->d_seq; A.tok = b->d_tok; A.names = b->d_names; A.blocks = b->d_blocks;
+    A.ref = b->d_ref; A.out = b->d_out; A.results = b->d_results;
+    A.ref_bytes = b->ref_bytes; A.out_bytes = b->out_bytes; A.seq_bytes = b->seq_bytes; A.n_tok = b->n_tok;
+    A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    A.names_bytes = 0x7fffffffu;   /* names are NUL-terminated; bounded by CBC_CAP_NAME in the kernel */
+    HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
+    hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
+    HIPCHK(hipGetLastError(), "launch cbc_encode_blocks_kernel");
+    HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
+    ctx->have_timing = 1;
+    return CBC_OK;
+}
+
+API int cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms || !ctx->have_timing) return CBC_E_ARG;
+    HIPCHK(hipEventSynchronize(ctx->ev1), "hipEventSynchronize");
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1), "hipEventElapsedTime");
+    return CBC_OK;
+}
+
+API int cbc_gpu_synchronize(cbc_gpu_ctx *ctx)
+{
+    if (!ctx) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return CBC_OK;
+}
+
+API int cbc_gpu_compact_device(cbc_gpu_ctx *ctx, const uint8_t *d_scratch, const cbc_block_desc *d_blocks,
+                               const cbc_block_result *d_results, uint32_t n_blocks, uint64_t *d_offsets,
+                               uint8_t *d_packed, uint64_t packed_cap, void *hip_stream)
+{
+    if (!ctx || !d_scratch || !d_blocks || !d_results || !d_offsets || !d_packed) return CBC_E_ARG;
+    if (n_blocks == 0) return CBC_OK;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipLaunchKernelGGL(cbc_scan_sizes_kernel, dim3(1), dim3(1024), 0, s, d_results, d_offsets, n_blocks);
+    HIPCHK(hipGetLastError(), "launch cbc_scan_sizes_kernel");
+    hipLaunchKernelGGL(cbc_compact_kernel, dim3(n_blocks), dim3(256), 0, s, d_scratch, d_blocks,
+                       (const uint64_t *)d_offsets, d_packed, packed_cap, n_blocks);
+    HIPCHK(hipGetLastError(), "launch cbc_compact_kernel");
+    return CBC_OK;
+}
+
+/* host-buffer entry point: H2D, encode, size scan, device-side compaction, D2H */
+API int cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_t *out, uint64_t out_cap,
+                              uint64_t *out_offsets, cbc_block_result *results)
+{
+    if (!ctx || !hb || !out || !out_offsets) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    const uint32_t nb = hb->n_blocks;
+    out_offsets[0] = 0;
+    if (nb == 0) return CBC_OK;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const uint64_t scratch = cbc_plan_output(hb->blocks, nb, hb->recs, hb->tok);
+    void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_blocks = NULL, *d_out = NULL, *d_res = NULL,
+         *d_off = NULL, *d_packed = NULL;
+    cbc_block_result *res = NULL;
+    int rc = CBC_OK;
+    uint64_t total = 0;
+    const uint64_t ntok = hb->n_tok ? hb->n_tok : 1;
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_recs, hb->n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
+    GO(hipMalloc(&d_seq, hb->seq_bytes + 16), "hipMalloc seq");
+    GO(hipMalloc(&d_tok, ntok * 4 + 16), "hipMalloc tok");
+    GO(hipMalloc(&d_names, hb->names_bytes + 16), "hipMalloc names");
+    GO(hipMalloc(&d_blocks, (uint64_t)nb * sizeof(cbc_block_desc)), "hipMalloc blocks");
+    GO(hipMalloc(&d_out, scratch), "hipMalloc out scratch");
+    GO(hipMalloc(&d_res, (uint64_t)nb * sizeof(cbc_block_result)), "hipMalloc results");
+    GO(hipMalloc(&d_off, ((uint64_t)nb + 1) * 8), "hipMalloc offsets");
+    GO(hipMemcpyAsync(d_recs, hb->recs, hb->n_recs * sizeof(cbc_read_rec), hipMemcpyHostToDevice, ctx->stream), "H2D recs");
+    GO(hipMemcpyAsync(d_seq, hb->seq, hb->seq_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D seq");
+    GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
+    GO(hipMemcpyAsync(d_names, hb->names, hb->names_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D names");
+    GO(hipMemcpyAsync(d_blocks, hb->blocks, (uint64_t)nb * sizeof(cbc_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
+    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)nb * sizeof(cbc_block_result), ctx->stream), "memset results");
+    {
+        cbc_device_batch db;
+        memset(&db, 0, sizeof db);
+        db.d_recs = (const cbc_read_rec *)d_recs; db.d_seq = (const uint8_t *)d_seq; db.d_tok = (const uint32_t *)d_tok;
+        db.d_names = (const uint8_t *)d_names; db.d_blocks = (const cbc_block_desc *)d_blocks; db.n_blocks = nb;
+        db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_out = (uint8_t *)d_out; db.out_bytes = scratch;
+        db.d_results = (cbc_block_result *)d_res; db.seq_bytes = hb->seq_bytes; db.n_tok = ntok; db.n_recs = hb->n_recs;
+        db.caps = hb->caps;
+        rc = cbc_gpu_encode_blocks_device(ctx, &db, NULL);
+        if (rc) goto done;
+    }
+    GO(hipMalloc(&d_packed, scratch), "hipMalloc packed");
+    rc = cbc_gpu_compact_device(ctx, (const uint8_t *)d_out, (const cbc_block_desc *)d_blocks, (const cbc_block_result *)d_res,
+                                nb, (uint64_t *)d_off, (uint8_t *)d_packed, scratch, NULL);
+    if (rc) goto done;
+    res = results ? results : (cbc_block_result *)malloc((size_t)nb * sizeof(cbc_block_result));
+    if (!res) { rc = CBC_E_NOMEM; goto done; }
+    GO(hipMemcpyAsync(res, d_res, (uint64_t)nb * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
+    GO(hipMemcpyAsync(out_offsets, d_off, ((uint64_t)nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H offsets");
+    GO(hipStreamSynchronize(ctx->stream), "encode kernel");
+    for (uint32_t b = 0; b < nb; b++) {
+        if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
+            snprintf(ctx->err, sizeof ctx->err, "block %u failed with status %u at record %u", b, res[b].status, res[b].fail_read);
+            rc = CBC_E_BLOCK;
+        }
+    }
+    total = out_offsets[nb];
+    if (total > out_cap) { rc = set_err(ctx, CBC_E_ARG, "out_cap too small for the compacted payloads", hipSuccess); goto done; }
+    if (total) {
+        GO(hipMemcpyAsync(out, d_packed, total, hipMemcpyDeviceToHost, ctx->stream), "D2H payloads");
+        GO(hipStreamSynchronize(ctx->stream), "D2H payloads");
+    }
+done:
+#undef GO
+    if (res && res != results) free(res);
+    if (d_recs) (void)hipFree(d_recs); if (d_seq) (void)hipFree(d_seq); if (d_tok) (void)hipFree(d_tok);
+    if (d_names) (void)hipFree(d_names); if (d_blocks) (void)hipFree(d_blocks); if (d_out) (void)hipFree(d_out);
+    if (d_res) (void)hipFree(d_res); if (d_off) (void)hipFree(d_off); if (d_packed) (void)hipFree(d_packed);
+    return rc;
+}

@@ -1,0 +1,159 @@
+"""ctypes binding of libcbc_gpu.so -- the C ABI of include/cbc_gpu.h (HIP kernels for gfx950).
+
+There is no CPU fallback: if the library is not built or no MI355X is visible, every entry point
+raises.  Python here only moves pointers; `torch` (when used by bench.py / the multi-GPU host) only
+owns device memory and process groups.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import host
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+GPU_LIB = os.path.join(_CSRC, "libcbc_gpu.so")
+
+ST_NAMES = {0: "OK", 1: "OUT_FULL", 2: "ASSERT", 3: "CAP_POS", 4: "CAP_FLAG", 5: "CAP_VAR", 6: "CAP_NAME",
+            7: "UNSUPPORTED"}
+
+
+class HostBatch(ctypes.Structure):
+    _fields_ = [
+        ("recs", ctypes.c_void_p), ("n_recs", ctypes.c_uint64),
+        ("seq", ctypes.c_void_p), ("seq_bytes", ctypes.c_uint64),
+        ("tok", ctypes.c_void_p), ("n_tok", ctypes.c_uint64),
+        ("names", ctypes.c_void_p), ("names_bytes", ctypes.c_uint32),
+        ("blocks", ctypes.c_void_p), ("n_blocks", ctypes.c_uint32),
+        ("caps", host.LdsCaps),
+    ]
+
+
+class DeviceBatch(ctypes.Structure):
+    _fields_ = [
+        ("d_recs", ctypes.c_void_p), ("d_seq", ctypes.c_void_p), ("d_tok", ctypes.c_void_p),
+        ("d_names", ctypes.c_void_p), ("d_blocks", ctypes.c_void_p), ("n_blocks", ctypes.c_uint32),
+        ("d_ref", ctypes.c_void_p), ("ref_bytes", ctypes.c_uint64),
+        ("d_out", ctypes.c_void_p), ("out_bytes", ctypes.c_uint64),
+        ("d_results", ctypes.c_void_p),
+        ("seq_bytes", ctypes.c_uint64), ("n_tok", ctypes.c_uint64), ("n_recs", ctypes.c_uint64),
+        ("caps", host.LdsCaps),
+    ]
+
+
+class CbcGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(GPU_LIB):
+            raise CbcGpuError("libcbc_gpu.so is not built (cbc_amd/csrc): the HIP path is the only path; "
+                              "run __graft_entry__.build() or `make -C cbc_amd/csrc`")
+        L = ctypes.CDLL(GPU_LIB)
+        L.cbc_gpu_abi_version.restype = ctypes.c_int
+        L.cbc_gpu_device_count.restype = ctypes.c_int
+        L.cbc_gpu_init.restype = ctypes.c_int
+        L.cbc_gpu_init.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.cbc_gpu_shutdown.restype = ctypes.c_int
+        L.cbc_gpu_shutdown.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_last_error.restype = ctypes.c_char_p
+        L.cbc_gpu_last_error.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_upload_reference.restype = ctypes.c_int
+        L.cbc_gpu_upload_reference.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_gpu_encode_blocks.restype = ctypes.c_int
+        L.cbc_gpu_encode_blocks.argtypes = [ctypes.c_void_p, ctypes.POINTER(HostBatch), ctypes.c_void_p,
+                                            ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_gpu_encode_blocks_device.restype = ctypes.c_int
+        L.cbc_gpu_encode_blocks_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeviceBatch), ctypes.c_void_p]
+        L.cbc_gpu_compact_device.restype = ctypes.c_int
+        L.cbc_gpu_compact_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                             ctypes.c_void_p]
+        L.cbc_gpu_plan_output.restype = ctypes.c_uint64
+        L.cbc_gpu_plan_output.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_gpu_lds_bytes.restype = ctypes.c_uint32
+        L.cbc_gpu_lds_bytes.argtypes = [ctypes.POINTER(host.LdsCaps)]
+        L.cbc_gpu_last_kernel_ms.restype = ctypes.c_int
+        L.cbc_gpu_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.cbc_gpu_synchronize.restype = ctypes.c_int
+        L.cbc_gpu_synchronize.argtypes = [ctypes.c_void_p]
+        if L.cbc_gpu_abi_version() != 1:
+            raise CbcGpuError("libcbc_gpu.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_gpu_shutdown", "cbc_gpu_last_error",
+           "cbc_gpu_upload_reference", "cbc_gpu_encode_blocks", "cbc_gpu_encode_blocks_device", "cbc_gpu_compact_device",
+           "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_synchronize"]
+
+
+class Encoder:
+    """One context per device (mirrors the lifetime of the reference's compress() call)."""
+
+    def __init__(self, device=0):
+        L = lib()
+        if L.cbc_gpu_device_count() <= 0:
+            raise CbcGpuError("no HIP device visible: the cbc hot path has no CPU fallback")
+        self._ctx = ctypes.c_void_p()
+        rc = L.cbc_gpu_init(device, ctypes.byref(self._ctx))
+        if rc != 0:
+            raise CbcGpuError("cbc_gpu_init(%d) failed: %d" % (device, rc))
+        self.device = device
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = lib().cbc_gpu_last_error(self._ctx)
+            raise CbcGpuError("%s failed (%d): %s" % (what, rc, msg.decode(errors="replace") if msg else ""))
+
+    def upload_reference(self, ref: np.ndarray):
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        self._check(lib().cbc_gpu_upload_reference(self._ctx, ref.ctypes.data, ref.size), "cbc_gpu_upload_reference")
+
+    def encode_blocks(self, pb: "host.PackedBatch"):
+        """Host-buffer path.  Returns (list of payload bytes per block, results array, out_offsets)."""
+        nb = pb.n_blocks
+        blocks = pb.blocks.copy()
+        hb = HostBatch(pb.recs.ctypes.data, pb.n_recs, pb.seq.ctypes.data, len(pb.seq), pb.tok.ctypes.data, pb.n_tok,
+                       pb.names.ctypes.data, len(pb.names), blocks.ctypes.data, nb, host.LdsCaps(pb.cap_pos, pb.cap_var))
+        total = lib().cbc_gpu_plan_output(blocks.ctypes.data, nb, pb.recs.ctypes.data, pb.tok.ctypes.data)
+        out = np.zeros(int(total), dtype=np.uint8)
+        offs = np.zeros(nb + 1, dtype=np.uint64)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        rc = lib().cbc_gpu_encode_blocks(self._ctx, ctypes.byref(hb), out.ctypes.data, out.size, offs.ctypes.data,
+                                         res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_encode_blocks")
+        payloads = [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)]
+        return payloads, res, offs, out[:int(offs[nb])]
+
+    def encode_device(self, db: DeviceBatch, stream=None):
+        self._check(lib().cbc_gpu_encode_blocks_device(self._ctx, ctypes.byref(db), stream), "cbc_gpu_encode_blocks_device")
+
+    def compact_device(self, d_scratch, d_blocks, d_results, n_blocks, d_offsets, d_packed, packed_cap, stream=None):
+        self._check(lib().cbc_gpu_compact_device(self._ctx, d_scratch, d_blocks, d_results, n_blocks, d_offsets,
+                                                 d_packed, packed_cap, stream), "cbc_gpu_compact_device")
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        self._check(lib().cbc_gpu_last_kernel_ms(self._ctx, ctypes.byref(ms)), "cbc_gpu_last_kernel_ms")
+        return float(ms.value)
+
+    def synchronize(self):
+        self._check(lib().cbc_gpu_synchronize(self._ctx), "cbc_gpu_synchronize")
+
+    def close(self):
+        if self._ctx:
+            lib().cbc_gpu_shutdown(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -168,6 +168,13 @@ typedef struct cbc_device_batch {
 
 int  cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *batch, void *hip_stream);
 
+/* Device-side compaction of the per-block payload areas written by the encode launch: an exclusive
+ * scan of cbc_block_result.nbytes into d_offsets[n_blocks+1], then a gather into d_packed
+ * (block b -> d_packed[d_offsets[b] .. d_offsets[b+1])).  Asynchronous on `hip_stream`. */
+int  cbc_gpu_compact_device(cbc_gpu_ctx *ctx, const uint8_t *d_scratch, const cbc_block_desc *d_blocks,
+                            const cbc_block_result *d_results, uint32_t n_blocks, uint64_t *d_offsets,
+                            uint8_t *d_packed, uint64_t packed_cap, void *hip_stream);
+
 /* Fills blocks[b].out_off / out_cap with a worst-case bound (every coded symbol costs at most 20
  * bits because every model total stays below 2^20) and returns the scratch bytes needed. */
 uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks,

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build the host library and the oracle (CPU only, seconds)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cbc_amd", "csrc"), "libcbc_host.so"],
+                          stdout=subprocess.DEVNULL)
+    from oracle import oracle
+    oracle.build()
+    return True
