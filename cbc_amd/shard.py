@@ -1,0 +1,63 @@
+"""Multi-GPU host path: blocks are independent streams, so they shard across ranks with no
+collective on the data path; the one exchange step is the gather of the per-rank bitstreams (and
+their per-block sizes) to rank 0, which concatenates them in block order.
+
+Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) with device tensors on the GPU
+box, "gloo" with CPU tensors in the CPU test suite.
+"""
+import numpy as np
+
+
+def shard_ranges(block_reads, world):
+    """Contiguous block ranges per rank, balanced by record count.
+
+    block_reads: per-block record counts (array).  Returns [(b0, b1)] * world with b0 <= b1.
+    """
+    br = np.asarray(block_reads, dtype=np.int64)
+    n = len(br)
+    if world <= 1:
+        return [(0, n)]
+    cum = np.concatenate([[0], np.cumsum(br)])
+    total = int(cum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(cum, target, side="left"))
+        k = min(max(k, cuts[-1]), n)
+        cuts.append(k)
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def gather_bitstreams(dist, local_packed, local_sizes, device, dst=0):
+    """Gather every rank's compacted payload bytes and per-block sizes to rank `dst`.
+
+    local_packed: 1-D uint8 tensor (this rank's payloads, block order); local_sizes: 1-D int64
+    tensor (bytes per block).  Returns (payload uint8 tensor, sizes int64 tensor) on `dst`
+    in global block order, (None, None) elsewhere.
+    """
+    import torch
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    meta = torch.tensor([local_packed.numel(), local_sizes.numel()], dtype=torch.int64, device=device)
+    metas = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    nbytes = [int(m[0].item()) for m in metas]
+    nblk = [int(m[1].item()) for m in metas]
+    cap_b, cap_n = max(max(nbytes), 1), max(max(nblk), 1)
+    pb = torch.zeros(cap_b, dtype=torch.uint8, device=device)
+    pb[:local_packed.numel()] = local_packed
+    ps = torch.zeros(cap_n, dtype=torch.int64, device=device)
+    ps[:local_sizes.numel()] = local_sizes
+    if rank == dst:
+        gl_b = [torch.empty(cap_b, dtype=torch.uint8, device=device) for _ in range(world)]
+        gl_s = [torch.empty(cap_n, dtype=torch.int64, device=device) for _ in range(world)]
+    else:
+        gl_b = gl_s = None
+    dist.gather(pb, gl_b, dst=dst)
+    dist.gather(ps, gl_s, dst=dst)
+    if rank != dst:
+        return None, None
+    payload = torch.cat([gl_b[r][:nbytes[r]] for r in range(world)])
+    sizes = torch.cat([gl_s[r][:nblk[r]] for r in range(world)])
+    return payload, sizes

@@ -61,6 +61,24 @@ def emu_encode(pb):
     return payloads, res
 
 
+def emu_encode_blocks(pb, which):
+    """Emulate only the listed blocks (for large batches).  Returns [(b, payload, result)]."""
+    L = emu_lib()
+    out = []
+    for b in which:
+        blocks = pb.blocks[b:b + 1].copy()
+        total = L.emu_plan_output(blocks.ctypes.data, 1, pb.recs.ctypes.data, pb.tok.ctypes.data)
+        buf = np.zeros(int(total), dtype=np.uint8)
+        res = np.zeros(1, dtype=host.RESULT_DTYPE)
+        db = DeviceBatch(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data,
+                         blocks.ctypes.data, 1, pb.ref.ctypes.data, len(pb.ref), buf.ctypes.data, int(total),
+                         res.ctypes.data, len(pb.seq), pb.n_tok, pb.n_recs, host.LdsCaps(pb.cap_pos, pb.cap_var))
+        if L.emu_encode_blocks(ctypes.byref(db)) != 0:
+            raise RuntimeError("emulation reported an invariant violation")
+        out.append((b, buf[:int(res[0]["nbytes"])].tobytes(), res[0]))
+    return out
+
+
 def block_alone_inputs(pb, sam_lines, b):
     """SAM + FASTA text of block b alone: its records with POS rebased to the block window, and the
     window (from the block's first base to the end of the contig, capped) as a one-contig FASTA."""

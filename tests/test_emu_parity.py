@@ -1,0 +1,125 @@
+"""The kernel BODY (cbc_amd/csrc/cbc_encode_body.h) single-stepped on the CPU lock-step wave
+emulation, against the oracle.  This is not the GPU parity test (tests/test_gpu_parity.py is): it
+checks the body's logic and indexing without a GPU, so a kernel is never launched on hardware with
+an out-of-range access the CPU could have caught."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import blockref
+import synth
+from cbc_amd import host
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _check(pb, sam):
+    payloads, res = blockref.emu_encode(pb)
+    assert (res["status"] == 0).all(), res[res["status"] != 0]
+    lines = blockref.mapped_sam_lines(sam)
+    assert len(lines) == pb.n_recs
+    for b in range(pb.n_blocks):
+        bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
+        exp, st = oracle.encode(bsam, bfa, return_stats=True)
+        assert payloads[b] == exp, "block %d" % b
+        assert int(res[b]["n_symbols"]) == st.n_symbols
+    return payloads, res
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*_L*.json"))))
+def test_golden_block_payloads(built, path):
+    g = json.load(open(path))
+    pb = host.pack_sam(g["sam"].encode(), g["fasta"].encode(), block_reads=g["block_reads"])
+    payloads, res = blockref.emu_encode(pb)
+    assert (res["status"] == 0).all()
+    assert [p.hex() for p in payloads] == g["block_payload_hex"]
+
+
+@pytest.mark.parametrize("kw,L,br", [
+    (dict(sub_rate=0.0, indel_frac=0.0), 100, 1000),
+    (dict(), 150, 1024),
+    (dict(sub_rate=0.01, indel_frac=0.3), 150, 700),
+    (dict(sub_rate=0.02, indel_frac=0.5, trailing_s_frac=0.2, dup_pos_frac=0.1), 100, 512),
+    (dict(sub_rate=0.05, indel_frac=0.0), 252, 300),
+    (dict(flags=(0, 16, 83, 99, 147, 163, 1024 + 99, 2048)), 150, 2048),
+    (dict(sub_rate=0.01, indel_frac=0.1), 33, 4096),
+])
+def test_blocks_match_oracle(built, kw, L, br):
+    fa, sam, _, _ = synth.dataset(5, [300000, 120000], [4000, 1500], L, **kw)
+    pb = host.pack_sam(sam, fa, block_reads=br)
+    _check(pb, sam)
+
+
+def test_md_last_column_quirk(built):
+    """Q2: the '\\n' letter token -> phantom N->N SNP, same bytes as the oracle."""
+    fa, _, rbc, _ = synth.dataset(9, [100000], [600], 100, sub_rate=0.02, indel_frac=0.0)
+    sam = synth.sam_text(rbc, md_last=True)
+    pb = host.pack_sam(sam, fa, block_reads=200)
+    _check(pb, sam)
+
+
+def test_md_last_with_deletion_aborts_like_the_reference(built):
+    """Q2 + a SNP-free deletion read: the phantom SNP's gap equals the read length, which is outside
+    the var alphabet -> assert(x < alphabetCard) in the reference; here: status ASSERT, oracle error."""
+    fa, _, rbc, _ = synth.dataset(9, [100000], [600], 100, sub_rate=0.0, indel_frac=0.3)
+    sam = synth.sam_text(rbc, md_last=True)
+    pb = host.pack_sam(sam, fa, block_reads=4096)
+    payloads, res = blockref.emu_encode(pb)
+    assert int(res[0]["status"]) == 2
+    with pytest.raises(oracle.OracleError):
+        oracle.encode(sam, fa)
+
+
+def test_sparse_positions_many_escapes(built):
+    """Every POS delta distinct: the escape path and the derived pos_alpha byte models."""
+    fa, sam, _, _ = synth.dataset(12, [40_000_000], [1500], 100, sub_rate=0.003, indel_frac=0.02)
+    pb = host.pack_sam(sam, fa, block_reads=1000)
+    assert pb.cap_pos >= 900
+    _check(pb, sam)
+
+
+def test_packer_cuts_blocks_at_table_caps(built):
+    fa, sam, _, _ = synth.dataset(13, [20_000_000], [2000], 100, sub_rate=0.03, indel_frac=0.3)
+    pb = host.pack_sam(sam, fa, block_reads=4096, max_cap_pos=256, max_cap_var=512)
+    assert pb.n_blocks > 4 and pb.cap_pos <= 256 and pb.cap_var <= 512
+    _check(pb, sam)
+
+
+def test_c_generator_matches_oracle(built):
+    pb, sam, fa = host.synth(0xCBC00002, 3_000_000, 12000, 150, want_text=True, block_reads=4096)
+    _check(pb, sam)
+
+
+def test_output_bound_holds(built):
+    """cbc_gpu_plan_output's worst case (3 bytes per coded symbol) really bounds the payloads."""
+    fa, sam, _, _ = synth.dataset(14, [200000], [3000], 150, sub_rate=0.08, indel_frac=0.8)
+    pb = host.pack_sam(sam, fa, block_reads=500)
+    payloads, res = blockref.emu_encode(pb)
+    blocks = pb.blocks.copy()
+    blockref.emu_lib().emu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data)
+    for b in range(pb.n_blocks):
+        assert res[b]["status"] == 0
+        assert len(payloads[b]) * 4 < int(blocks[b]["out_cap"]) * 3     # comfortably inside
+
+
+def test_kernel_reports_reference_aborts(built):
+    """Inputs the reference would abort on come back as a per-block status, never as bad bytes."""
+    fa, sam, rbc, _ = synth.dataset(15, [100000], [100], 100, sub_rate=0.0, indel_frac=0.0)
+    # MD claims a mismatch whose letter equals the read base: zero-count chars symbol (quirk Q4)
+    recs = rbc[0][2]
+    r = recs[50]
+    seq = bytearray(r["seq"])
+    seq[10] = ord("A") if seq[10] != ord("A") else ord("C")          # real mismatch -> imperfect read
+    r["seq"] = bytes(seq)
+    r["md"] = "10%s89" % chr(seq[10])                                  # ...but MD names the READ base
+    r["nm"] = 1
+    sam2 = synth.sam_text(rbc)
+    pb = host.pack_sam(sam2, fa, block_reads=4096)
+    payloads, res = blockref.emu_encode(pb)
+    assert int(res[0]["status"]) == 2 and int(res[0]["fail_read"]) == 50 and payloads[0] == b""
+    with pytest.raises(oracle.OracleError):
+        oracle.encode(sam2, fa)

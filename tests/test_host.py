@@ -1,0 +1,219 @@
+"""Host logic without a GPU: the packer's parsing rules and limits, block cutting, the container,
+and that libcbc_gpu.so loads and exports every symbol include/cbc_gpu.h declares."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import synth
+from cbc_amd import gpu, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tokens(pb, i):
+    r = pb.recs[i]
+    b = next(k for k in range(pb.n_blocks) if pb.blocks[k]["rec_base"] <= i < pb.blocks[k]["rec_base"] + pb.blocks[k]["n_reads"])
+    base = int(pb.blocks[b]["tok_base"]) + int(r["tok_off"])
+    hdr = int(pb.tok[base])
+    nc, nm = hdr & 0xffff, hdr >> 16
+    cig = [(int(t) >> 4, int(t) & 15) for t in pb.tok[base + 1: base + 1 + nc]]
+    md = [(int(t) >> 8, chr(int(t) & 0xff)) for t in pb.tok[base + 1 + nc: base + 1 + nc + nm]]
+    return cig, md
+
+
+def _one(fields, fa_seq="ACGT" * 100):
+    """SAM with two identical-length records so the header read length is well defined."""
+    fa = (">c\n%s\n" % fa_seq).encode()
+    lines = []
+    for f in fields:
+        lines.append("\t".join(str(x) for x in f) + "\n")
+    return "".join(lines).encode(), fa
+
+
+def test_gpu_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "cbc_gpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(cbc_gpu_\w+)\s*\(", hdr)))
+    assert len(declared) >= 12
+    assert sorted(gpu.EXPORTS) == declared
+    L = ctypes.CDLL(gpu.GPU_LIB)                         # loads without a GPU; no compute call made
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert gpu.lib().cbc_gpu_abi_version() == 1
+
+
+def test_host_library_exports(built):
+    hdr = open(os.path.join(ROOT, "include", "cbc_host.h")).read()
+    declared = sorted(set(re.findall(r"\b(cbc_(?:pack|packed|synth|free|container)\w*)\s*\(", hdr)))
+    L = ctypes.CDLL(host.HOST_LIB)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_no_gpu_means_loud_failure(built):
+    """The product has no CPU fallback: without a device the encoder refuses to exist."""
+    if gpu.lib().cbc_gpu_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(gpu.CbcGpuError):
+        gpu.Encoder(0)
+
+
+def test_struct_layouts_match_the_header():
+    assert ctypes.sizeof(host.ReadRec) == 16 and ctypes.sizeof(host.BlockDesc) == 64
+    assert ctypes.sizeof(host.BlockResult) == 16 and ctypes.sizeof(gpu.DeviceBatch) == ctypes.sizeof(ctypes.c_void_p) * 8 + 8 * 5 + 8 + 8
+
+
+def test_rebase_and_block_cut(built):
+    fa, sam, rbc, _ = synth.dataset(2, [300000, 100000], [2500, 700], 100)
+    pb = host.pack_sam(sam, fa, block_reads=1000)
+    assert pb.n_recs == 3200 and pb.read_length == 100
+    assert [int(x) for x in pb.info["n_reads"]] == [1000, 1000, 500, 700]
+    assert [int(x) for x in pb.info["contig"]] == [0, 0, 0, 1]
+    recs = [r for c in rbc for r in c[2]]
+    k = 0
+    for b in range(pb.n_blocks):
+        w0 = int(pb.info[b]["window_start"])
+        first = int(pb.blocks[b]["rec_base"])
+        assert int(pb.recs[first]["pos"]) == 1 and w0 == recs[first]["pos"] - 1
+        c = pb.contigs[int(pb.info[b]["contig"])]
+        assert int(pb.blocks[b]["ref_off"]) == int(c["ref_off"]) + w0
+        for j in range(int(pb.blocks[b]["n_reads"])):
+            assert int(pb.recs[first + j]["pos"]) + w0 == recs[first + j]["pos"]
+            k += 1
+    assert k == 3200
+    assert pb.contig_name(0) == b"chr1" and pb.contig_name(1) == b"chr2"
+    # reference: upper-cased, each contig followed by CBC_REF_PAD zero bytes
+    c0 = pb.contigs[0]
+    assert int(c0["length"]) == 300000 and not pb.ref[int(c0["length"]): int(c0["length"]) + host.CBC_REF_PAD].any()
+
+
+def test_cigar_and_md_tokens_follow_the_reference_scanners(built):
+    seq = "A" * 50
+    sam, fa = _one([
+        ["r0", 0, "c", 1, 60, "50M", "*", 0, 0, seq, "I" * 50, "MD:Z:50", "NM:i:0"],
+        ["r1", 16, "c", 3, 60, "10M2I38M", "*", 0, 0, seq, "I" * 50, "MD:Z:5C10^AC0T31", "NM:i:5"],
+        # ops the reference ignores (H, N, =, X) do not consume the number: the next recognised op
+        # takes atoi() of the whole unconsumed segment, i.e. the FIRST number in it
+        ["r2", 0, "c", 5, 60, "5H45M5S", "*", 0, 0, seq, "I" * 50, "NM:i:0", "MD:Z:45\n".strip("\n")],
+        # MD as the last column keeps its newline as a letter token (quirk Q2)
+        ["r3", 0, "c", 7, 60, "50M", "*", 0, 0, seq, "I" * 50, "NM:i:1", "MD:Z:20G29"],
+    ])
+    pb = host.pack_sam(sam, fa)
+    assert _tokens(pb, 0) == ([(50, 0)], [])
+    assert _tokens(pb, 1) == ([(10, 0), (2, 1), (38, 0)], [(5, "C"), (10, "T")])   # 10 + 0 around ^AC
+    assert _tokens(pb, 2)[0] == [(5, 0), (5, 3)]                                   # "5H45M" -> atoi = 5
+    assert _tokens(pb, 3)[1] == [(20, "G"), (29, "\n")]
+
+
+def test_record_without_md_keeps_previous_md(built):
+    """load_sam_line only strcpy()s edits when an MD/XD field is present (sam_file_allocation.c:507-511)."""
+    seq = "A" * 40
+    sam, fa = _one([
+        ["r0", 0, "c", 1, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:7C32", "NM:i:1"],
+        ["r1", 0, "c", 2, 60, "40M", "*", 0, 0, seq, "I" * 40, "NM:i:0"],
+    ])
+    pb = host.pack_sam(sam, fa)
+    assert _tokens(pb, 1)[1] == [(7, "C")]
+
+
+def test_unmapped_skipped_and_headers_ignored(built):
+    seq = "A" * 40
+    sam, fa = _one([
+        ["r0", 0, "c", 1, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"],
+        ["u", 4, "*", 0, 0, "*", "*", 0, 0, seq, "I" * 40],
+        ["r1", 0, "c", 2, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"],
+    ])
+    pb = host.pack_sam(b"@HD\tVN:1.6\n@SQ\tSN:c\tLN:400\n" + sam, fa)
+    assert pb.n_recs == 2 and pb.n_skipped_unmapped == 1
+
+
+@pytest.mark.parametrize("mutate,msg", [
+    (lambda f: f.__setitem__(3, 0), "POS"),
+    (lambda f: f.__setitem__(5, "5S35M"), "leading soft clip"),
+    (lambda f: f.__setitem__(5, "*"), "CIGAR '*'"),
+    (lambda f: f.__setitem__(9, "A" * 253), "read length"),
+])
+def test_inputs_outside_the_reference_limits_are_rejected(built, mutate, msg):
+    seq = "A" * 40
+    good = ["r0", 0, "c", 1, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"]
+    bad = list(good)
+    bad[3] = 2
+    mutate(bad)
+    sam, fa = _one([good, bad], fa_seq="ACGT" * 200)
+    with pytest.raises(host.CbcInputError) as e:
+        host.pack_sam(sam, fa)
+    assert msg in str(e.value)
+
+
+def test_unsorted_and_missing_contig_rejected(built):
+    seq = "A" * 40
+    n0 = ["r0", 0, "n" * 200, 10, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"]
+    sam, fa = _one([n0, n0])
+    with pytest.raises(host.CbcInputError, match="longer than"):
+        host.pack_sam(sam, fa)
+    a = ["r0", 0, "c", 10, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"]
+    b = ["r1", 0, "c", 5, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"]
+    sam, fa = _one([a, b])
+    with pytest.raises(host.CbcInputError, match="not sorted"):
+        host.pack_sam(sam, fa)
+    c = ["r1", 0, "d", 5, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"]
+    sam, fa = _one([a, c])
+    with pytest.raises(host.CbcInputError, match="FASTA has fewer"):
+        host.pack_sam(sam, fa)
+    long_line = ["r0", 0, "c", 10, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40", "XX:Z:" + "y" * 1100]
+    sam, fa = _one([a, long_line])
+    with pytest.raises(host.CbcInputError, match="1023"):
+        host.pack_sam(sam, fa)
+
+
+def test_fasta_is_consumed_in_order_and_upper_cased(built):
+    fa = b">first\nacgtn\nACGT\n>second\nGGGG\nCC\n"
+    seq = "ACGTN"
+    sam = ("r0\t0\tzzz\t1\t60\t5M\t*\t0\t0\t%s\tIIIII\tMD:Z:5\n" % seq +
+           "r1\t0\tzzz\t1\t60\t5M\t*\t0\t0\t%s\tIIIII\tMD:Z:5\n" % seq +
+           "r2\t0\tother\t1\t60\t5M\t*\t0\t0\tGGGGC\tIIIII\tMD:Z:5\n")
+    # read length 5 < 30 is fine for the packer (only the generator has a lower bound)
+    pb = host.pack_sam(sam.encode(), fa)
+    c0, c1 = pb.contigs[0], pb.contigs[1]
+    assert pb.ref[int(c0["ref_off"]): int(c0["ref_off"]) + 9].tobytes() == b"ACGTNACGT"
+    assert pb.ref[int(c1["ref_off"]): int(c1["ref_off"]) + 6].tobytes() == b"GGGGCC"
+    assert pb.contig_name(0) == b"zzz" and pb.contig_name(1) == b"other"      # FASTA header text is ignored
+
+
+def test_header_read_length_rule(built):
+    """get_read_length: SEQ length of the SECOND record; -l takes the maximum."""
+    fa = (">c\n" + "A" * 400 + "\n").encode()
+    mk = lambda n, p: "r\t0\tc\t%d\t60\t%dM\t*\t0\t0\t%s\t%s\tMD:Z:%d\n" % (p, n, "A" * n, "I" * n, n)
+    sam = (mk(40, 1) + mk(36, 2) + mk(50, 3)).encode()
+    assert host.pack_sam(sam, fa).read_length == 36
+    assert host.pack_sam(sam, fa, var_length=True).read_length == 50
+
+
+def test_container_layout(built):
+    fa, sam, _, _ = synth.dataset(3, [100000, 50000], [300, 100], 100)
+    pb = host.pack_sam(sam, fa, block_reads=128)
+    sizes = np.arange(10, 10 + pb.n_blocks, dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    payload = np.arange(int(offs[-1]), dtype=np.uint64).astype(np.uint8)
+    blob = pb.container(payload, offs)
+    magic, ver, L0, nc, nb, nbytes = struct.unpack_from("<6I", blob, 0)
+    assert magic == 0x42434243 and ver == 1 and L0 == 100 and nc == 2 and nb == pb.n_blocks
+    p = 24 + ((nbytes + 3) & ~3)
+    p += 16 * nc
+    for b in range(nb):
+        contig, nreads, w0, poff, pbytes, _ = struct.unpack_from("<IIQQII", blob, p + 32 * b)
+        assert (contig, nreads, w0) == (int(pb.info[b]["contig"]), int(pb.info[b]["n_reads"]), int(pb.info[b]["window_start"]))
+        assert poff == int(offs[b]) and pbytes == int(sizes[b])
+    assert blob[p + 32 * nb:] == payload.tobytes()
+
+
+def test_synth_is_seeded_and_sorted(built):
+    a = host.synth(5, 500000, 5000, 150)
+    b = host.synth(5, 500000, 5000, 150)
+    c = host.synth(6, 500000, 5000, 150)
+    assert a.seq.tobytes() == b.seq.tobytes() and a.recs.tobytes() == b.recs.tobytes()
+    assert a.seq.tobytes() != c.seq.tobytes()
+    assert a.n_bases == 5000 * 150 and set(np.unique(a.recs["flag"]).tolist()) <= {0, 16}
