@@ -19,6 +19,13 @@
  * Model tables are kept SPARSE and exact (SURVEY.md section 7 hard part 2): every symbol of the
  * big models starts at count 1 and rescaling maps 1 -> (1>>1)+1 = 1, so with e[s] = count[s]-1:
  *     cum(x) = x + sum_{s<x} e[s],   n = card + sum e[s],   rescale: e' = (1+e)>>1.
+ *
+ * CBC_LOOP note (uniformity).  A chunk loop `for (b = 0; b < N; b += 64) { m = lane + b < N; ... }`
+ * must take its bound from W::uni(N), an opaque copy: hipcc otherwise proves "m false => loop done"
+ * (lane id < 64), threads the per-lane mask into the loop exit, the exit becomes divergent, and
+ * everything live across the loop -- the whole coder state -- is classified divergent and moved
+ * from the scalar unit to VGPRs + exec-mask branches.  encode() carries an asm("+s") guard that turns
+ * any such regression into a compile error ("illegal VGPR to SGPR copy").
  */
 #ifndef CBC_ENCODE_BODY_H
 #define CBC_ENCODE_BODY_H
@@ -44,7 +51,8 @@
 #define CBC_LDS_INDELS  512u                       /* 256: indels excess                */
 #define CBC_LDS_RNKEY   768u                       /* CBC_CAP_NAME: (ctx<<8)|char       */
 #define CBC_LDS_RNEXC   (768u + CBC_CAP_NAME)      /* CBC_CAP_NAME                      */
-#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME)
+#define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* 256 words = 8192-bit Bloom filter on var ctx */
+#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u)
 /* then pos_val[cap_pos], pos_cnt[cap_pos], var_ev[cap_var] */
 
 struct cbc_enc_args {
@@ -60,6 +68,16 @@ struct cbc_enc_args {
     uint32_t n_blocks, cap_pos, cap_var, names_bytes;
 };
 
+/* CBC_STAMP: diagnostic build only (never shipped): per-section s_memtime sums, written over the
+ * start of the block's payload area at the end -- outputs of such a build are garbage by design. */
+#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+#define CBC_T0() do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); E.t_last = t_; } while (0)
+#define CBC_TS(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); E.t_sum[k] += t_ - E.t_last; E.t_last = t_; } while (0)
+#else
+#define CBC_T0() do {} while (0)
+#define CBC_TS(k) do {} while (0)
+#endif
+
 template <class W>
 struct CbcEnc {
     typedef typename W::V32 V32;
@@ -70,16 +88,21 @@ struct CbcEnc {
     uint64_t acc; uint32_t nacc;
     V32 stage; uint32_t nwords; uint32_t *out32; uint32_t cap_words;
     uint32_t status, nsym, fail_read, cur_read;
+    V32 q_lo, q_cnt, q_n; uint32_t q_len;   /* pending symbols: lane k = k-th queued (lo, cnt, n)      */
+#ifdef CBC_STAMP
+    unsigned long long t_last, t_sum[16];
+#endif
 
     /* ---- models ---- */
     V32 small;                              /* match / same_ref / chars lane table            */
     V32 fkey, fexc; uint32_t fcount, fn;    /* flag: sparse, one entry per lane                */
     V32 hkey, hexc; uint32_t hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;   /* codebook ctx 0..3: sparse, 8 lanes each */
-    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_cnt, *var_ev;
+    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_cnt, *var_ev, *bloom;
     uint32_t rlen_n, rlen_memo_x, rlen_memo_lo, rlen_memo_cnt;
     uint32_t rl123_c0, rl123_n;             /* rlength[1..3]: only symbol 0 is ever coded (Q1)  */
     uint32_t snps_n, indels_n;
     uint32_t rn_count;
+    V32 pval, pcnt;                          /* pos alphabet entries 0..63 (value, count)        */
     uint32_t pos_card, pos_n, cap_pos;
     uint32_t nev, cap_var;
     uint32_t L0;
@@ -118,14 +141,42 @@ struct CbcEnc {
      * closed form: within one step all E1/E2 iterations come first (they strip the common
      * leading bits of l and u), then all E3 iterations (they strip the run of positions below
      * the MSB where l has 1 and u has 0); E3 leaves msb(l)=0, msb(u)=1, so E1/E2 cannot recur. */
+    /* Symbol queue.  The models do not depend on the coder, so they push their (lo, cnt, n) triples
+     * into three VGPRs (lane k = k-th pending symbol) and the coder step is instantiated only at the
+     * few drain() sites instead of at every model call site: a ~6x smaller kernel (it has to live in
+     * the instruction cache next to other waves' working sets) and the coder state is not live across
+     * the model code. */
     CBC_MFN void encode(uint32_t lo, uint32_t cnt, uint32_t n)
+    {
+        V32 ln = W::lane();
+        Mask here = ln == q_len;
+        q_lo = W::select(here, W::splat(lo), q_lo);
+        q_cnt = W::select(here, W::splat(cnt), q_cnt);
+        q_n = W::select(here, W::splat(n), q_n);
+        q_len++;
+    }
+    CBC_MFN void drain()
+    {
+        const uint32_t m = W::uni(q_len);
+        for (uint32_t k = 0; k < m && status == CBC_ST_OK; k++)
+            code1(W::readlane(q_lo, k), W::readlane(q_cnt, k), W::readlane(q_n, k));
+        q_len = 0;
+    }
+    CBC_MFN void code1(uint32_t lo, uint32_t cnt, uint32_t n)
     {
         if (cnt == 0u || n == 0u) { fail(CBC_ST_ASSERT); return; }      /* assert(cumCountX_1 < cumCountX) */
         nsym++;
+#ifdef CBC_ABLATE_CODER          /* timing experiments only: keeps the operands live, skips the coder */
+        l ^= lo; u ^= cnt + n; return;
+#endif
+#ifdef __HIP_DEVICE_COMPILE__
+        asm volatile("" : "+s"(l), "+s"(u), "+s"(scale3), "+s"(nacc), "+s"(nwords));
+#endif
         uint32_t range = u - l + 1u;
-        double inv = W::recip(n);
-        uint32_t qh = W::muldiv(range, lo + cnt, n, inv);
-        uint32_t ql = W::muldiv(range, lo, n, inv);
+        auto inv = W::recip(n);
+        /* the first symbol of an alphabet has lo = 0 and the last has lo + cnt = n: no division needed */
+        uint32_t qh = (lo + cnt == n) ? range : W::muldiv(range, lo + cnt, n, inv);
+        uint32_t ql = (lo == 0u) ? 0u : W::muldiv(range, lo, n, inv);
         u = l + qh - 1u;
         l = l + ql;
         uint32_t x = l ^ u;
@@ -201,25 +252,29 @@ struct CbcEnc {
     {
         V32 ln = W::lane();
         V32 a = W::splat(0u);
-        for (uint32_t b = 0; b < x; b += 64u) { V32 i = ln + b; a = a + W::load32(exc, i, i < x, 0u); }
+        const uint32_t xb = W::uni(x);                       /* opaque loop bound: see CBC_LOOP note */
+        for (uint32_t b = 0; b < xb; b += 64u) { V32 i = ln + b; a = a + W::load32(exc, i, i < x, 0u); }
         lo = x + W::reduce_add(a);
         cnt = 1u + W::read_uni(exc, x);
+    }
+    CBC_MFN void dense_rescale(uint32_t *exc, uint32_t card, uint32_t &n)   /* stream_model.c:41-48 on e = count-1 */
+    {
+        V32 ln = W::lane();
+        V32 a = W::splat(0u);
+        const uint32_t cb = W::uni(card);
+        for (uint32_t b = 0; b < cb; b += 64u) {
+            V32 i = ln + b; Mask m = i < card;
+            V32 e = (W::load32(exc, i, m, 0u) + 1u) >> 1;
+            W::store32(exc, i, e, m);
+            a = a + W::select(m, e, W::splat(0u));
+        }
+        n = card + W::reduce_add(a);
     }
     CBC_MFN void dense_update(uint32_t *exc, uint32_t card, uint32_t step, uint32_t x, uint32_t &n)
     {
         W::write_uni(exc, x, W::read_uni(exc, x) + step);
         n += step;
-        if (n >= CBC_RESCALE) {
-            V32 ln = W::lane();
-            V32 a = W::splat(0u);
-            for (uint32_t b = 0; b < card; b += 64u) {
-                V32 i = ln + b; Mask m = i < card;
-                V32 e = (W::load32(exc, i, m, 0u) + 1u) >> 1;
-                W::store32(exc, i, e, m);
-                a = a + W::select(m, e, W::splat(0u));
-            }
-            n = card + W::reduce_add(a);
-        }
+        if (n >= CBC_RESCALE) dense_rescale(exc, card, n);
     }
     CBC_MFN void dense_code(uint32_t *exc, uint32_t card, uint32_t step, uint32_t x, uint32_t &n)
     {
@@ -255,7 +310,8 @@ struct CbcEnc {
         V32 ln = W::lane();
         V32 an = W::splat(0u), alo = W::splat(0u);
         uint32_t key = (ctx << 8) | sym, found = CBC_NOMEMO;
-        for (uint32_t b = 0; b < rn_count; b += 64u) {
+        const uint32_t rb = W::uni(rn_count);
+        for (uint32_t b = 0; b < rb; b += 64u) {
             V32 i = ln + b; Mask m = i < rn_count;
             V32 k = W::load32(rname_key, i, m, 0xffffffffu);
             V32 e = W::load32(rname_exc, i, m, 0u);
@@ -279,31 +335,44 @@ struct CbcEnc {
         }
     }
 
-    /* ---- pos (read_compression.c:113-159): dynamic alphabet, literal counts ---- */
+    /* ---- pos (read_compression.c:113-159): dynamic alphabet, literal counts.
+     * Entries 0..63 (the escape symbol and the first 63 deltas to appear -- at usual coverage these
+     * are the frequent ones) live in two VGPRs, lane = alphabet index; later entries in LDS at their
+     * absolute index.  A hit in the first tier costs one compare + ballot and a masked wave sum, no
+     * LDS round trip. ---- */
+    CBC_MFN void pos_rescale()                           /* stream_model.c:41-48, literal counts */
+    {
+        V32 ln = W::lane();
+        Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
+        pcnt = W::select(m0, (pcnt >> 1) + 1u, pcnt);
+        V32 a = W::select(m0, pcnt, W::splat(0u));
+        const uint32_t pc = W::uni(pos_card);
+        for (uint32_t b = 64u; b < pc; b += 64u) {
+            V32 i = ln + b; Mask m = i < pos_card;
+            V32 c = (W::load32(pos_cnt, i, m, 0u) >> 1) + 1u;
+            W::store32(pos_cnt, i, c, m);
+            a = a + W::select(m, c, W::splat(0u));
+        }
+        pos_n = W::reduce_add(a);
+    }
     CBC_MFN void pos_update(uint32_t idx)
     {
-        W::write_uni(pos_cnt, idx, W::read_uni(pos_cnt, idx) + 10u);
+        if (idx < 64u) pcnt = W::select(W::lane() == idx, pcnt + 10u, pcnt);
+        else W::write_uni(pos_cnt, idx, W::read_uni(pos_cnt, idx) + 10u);
         pos_n += 10u;
-        if (pos_n >= CBC_RESCALE) {
-            V32 ln = W::lane();
-            V32 a = W::splat(0u);
-            for (uint32_t b = 0; b < pos_card; b += 64u) {
-                V32 i = ln + b; Mask m = i < pos_card;
-                V32 c = (W::load32(pos_cnt, i, m, 0u) >> 1) + 1u;
-                W::store32(pos_cnt, i, c, m);
-                a = a + W::select(m, c, W::splat(0u));
-            }
-            pos_n = W::reduce_add(a);
-        }
+        if (pos_n >= CBC_RESCALE) pos_rescale();
     }
     /* one byte of compress_pos_alpha (:75-108).  The four 256-symbol models only ever see the
-     * bytes of the values already registered in pos_val[1..card), so their state is recomputed
-     * from that array: count(b) = 1 + 10 * #{registered v : byte_k(v) == b}. */
+     * bytes of the values already registered in the alphabet, so their state is recomputed from
+     * it: count(b) = 1 + 10 * #{registered v : byte_k(v) == b}. */
     CBC_MFN void pos_alpha_byte(uint32_t shift, uint32_t byte)
     {
         V32 ln = W::lane();
-        uint32_t lt = 0, eq = 0;
-        for (uint32_t b = 1; b < pos_card; b += 64u) {
+        Mask m0 = (ln != 0u) & (ln < (pos_card < 64u ? pos_card : 64u));
+        V32 v0 = (pval >> shift) & 0xffu;
+        uint32_t lt = W::popc64(W::ballot(m0 & (v0 < byte))), eq = W::popc64(W::ballot(m0 & (v0 == byte)));
+        const uint32_t pc = W::uni(pos_card);
+        for (uint32_t b = 64u; b < pc; b += 64u) {
             V32 i = ln + b; Mask m = i < pos_card;
             V32 v = (W::load32(pos_val, i, m, 0u) >> shift) & 0xffu;
             lt += W::popc64(W::ballot(m & (v < byte)));
@@ -316,13 +385,23 @@ struct CbcEnc {
     CBC_MFN void pos_code(uint32_t x)
     {
         V32 ln = W::lane();
-        V32 a = W::splat(0u);
+        Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
+        uint64_t eq0 = W::ballot(m0 & (ln != 0u) & (pval == x));
+        if (eq0) {                                            /* hit in the register tier */
+            uint32_t fl = W::ctz64(eq0);
+            uint32_t lo = W::reduce_add(W::select(ln < fl, pcnt, W::splat(0u)));
+            encode(lo, W::readlane(pcnt, fl), pos_n);
+            pos_update(fl);
+            return;
+        }
+        V32 a = W::select(m0, pcnt, W::splat(0u));
         uint32_t found = 0;
-        for (uint32_t b = 0; b < pos_card && !found; b += 64u) {
+        const uint32_t pc = W::uni(pos_card);
+        for (uint32_t b = 64u; b < pc && !found; b += 64u) {
             V32 i = ln + b; Mask m = i < pos_card;
             V32 v = W::load32(pos_val, i, m, 0u);
             V32 c = W::load32(pos_cnt, i, m, 0u);
-            uint64_t eq = W::ballot(m & (v == x) & (i != 0u));
+            uint64_t eq = W::ballot(m & (v == x));
             if (eq) {
                 uint32_t fl = W::ctz64(eq);
                 found = b + fl;
@@ -334,37 +413,57 @@ struct CbcEnc {
             encode(lo, W::read_uni(pos_cnt, found), pos_n);
             pos_update(found);
         } else {
-            encode(0u, W::read_uni(pos_cnt, 0u), pos_n);       /* escape symbol 0 */
+            encode(0u, W::readlane(pcnt, 0u), pos_n);          /* escape symbol 0 */
             pos_update(0u);
             pos_alpha_byte(24u, x >> 24);
             pos_alpha_byte(16u, (x >> 16) & 0xffu);
             pos_alpha_byte(8u, (x >> 8) & 0xffu);
             pos_alpha_byte(0u, x & 0xffu);
             if (pos_card >= cap_pos) { fail(CBC_ST_CAP_POS); return; }
-            W::write_uni(pos_val, pos_card, x);
-            W::write_uni(pos_cnt, pos_card, 0u);
+            if (pos_card < 64u) {
+                pval = W::select(ln == pos_card, W::splat(x), pval);
+                pcnt = W::select(ln == pos_card, W::splat(0u), pcnt);
+            } else {
+                W::write_uni(pos_val, pos_card, x);
+                W::write_uni(pos_cnt, pos_card, 0u);
+            }
             pos_card++;                                        /* update_model(P, alphabetCard++) :153 */
             pos_update(pos_card - 1u);
         }
     }
 
-    /* ---- var (read_compression.c:230-245): 65535 contexts x L0, kept as the list of events ---- */
+    /* ---- var (read_compression.c:230-245): 65535 contexts x L0, kept as the list of events.
+     * Most contexts are seen once per block, so an 8192-bit Bloom filter on the context answers
+     * "never seen" (n = L0, cum = sym) without touching the list; only on a filter hit is the list
+     * scanned, 256 events per iteration (4 independent LDS reads in flight per lane). ---- */
     CBC_MFN void var_code(uint32_t ctx, uint32_t sym)
     {
         if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
         V32 ln = W::lane();
         uint32_t cn = 0, clo = 0, ceq = 0, key = (ctx << 8) | sym;
-        for (uint32_t b = 0; b < nev; b += 64u) {
-            V32 i = ln + b; Mask m = i < nev;
-            V32 e = W::load32(var_ev, i, m, 0xffffffffu);
-            Mask inctx = m & ((e >> 8) == ctx);
-            uint64_t bn = W::ballot(inctx);
-            if (bn) {
-                cn += W::popc64(bn);
-                clo += W::popc64(W::ballot(inctx & ((e & 0xffu) < sym)));
-                ceq += W::popc64(W::ballot(inctx & (e == key)));
+        const uint32_t h = (ctx * 0x9E3779B1u) >> 19;
+        const uint32_t bw = W::read_uni(bloom, h >> 5), bbit = 1u << (h & 31u);
+        if (bw & bbit) {
+            const uint32_t nb = W::uni(nev);
+            for (uint32_t b = 0; b < nb; b += 256u) {
+                V32 i0 = ln * 4u + b;
+                V32 e0 = W::load32(var_ev, i0, i0 < nev, 0xffffffffu);
+                V32 e1 = W::load32(var_ev, i0 + 1u, (i0 + 1u) < nev, 0xffffffffu);
+                V32 e2 = W::load32(var_ev, i0 + 2u, (i0 + 2u) < nev, 0xffffffffu);
+                V32 e3 = W::load32(var_ev, i0 + 3u, (i0 + 3u) < nev, 0xffffffffu);
+                uint64_t b0 = W::ballot((e0 >> 8) == ctx), b1 = W::ballot((e1 >> 8) == ctx);
+                uint64_t b2 = W::ballot((e2 >> 8) == ctx), b3 = W::ballot((e3 >> 8) == ctx);
+                if (b0 | b1 | b2 | b3) {
+                    cn += W::popc64(b0) + W::popc64(b1) + W::popc64(b2) + W::popc64(b3);
+                    clo += W::popc64(W::ballot(((e0 >> 8) == ctx) & ((e0 & 0xffu) < sym))) +
+                           W::popc64(W::ballot(((e1 >> 8) == ctx) & ((e1 & 0xffu) < sym))) +
+                           W::popc64(W::ballot(((e2 >> 8) == ctx) & ((e2 & 0xffu) < sym))) +
+                           W::popc64(W::ballot(((e3 >> 8) == ctx) & ((e3 & 0xffu) < sym)));
+                    ceq += W::popc64(W::ballot(e0 == key)) + W::popc64(W::ballot(e1 == key)) +
+                           W::popc64(W::ballot(e2 == key)) + W::popc64(W::ballot(e3 == key));
+                }
             }
-        }
+        } else W::write_uni(bloom, h >> 5, bw | bbit);
         encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
         if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
         W::write_uni(var_ev, nev, key);
@@ -409,16 +508,29 @@ struct CbcEnc {
     }
     CBC_MFN void win_set(uint32_t k)
     {
+        /* selects, not an if-chain: an if-chain over adjacent members is turned back into a
+         * runtime-indexed access by the optimiser, which forces the window into scratch memory */
         uint64_t bit = 1ull << (k & 63u); uint32_t kw = k >> 6;
-        if (kw == 0u) w0 |= bit; else if (kw == 1u) w1 |= bit; else if (kw == 2u) w2 |= bit; else if (kw == 3u) w3 |= bit;
+        w0 |= (kw == 0u) ? bit : 0ull;
+        w1 |= (kw == 1u) ? bit : 0ull;
+        w2 |= (kw == 2u) ? bit : 0ull;
+        w3 |= (kw == 3u) ? bit : 0ull;
     }
 };
 
 /* bytes readable from offset `off` of a buffer with `total` bytes, clamped to 32 bits */
+/* a <= b for 64-bit values using 32-bit compares only: gfx950's scalar ALU has no ordered 64-bit
+ * compare, and one VALU compare on a uniform value drags everything downstream onto the VALU */
+CBC_FN bool cbc_le64(uint64_t a, uint64_t b)
+{
+    uint32_t ah = (uint32_t)(a >> 32), al = (uint32_t)a, bh = (uint32_t)(b >> 32), bl = (uint32_t)b;
+    return (ah < bh) | ((ah == bh) & (al <= bl));
+}
 CBC_FN uint32_t cbc_avail32(uint64_t total, uint32_t off)
 {
-    uint64_t a = total > off ? total - off : 0;
-    return a > 0xffffffffull ? 0xffffffffu : (uint32_t)a;
+    uint64_t a = total - off;                       /* callers guarantee off <= total or get 0 below */
+    if (!cbc_le64((uint64_t)off, total)) return 0u;
+    return (uint32_t)(a >> 32) ? 0xffffffffu : (uint32_t)a;
 }
 CBC_FN uint32_t cbc_basepair(uint32_t c)            /* char2basepair sam_models.c:11-21 */
 {
@@ -447,10 +559,11 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
     E.l = 0; E.u = CBC_M26; E.scale3 = 0; E.acc = 0; E.nacc = 0; E.nwords = 0;
     E.stage = W::splat(0u);
+    E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
     E.out32 = (uint32_t *)(A.out + out_off);
     E.cap_words = out_cap >> 2;
-    bool args_ok = (out_off + out_cap <= A.out_bytes) && ((out_off & 3u) == 0) &&
-                   (rec_base + n_reads <= A.n_recs) && (tok_base + n_tok_blk <= A.n_tok) &&
+    bool args_ok = cbc_le64(out_off + out_cap, A.out_bytes) && ((out_off & 3u) == 0) &&
+                   cbc_le64(rec_base + n_reads, A.n_recs) && cbc_le64(tok_base + n_tok_blk, A.n_tok) &&
                    (L0 >= 1u && L0 <= 256u) && (name_off < A.names_bytes);
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
 
@@ -458,15 +571,17 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.L0 = L0;
     E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
     E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
+    E.bloom = lds + CBC_LDS_BLOOM;
     E.pos_val = lds + CBC_LDS_FIXED; E.pos_cnt = E.pos_val + A.cap_pos; E.var_ev = E.pos_cnt + A.cap_pos;
     E.cap_pos = A.cap_pos; E.cap_var = A.cap_var;
     for (uint32_t b = 0; b < 768u; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
+    for (uint32_t b = 0; b < 256u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());
     E.rlen_n = 255u; E.rlen_memo_x = CBC_NOMEMO; E.rlen_memo_lo = 0; E.rlen_memo_cnt = 0;
     E.rl123_c0 = 1u; E.rl123_n = 255u;
     E.snps_n = L0; E.indels_n = L0;
     E.rn_count = 0;
     E.pos_card = 1u; E.pos_n = 1u;                           /* initialize_stream_model_pos :132-162 */
-    W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_cnt, 0u, 1u);
+    E.pval = W::splat(0xffffffffu); E.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
     E.nev = 0;
     E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0; E.fn = 65536u;
     E.hkey = W::splat(0u); E.hexc = W::splat(0u);
@@ -495,6 +610,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
         E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
         E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
+        if ((k & 7u) == 7u || k == 33u) E.drain();
     }
 
     /* ---- records ---- */
@@ -502,13 +618,27 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const uint8_t *seqb = A.seq + seq_base;
     const uint32_t *tokb = A.tok + tok_base;
     const uint8_t *refb = A.ref + ref_off;
-    const uint64_t seq_avail = A.seq_bytes > seq_base ? A.seq_bytes - seq_base : 0;
-    const uint64_t ref_avail = A.ref_bytes > ref_off ? A.ref_bytes - ref_off : 0;
+    const uint64_t seq_avail = cbc_le64(seq_base, A.seq_bytes) ? A.seq_bytes - seq_base : 0;
+    const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
+    const uint32_t seq_lim = cbc_avail32(seq_avail, 0u), ref_lim = cbc_avail32(ref_avail, 0u);
 
+#ifdef CBC_STAMP
+    for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
+    CBC_T0();
+#endif
     for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
         V32 r_pos, r_fl, r_seq, r_tok;
         W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
         uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
+        {   /* validate the 64 records at once (one lane each) so the per-record loads below need no
+             * clamping: read length 1..252, POS >= 1, bases and reference window inside the buffers */
+            V32 vrl = r_fl >> 16;
+            Mask live = (ln + c0) < n_reads;
+            Mask bad = live & ((vrl == 0u) | (vrl > CBC_MAX_READ_LEN) | (r_pos == 0u) |
+                               ((r_seq + vrl + 4u) > seq_lim) | ((r_pos + vrl + 3u) > ref_lim) | (r_tok >= n_tok_blk));
+            uint64_t bb = W::ballot(bad);
+            if (bb) { E.cur_read = c0 + W::ctz64(bb); E.fail(CBC_ST_ASSERT); break; }
+        }
 
         /* software prefetch of record j's bases, reference window and tokens one record ahead */
         V32 nx_seq = W::splat(0u), nx_ref = W::splat(0u), nx_tok = W::splat(0u);
@@ -516,9 +646,8 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             uint32_t pos = W::readlane(r_pos, 0u), fl = W::readlane(r_fl, 0u);
             uint32_t so = W::readlane(r_seq, 0u), to = W::readlane(r_tok, 0u), rl = fl >> 16;
             V32 bo = ln * 4u;
-            uint32_t slim = cbc_avail32(seq_avail, so), rlim = pos ? cbc_avail32(ref_avail, pos - 1u) : 0u;
-            nx_seq = W::load32_bytes(seqb + so, bo, (bo < rl) & (bo + 4u <= slim));
-            nx_ref = W::load32_bytes(refb + (pos ? pos - 1u : 0u), bo, (bo < rl) & (bo + 4u <= rlim));
+            nx_seq = W::load32_bytes(seqb + so, bo, bo < rl);
+            nx_ref = W::load32_bytes(refb + (pos - 1u), bo, bo < rl);
             nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
         }
         for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
@@ -531,12 +660,11 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                 uint32_t npos = W::readlane(r_pos, j + 1u), nfl = W::readlane(r_fl, j + 1u);
                 uint32_t so = W::readlane(r_seq, j + 1u), to = W::readlane(r_tok, j + 1u), nrl = nfl >> 16;
                 V32 bo = ln * 4u;
-                uint32_t slim = cbc_avail32(seq_avail, so), rlim = npos ? cbc_avail32(ref_avail, npos - 1u) : 0u;
-                nx_seq = W::load32_bytes(seqb + so, bo, (bo < nrl) & (bo + 4u <= slim));
-                nx_ref = W::load32_bytes(refb + (npos ? npos - 1u : 0u), bo, (bo < nrl) & (bo + 4u <= rlim));
+                nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
+                nx_ref = W::load32_bytes(refb + (npos - 1u), bo, bo < nrl);
                 nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
             }
-            if (rl == 0u || rl > CBC_MAX_READ_LEN || pos == 0u) { E.fail(CBC_ST_ASSERT); break; }
+            CBC_TS(0);                                        /* loop top: readlanes + prefetch issue */
 
             /* -- compress_rname (id_compression.c:39-65); a block holds one contig -- */
             const bool first = (c0 + j) == 0u;
@@ -546,6 +674,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                 for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
                     uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
                     E.rname_code(E.prevChar, ch);
+                    if ((q & 31u) == 31u) E.drain();          /* long contig names: keep the queue short */
                     if (ch == 0u) break;
                     E.prevChar = ch;
                 }
@@ -553,18 +682,26 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                 E.win_clear();                                /* compression.c:62-63 */
             }
 
-            /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1) -- */
+            /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1) --
+             * rlength[0] is cached: while the same length repeats (fixed-length data: always) the
+             * symbol's (lo, count) live in scalars and the LDS table is not touched; the cached count
+             * is written back when another length shows up. */
             {
                 uint32_t x = rl & 0xffu;
                 if (x >= 255u) { E.fail(CBC_ST_ASSERT); break; }
-                uint32_t lo, cnt;
-                if (x == E.rlen_memo_x) { lo = E.rlen_memo_lo; cnt = E.rlen_memo_cnt; }
-                else { E.dense_lookup(E.rlen_exc, x, lo, cnt); E.rlen_memo_x = x; E.rlen_memo_lo = lo; }
-                E.encode(lo, cnt, E.rlen_n);
-                const uint32_t nb = E.rlen_n;
-                E.dense_update(E.rlen_exc, 255u, 10u, x, E.rlen_n);
-                E.rlen_memo_cnt = cnt + 10u;
-                if (E.rlen_n != nb + 10u) E.rlen_memo_x = CBC_NOMEMO;     /* rescaled: memo is stale */
+                if (x != E.rlen_memo_x) {
+                    if (E.rlen_memo_x != CBC_NOMEMO) W::write_uni(E.rlen_exc, E.rlen_memo_x, E.rlen_memo_cnt - 1u);
+                    uint32_t lo, cnt;
+                    E.dense_lookup(E.rlen_exc, x, lo, cnt);
+                    E.rlen_memo_x = x; E.rlen_memo_lo = lo; E.rlen_memo_cnt = cnt;
+                }
+                E.encode(E.rlen_memo_lo, E.rlen_memo_cnt, E.rlen_n);
+                E.rlen_memo_cnt += 10u; E.rlen_n += 10u;
+                if (E.rlen_n >= CBC_RESCALE) {                 /* rescale through the table, then re-read */
+                    W::write_uni(E.rlen_exc, x, E.rlen_memo_cnt - 1u);
+                    E.dense_rescale(E.rlen_exc, 255u, E.rlen_n);
+                    E.rlen_memo_x = CBC_NOMEMO;
+                }
                 for (int k = 1; k < 4; k++) {
                     /* the three contexts evolve identically, but symbols interleave: k=1 sees the
                      * state before this read's update, so code all three, then update once */
@@ -574,17 +711,24 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                 if (E.rl123_n >= CBC_RESCALE) { E.rl123_c0 = (E.rl123_c0 >> 1) + 1u; E.rl123_n = 254u + E.rl123_c0; }
             }
 
+            CBC_TS(1);                                        /* rname + rlength */
             /* -- compress_pos -- */
             const int32_t dx = (int32_t)(pos - E.prevPos) + 1;
             if (dx < 1 || (uint32_t)dx >= 5000000u) { E.fail(CBC_ST_ASSERT); break; }   /* MAX_ALPHA sam_block.h:54 */
             E.win_shift(first ? 256u : (uint32_t)(dx - 1));
+#ifndef CBC_ABLATE_POS
             E.pos_code((uint32_t)dx);
+#endif
             E.prevPos = pos;
 
+            CBC_TS(2);                                        /* pos */
             /* -- compress_flag (read_compression.c:50-70) -- */
+#ifndef CBC_ABLATE_FLAG
             E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, E.fn, 65536u, 8u, flag, CBC_ST_CAP_FLAG);
+#endif
             const uint32_t strand = (flag >> 4) & 1u;
 
+            CBC_TS(3);                                        /* flag */
             /* -- match test (read_compression.c:291-296) -- */
             V32 bo = ln * 4u;
             V32 bmask = W::select(bo + 4u <= rl, W::splat(0xffffffffu),
@@ -593,87 +737,109 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             uint32_t match = neq ? 0u : 1u;
             E.small_code(CBC_LT_MATCH + (((dx == 1) ? 2u : 0u) | E.prevM) * 2u, 2u, 1u, match);
             E.prevM = match;
-            if (match || E.status != CBC_ST_OK) continue;
-
-            /* -- compress_edits for an imperfect read (read_compression.c:308-600) -- */
-            const uint32_t hdr = W::readlane(tokv, 0u);
+#ifdef CBC_ABLATE_EDITS
+            match = 1u;
+#endif
+            CBC_TS(4);                                        /* match test + symbol (waits for the prefetch) */
+            if (!match && E.status == CBC_ST_OK) {
+            /* -- compress_edits for an imperfect read (read_compression.c:308-600) --
+             * The packer has already counted the edits (token word 1) and checked that the MD string is
+             * consistent with the read, so every MD token becomes exactly one SNP: numSnps = n_md. */
+            const uint32_t hdr = W::readlane(tokv, 0u), hdr1 = W::readlane(tokv, 1u);
             const uint32_t n_cig = hdr & 0xffffu, n_md = hdr >> 16;
-            if (tok_off + 1u + n_cig + n_md > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
+            const uint32_t nSnp = n_md, nDel = hdr1 & 0xffffu, nIns = hdr1 >> 16;
+            if (tok_off + 2u + n_cig + n_md > n_tok_blk || nSnp >= 1024u || nDel >= 1024u || nIns >= 1024u) {
+                E.fail(CBC_ST_ASSERT); break;
+            }
 #define CBC_TOK(i) ((i) < 64u ? W::readlane(tokv, (i)) : W::read_uni(tokb + tok_off, (i)))
 #define CBC_READ_BYTE(i) ((i) < rl ? ((W::readlane(seqv, (i) >> 2) >> (((i) & 3u) * 8u)) & 0xffu) : 0u)
-            uint32_t nSnp = 0, nDel = 0, nIns = 0;
-            for (int pass = 0; pass < 4 && E.status == CBC_ST_OK; pass++) {
-                /* pass 0 counts; 1 deletions; 2 SNPs; 3 insertions (emission order :568-600) */
-                if (pass == 1) {
-                    if ((nDel | nIns) == 0u) E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
-                    else {
-                        E.dense_code(E.snps_exc, L0, 10u, 0u, E.snps_n);
-                        E.dense_code(E.indels_exc, L0, 16u, nSnp & 0xffu, E.indels_n);
-                        E.dense_code(E.indels_exc, L0, 16u, nDel & 0xffu, E.indels_n);
-                        E.dense_code(E.indels_exc, L0, 16u, nIns & 0xffu, E.indels_n);
-                    }
-                    if (nDel == 0u) continue;
+#define CBC_SNP(gap_, letter_, cum_, p_) do {                                                              \
+                uint32_t d_ = E.win_first(p_, rl);                                                          \
+                E.var_code(((((d_ << 7) + (p_)) << 1) | strand), (gap_));                                   \
+                (p_) += (gap_) + 1u;                                                                        \
+                E.win_set((p_) - 1u);                     /* snpInRef[cumsumP+prev_pos-2] = 1  (:589) */     \
+                E.small_code(CBC_LT_CHARS + cbc_basepair(letter_) * 8u, 5u, 8u, cbc_basepair(CBC_READ_BYTE(cum_))); \
+            } while (0)
+            if ((nDel | nIns) == 0u) {
+                /* SNP-only read (:557-558, :573-593): no insertion can interleave, so the MD tokens are
+                 * the SNP list in order -- one loop, no CIGAR walk */
+                E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
+                uint32_t cum = 0, p = 0;
+                for (uint32_t k = 0; k < n_md && E.status == CBC_ST_OK; k++) {
+                    if (E.q_len >= 56u) E.drain();
+                    const uint32_t t = CBC_TOK(2u + n_cig + k);
+                    const uint32_t g = t >> 8;
+                    cum += g;
+                    CBC_SNP(g, t & 0xffu, cum, p);
+                    cum++;
                 }
-                if (pass == 2 && nSnp == 0u) continue;
-                if (pass == 3 && nIns == 0u) continue;
-                uint32_t Mc = 0, ins = 0, prevI = 0, prevD = 0, p = 0;
-                uint32_t k = 0, cum = 0; bool more = true;          /* add_snps_to_array statics */
-                for (uint32_t o = 0; o <= n_cig && E.status == CBC_ST_OK; o++) {
-                    uint32_t op, len;
-                    if (o < n_cig) { uint32_t t = CBC_TOK(1u + o); op = t & 15u; len = t >> 4; }
-                    else { op = 99u; len = 1u; }                     /* final pull with limit rl+1 :551 */
-                    if (op == CBC_OP_M) { Mc += len; continue; }
-                    if (op == CBC_OP_STAR || (op == CBC_OP_S && o == 0u)) { E.fail(CBC_ST_UNSUPPORTED); break; }
-                    if (op == CBC_OP_D) {
-                        if (pass == 0) nDel += len;
-                        else if (pass == 1)
-                            for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) {
-                                uint32_t g = Mc - prevD;
-                                E.var_code((p << 1) | strand, g);
-                                p += g; prevD = Mc;
-                            }
-                        continue;
-                    }
-                    /* I, trailing S, or the final pull */
-                    for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) {
-                        if ((op == CBC_OP_I || op == 99u) && more && (pass == 0 || pass == 2)) {
-                            uint32_t limit = (op == 99u) ? rl + 1u : Mc + ins;
-                            more = false;
-                            while (k < n_md) {
-                                uint32_t t = CBC_TOK(1u + n_cig + k);
-                                uint32_t g = t >> 8, letter = t & 0xffu;
-                                if (cum + g >= limit) { cum++; more = true; break; }
-                                cum += g;
-                                if (pass == 0) nSnp++;
-                                else {
-                                    uint32_t d = E.win_first(p, rl);
-                                    E.var_code(((((d << 7) + p) << 1) | strand), g);
-                                    p += g + 1u;
-                                    E.win_set(p - 1u);               /* snpInRef[cumsumP+prev_pos-2] = 1 */
-                                    uint32_t alt = cbc_basepair(CBC_READ_BYTE(cum));
-                                    E.small_code(CBC_LT_CHARS + cbc_basepair(letter) * 8u, 5u, 8u, alt);
-                                    if (E.status != CBC_ST_OK) break;
+                /* a leading soft clip / '*' is rejected by the packer; refuse it here as well */
+                { const uint32_t t0 = CBC_TOK(2u); const uint32_t op0 = t0 & 15u;
+                  if (n_cig && (op0 == CBC_OP_STAR || op0 == CBC_OP_S)) E.fail(CBC_ST_UNSUPPORTED); }
+            } else {
+                E.dense_code(E.snps_exc, L0, 10u, 0u, E.snps_n);                 /* :561-564 */
+                E.dense_code(E.indels_exc, L0, 16u, nSnp & 0xffu, E.indels_n);
+                E.dense_code(E.indels_exc, L0, 16u, nDel & 0xffu, E.indels_n);
+                E.dense_code(E.indels_exc, L0, 16u, nIns & 0xffu, E.indels_n);
+                /* three walks over the CIGAR, in the emission order of :568-600: deletions, SNPs
+                 * (interleaved with the insertions through add_snps_to_array's early return), insertions */
+                for (int pass = 1; pass < 4 && E.status == CBC_ST_OK; pass++) {
+                    if ((pass == 1 && nDel == 0u) || (pass == 2 && nSnp == 0u) || (pass == 3 && nIns == 0u)) continue;
+                    uint32_t Mc = 0, ins = 0, prevI = 0, prevD = 0, p = 0;
+                    uint32_t k = 0, cum = 0; bool more = true;       /* add_snps_to_array statics */
+                    for (uint32_t o = 0; o <= n_cig && E.status == CBC_ST_OK; o++) {
+                        uint32_t op, len;
+                        if (o < n_cig) { uint32_t t = CBC_TOK(2u + o); op = t & 15u; len = t >> 4; }
+                        else { op = 99u; len = 1u; }                  /* final pull with limit rl+1 :551 */
+                        if (op == CBC_OP_M) { Mc += len; continue; }
+                        if (op == CBC_OP_STAR || (op == CBC_OP_S && o == 0u)) { E.fail(CBC_ST_UNSUPPORTED); break; }
+                        if (op == CBC_OP_D) {
+                            if (pass == 1)
+                                for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) {
+                                    uint32_t g = Mc - prevD;
+                                    if (E.q_len >= 56u) E.drain();
+                                    E.var_code((p << 1) | strand, g);
+                                    p += g; prevD = Mc;
                                 }
-                                cum++; k++;
+                            continue;
+                        }
+                        /* I, trailing S, or the final pull */
+                        for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) {
+                            if (E.q_len >= 56u) E.drain();
+                            if ((op == CBC_OP_I || op == 99u) && more && pass == 2) {
+                                uint32_t limit = (op == 99u) ? rl + 1u : Mc + ins;
+                                more = false;
+                                while (k < n_md && E.status == CBC_ST_OK) {
+                                    uint32_t t = CBC_TOK(2u + n_cig + k);
+                                    uint32_t g = t >> 8;
+                                    if (cum + g >= limit) { cum++; more = true; break; }
+                                    if (E.q_len >= 56u) E.drain();
+                                    cum += g;
+                                    CBC_SNP(g, t & 0xffu, cum, p);
+                                    cum++; k++;
+                                }
                             }
+                            if (op == 99u) break;
+                            if (pass == 3) {
+                                uint32_t g = Mc - prevI;
+                                uint32_t base = cbc_basepair(CBC_READ_BYTE(Mc + ins));
+                                E.var_code((p << 1) | strand, g);
+                                p += g;
+                                E.small_code(CBC_LT_CHARS + 5u * 8u, 5u, 8u, base);
+                                prevI = Mc;
+                            }
+                            ins++;
                         }
-                        if (op == 99u) break;
-                        if (pass == 0) nIns++;
-                        else if (pass == 3) {
-                            uint32_t g = Mc - prevI;
-                            uint32_t base = cbc_basepair(CBC_READ_BYTE(Mc + ins));
-                            E.var_code((p << 1) | strand, g);
-                            p += g;
-                            E.small_code(CBC_LT_CHARS + 5u * 8u, 5u, 8u, base);
-                            prevI = Mc;
-                        }
-                        ins++;
                     }
                 }
-                if (pass == 0 && (nSnp >= 1024u || nDel >= 1024u || nIns >= 1024u)) E.fail(CBC_ST_ASSERT);
             }
+#undef CBC_SNP
 #undef CBC_TOK
 #undef CBC_READ_BYTE
+            }
+            CBC_TS(5);                                        /* edits */
+            E.drain();                                        /* one coder instantiation per record */
+            CBC_TS(6);                                        /* coder */
         }
     }
 
@@ -685,8 +851,13 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         E.rname_code(E.prevChar, (uint32_t)'\n');
         E.rname_code((uint32_t)'\n', 0u);
     }
+    E.drain();
     if (E.status == CBC_ST_OK) nbytes = E.finish();
     if (E.status != CBC_ST_OK) nbytes = 0;
+#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+    if (out_cap >= 128u) for (int i = 0; i < 16; i++) {
+        W::write_uni(E.out32, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.out32, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
+#endif
     V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),
                W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
     W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);

@@ -201,7 +201,7 @@ static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos
         return fail(S, CBC_E_INPUT, "record at %s POS %lld runs past the contig end + pad", rname, pos);
 
     /* ---- tokens: CIGAR ---- */
-    uint32_t *tk = S->tokbuf; uint32_t nt = 1, n_cig = 0, n_md = 0;
+    uint32_t *tk = S->tokbuf; uint32_t nt = 2, n_cig = 0, n_md = 0;
     uint32_t ev = 0;                                    /* upper bound on var symbols of this record */
     {
         const char *seg = cigar; int i = 0;
@@ -251,6 +251,37 @@ static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos
     }
     if (n_cig > 0xffff || n_md > 0xffff) return fail(S, CBC_E_INPUT, "too many CIGAR/MD tokens%s%lld", "", 0);
     tk[0] = n_cig | (n_md << 16);
+    {
+        /* Edit counts for the kernel (token word 1) and a consistency check: replay compress_edits'
+         * CIGAR walk with add_snps_to_array's early-return rule (read_compression.c:308-352, 551-552,
+         * 656-659) and require that every MD mismatch token is consumed.  An MD string that names
+         * more bases than the read has makes the reference leave its parser statics dirty for the
+         * NEXT record (undefined behaviour there); such input is rejected here. */
+        uint32_t Mc = 0, ins = 0, nDel = 0, nIns = 0, k = 0, cum = 0, nS = 0; int more = 1;
+        for (uint32_t o = 0; o <= n_cig; o++) {
+            uint32_t op = 99, len = 1;
+            if (o < n_cig) { op = tk[2 + o] & 15u; len = tk[2 + o] >> 4; }
+            if (op == CBC_OP_M) { Mc += len; continue; }
+            if (op == CBC_OP_D) { nDel += len; continue; }
+            for (uint32_t c = 0; c < len; c++) {
+                if ((op == CBC_OP_I || op == 99) && more) {
+                    uint32_t limit = (op == 99) ? (uint32_t)rl + 1 : Mc + ins;
+                    more = 0;
+                    while (k < n_md) {
+                        uint32_t g = tk[2 + n_cig + k] >> 8;
+                        if (cum + g >= limit) { cum++; more = 1; break; }
+                        cum += g + 1; nS++; k++;
+                    }
+                }
+                if (op == 99) break;
+                nIns++; ins++;
+            }
+        }
+        if (nS != n_md)
+            return fail(S, CBC_E_INPUT, "MD:Z:%s is inconsistent with CIGAR/SEQ at POS %lld (it names more bases than the read has)", edits, pos);
+        if (nDel > 0xffff || nIns > 0xffff) return fail(S, CBC_E_INPUT, "too many inserted/deleted bases%s%lld", "", 0);
+        tk[1] = nDel | (nIns << 16);
+    }
     ev += n_md;
     if (ev + 1 > S->o.max_cap_var) return fail(S, CBC_E_INPUT, "record at %s:%lld has more edits than max_cap_var", rname, pos);
 

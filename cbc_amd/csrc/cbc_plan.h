@@ -10,7 +10,7 @@
 #include "../../include/cbc_gpu.h"
 
 /* must match CBC_LDS_FIXED in cbc_encode_body.h */
-#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME)
+#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u)
 
 static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
 {
@@ -33,7 +33,7 @@ static inline uint64_t cbc_plan_output(cbc_block_desc *blocks, uint32_t n_blocks
             const uint32_t *t = tok + bd->tok_base + rr->tok_off;
             uint32_t n_cig = t[0] & 0xffffu, n_md = t[0] >> 16;
             uint64_t ev = n_md;
-            for (uint32_t k = 0; k < n_cig; k++) if ((t[1 + k] & 15u) != CBC_OP_M) ev += t[1 + k] >> 4;
+            for (uint32_t k = 0; k < n_cig; k++) if ((t[2 + k] & 15u) != CBC_OP_M) ev += t[2 + k] >> 4;
             nsym += 2 * ev;
         }
         uint64_t cap = (3 * nsym + 256 + 255) & ~255ull;

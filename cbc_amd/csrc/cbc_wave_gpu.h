@@ -27,6 +27,15 @@ struct WaveGPU {
     static CBC_FN uint64_t ballot(Mask m) { return __ballot(m); }
     /* make a value the compiler cannot prove uniform a scalar (it IS uniform by construction) */
     static CBC_FN uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    /* same, for a value just produced by a VALU-only instruction (f64 math): the empty asm makes the
+     * VGPR value opaque so the optimiser cannot commute the readfirstlane back in front of the
+     * producing instruction (it otherwise rewrites readfirstlane(cvt(x)) as cvt(readfirstlane(x)),
+     * which lands in a VGPR again and drags every dependent scalar op onto the VALU) */
+    static CBC_FN uint32_t to_scalar(uint32_t x)
+    {
+        asm volatile("" : "+v"(x));
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+    }
     static CBC_FN uint32_t readlane(V32 v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni(k)); }
 
     /* sum over the 64 lanes: inclusive DPP scan inside each row of 16, then row_bcast15 /
@@ -64,17 +73,29 @@ struct WaveGPU {
     /* wave-uniform write: one lane stores */
     static CBC_FN void write_uni(uint32_t *p, uint32_t idx, uint32_t val) { if (lane() == 0) p[idx] = val; }
 
-    /* floor(range * c / n) for range <= 2^26, c <= n < 2^20 + 2^16.  One IEEE double reciprocal
-     * estimate can only truncate one below the true quotient (|error| < 2^-25 on a quotient that
-     * is either an integer or at least 2^-20 away from one), so a single upward fix-up is exact. */
-    static CBC_FN uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, double inv_n)
+    /* floor(range * c / n) for range <= 2^26, c <= n < 2^21 (so the quotient is < 2^27), exact, with
+     * one shared f32 reciprocal and two f32 estimates; everything else is 32-bit scalar integer work.
+     *   rinv = rcp((float)n), relative error <= 2^-22 (v_rcp_f32 is 1 ulp; (float)n is exact)
+     *   q0   = trunc((float)(p >> 16) * 65536 * rinv):  |q0 - p/n| <= 2^16/n + 33
+     *   r0   = p - q0*n  (|r0| < 2^18 + 34 n < 2^27: the low 32 bits are the whole value)
+     *   q1   = floor((float)r0 * rinv): within 1 of floor(r0 / n)
+     *   q    = q0 + q1, then one step of fix-up in either direction on r1 = r0 - q1*n.
+     * readfirstlane after each float->int conversion keeps the integer side on the scalar unit
+     * (the empty asm in to_scalar stops the optimiser from commuting it in front of the cvt). */
+    static CBC_FN uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, float rinv)
     {
         uint64_t p = (uint64_t)range * c;
-        uint32_t q = (uint32_t)((double)p * inv_n);
-        uint64_t r = p - (uint64_t)q * n;
-        return r >= n ? q + 1 : q;
+        float pf = (float)(uint32_t)(p >> 16) * 65536.0f;
+        uint32_t q0 = to_scalar((uint32_t)(pf * rinv));
+        int32_t r0 = (int32_t)((uint32_t)p - q0 * n);
+        int32_t q1 = (int32_t)to_scalar((uint32_t)(int32_t)__builtin_floorf((float)r0 * rinv));
+        int32_t r1 = r0 - q1 * (int32_t)n;
+        uint32_t q = q0 + (uint32_t)q1;
+        q -= (uint32_t)(r1 < 0);                  /* arithmetic, not an if-chain: keeps it on the SALU */
+        q += (uint32_t)(r1 >= (int32_t)n);
+        return q;
     }
-    static CBC_FN double recip(uint32_t n) { return 1.0 / (double)n; }
+    static CBC_FN float recip(uint32_t n) { return __builtin_amdgcn_rcpf((float)n); }
 
     static CBC_FN uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }       /* x != 0 */
     static CBC_FN uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }     /* x != 0 */

@@ -12,7 +12,7 @@ import numpy as np
 from . import host
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-GPU_LIB = os.path.join(_CSRC, "libcbc_gpu.so")
+GPU_LIB = os.environ.get("CBC_GPU_LIB", os.path.join(_CSRC, "libcbc_gpu.so"))   # override = kernel experiments only
 
 ST_NAMES = {0: "OK", 1: "OUT_FULL", 2: "ASSERT", 3: "CAP_POS", 4: "CAP_FLAG", 5: "CAP_VAR", 6: "CAP_NAME",
             7: "UNSUPPORTED"}

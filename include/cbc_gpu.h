@@ -70,6 +70,10 @@ typedef struct cbc_read_rec {
 
 /* Token stream of one record at tok[tok_base + tok_off]:
  *   word 0            : n_cigar | (n_md << 16)
+ *   word 1            : n_deleted_bases | (n_inserted_bases << 16)   (sum of D lengths; sum of I and
+ *                       trailing-S lengths) -- the counts compress_edits() codes first (:557-565);
+ *                       the number of SNPs is n_md (the packer rejects MD strings that are
+ *                       inconsistent with the read)
  *   n_cigar words     : (len << 4) | op      op: CBC_OP_M/I/D/S/STAR; len = atoi() of the CIGAR
  *                       segment exactly as compress_edits() reads it (read_compression.c:308-352)
  *   n_md words        : (gap << 8) | letter  one per mismatch letter of MD:Z, gap = matched bases

@@ -82,17 +82,32 @@ struct WaveEmu {
     static uint32_t read_uni8(const uint8_t *p, uint32_t idx) { return p[idx]; }
     static void write_uni(uint32_t *p, uint32_t idx, uint32_t val) { p[idx] = val; }
 
-    /* same double-reciprocal formula as the GPU policy, cross-checked against exact integers */
-    static uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, double inv_n)
+    /* same f32 two-estimate formula as the GPU policy, cross-checked against exact integer division
+     * on every call.  The reciprocal is deliberately perturbed by up to +-2 ulp (v_rcp_f32 is a 1-ulp
+     * approximation, the CPU's 1.0f/x is correctly rounded) so the fix-up logic is exercised. */
+    static uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, float rinv)
     {
         uint64_t p = (uint64_t)range * c;
-        uint32_t q = (uint32_t)((double)p * inv_n);
-        uint64_t r = p - (uint64_t)q * n;
-        uint32_t res = r >= n ? q + 1 : q;
-        if (res != (uint32_t)(p / n)) emu_oob("muldiv double-reciprocal mismatch");
-        return res;
+        float pf = (float)(uint32_t)(p >> 16) * 65536.0f;
+        uint32_t q0 = (uint32_t)(pf * rinv);
+        int32_t r0 = (int32_t)((uint32_t)p - q0 * n);
+        int32_t q1 = (int32_t)__builtin_floorf((float)r0 * rinv);
+        int32_t r1 = r0 - q1 * (int32_t)n;
+        uint32_t q = q0 + (uint32_t)q1;
+        if (r1 < 0) q -= 1u;
+        else if (r1 >= (int32_t)n) q += 1u;
+        if (q != (uint32_t)(p / n)) emu_oob("muldiv f32 two-estimate mismatch");
+        return q;
     }
-    static double recip(uint32_t n) { return 1.0 / (double)n; }
+    static float recip(uint32_t n)
+    {
+        float r = 1.0f / (float)n;
+        static unsigned tick = 0;
+        uint32_t bits; memcpy(&bits, &r, 4);
+        bits += (uint32_t)((int)(tick++ % 5u) - 2);          /* -2..+2 ulp */
+        memcpy(&r, &bits, 4);
+        return r;
+    }
     static uint32_t clz32(uint32_t x) { if (!x) emu_oob("clz32(0)"); return (uint32_t)__builtin_clz(x); }
     static uint32_t ctz64(uint64_t x) { if (!x) emu_oob("ctz64(0)"); return (uint32_t)__builtin_ctzll(x); }
     static uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }

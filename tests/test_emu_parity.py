@@ -123,3 +123,32 @@ def test_kernel_reports_reference_aborts(built):
     assert int(res[0]["status"]) == 2 and int(res[0]["fail_read"]) == 50 and payloads[0] == b""
     with pytest.raises(oracle.OracleError):
         oracle.encode(sam2, fa)
+
+
+def _variable_length_sam(seed, n=1500):
+    """Reads of mixed lengths (trimmed reads): exercises the rlength[0] cache switch / write-back."""
+    rng = np.random.default_rng(seed)
+    contig = synth.make_contig(rng, 200000)
+    recs, pos = [], 50
+    for i in range(n):
+        pos += int(rng.integers(0, 60))
+        L = int(rng.choice([100, 100, 100, 87, 64, 100, 99, 35]))
+        if i % 400 == 1:
+            L = 100        # the block's 2nd record sets the header read length in the oracle's block-alone run
+        seq = contig[pos - 1: pos - 1 + L].copy()
+        md, nm = str(L), 0
+        if i % 5 == 0:
+            q = int(rng.integers(1, L - 1))
+            old = seq[q]
+            seq[q] = synth._ACGT[(int(np.where(synth._ACGT == old)[0][0]) + 1) % 4]
+            md, nm = "%d%s%d" % (q, chr(old), L - q - 1), 1
+        recs.append(dict(pos=pos, flag=16 if i % 3 == 0 else 0, cigar="%dM" % L, seq=seq.tobytes(), md=md, nm=nm))
+    rbc = [("chrV", 200000, recs)]
+    return synth.fasta_text([("chrV", contig)]), synth.sam_text(rbc)
+
+
+def test_variable_read_lengths(built):
+    fa, sam = _variable_length_sam(17)
+    pb = host.pack_sam(sam, fa, block_reads=400)
+    assert pb.read_length == 100
+    _check(pb, sam)

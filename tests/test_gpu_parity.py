@@ -113,3 +113,10 @@ def test_full_size_properties(enc, built):
     ep = blockref.emu_encode_blocks(pb, [0, pb.n_blocks // 2, pb.n_blocks - 1])
     for b, payload, res in ep:
         assert p1[b] == payload and int(r1[b]["n_symbols"]) == int(res["n_symbols"])
+
+
+def test_variable_read_lengths(enc, built):
+    from test_emu_parity import _variable_length_sam
+    fa, sam = _variable_length_sam(17)
+    pb = host.pack_sam(sam, fa, block_reads=400)
+    _check_blocks(enc, pb, sam)

@@ -20,8 +20,8 @@ def _tokens(pb, i):
     base = int(pb.blocks[b]["tok_base"]) + int(r["tok_off"])
     hdr = int(pb.tok[base])
     nc, nm = hdr & 0xffff, hdr >> 16
-    cig = [(int(t) >> 4, int(t) & 15) for t in pb.tok[base + 1: base + 1 + nc]]
-    md = [(int(t) >> 8, chr(int(t) & 0xff)) for t in pb.tok[base + 1 + nc: base + 1 + nc + nm]]
+    cig = [(int(t) >> 4, int(t) & 15) for t in pb.tok[base + 2: base + 2 + nc]]
+    md = [(int(t) >> 8, chr(int(t) & 0xff)) for t in pb.tok[base + 2 + nc: base + 2 + nc + nm]]
     return cig, md
 
 
