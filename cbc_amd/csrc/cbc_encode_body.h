@@ -157,14 +157,21 @@ struct CbcEnc {
     }
     CBC_MFN void drain()
     {
-        const uint32_t m = W::uni(q_len);
-        for (uint32_t k = 0; k < m && status == CBC_ST_OK; k++)
-            code1(W::readlane(q_lo, k), W::readlane(q_cnt, k), W::readlane(q_n, k));
+        V32 ln = W::lane();
+        uint32_t m = W::uni(q_len);
+        /* assert(cumCountX_1 < cumCountX) of every pending symbol at once (stream_model.c:71) */
+        const uint64_t bad = W::ballot((ln < m) & ((q_cnt == 0u) | (q_n == 0u)));
+        if (bad) m = W::ctz64(bad);
+        const V32 inv_v = W::recip_v(q_n);
+        for (uint32_t k = 0; k < m; k++) {
+            code1(W::readlane(q_lo, k), W::readlane(q_cnt, k), W::readlane(q_n, k), W::lane_float(inv_v, k));
+            if (status != CBC_ST_OK) break;
+        }
+        if (bad) fail(CBC_ST_ASSERT);
         q_len = 0;
     }
-    CBC_MFN void code1(uint32_t lo, uint32_t cnt, uint32_t n)
+    CBC_MFN void code1(uint32_t lo, uint32_t cnt, uint32_t n, float inv)
     {
-        if (cnt == 0u || n == 0u) { fail(CBC_ST_ASSERT); return; }      /* assert(cumCountX_1 < cumCountX) */
         nsym++;
 #ifdef CBC_ABLATE_CODER          /* timing experiments only: keeps the operands live, skips the coder */
         l ^= lo; u ^= cnt + n; return;
@@ -172,11 +179,8 @@ struct CbcEnc {
 #ifdef __HIP_DEVICE_COMPILE__
         asm volatile("" : "+s"(l), "+s"(u), "+s"(scale3), "+s"(nacc), "+s"(nwords));
 #endif
-        uint32_t range = u - l + 1u;
-        auto inv = W::recip(n);
-        /* the first symbol of an alphabet has lo = 0 and the last has lo + cnt = n: no division needed */
-        uint32_t qh = (lo + cnt == n) ? range : W::muldiv(range, lo + cnt, n, inv);
-        uint32_t ql = (lo == 0u) ? 0u : W::muldiv(range, lo, n, inv);
+        uint32_t range = u - l + 1u, qh, ql;
+        W::muldiv2(range, lo, lo + cnt, n, inv, ql, qh);
         u = l + qh - 1u;
         l = l + ql;
         uint32_t x = l ^ u;

@@ -73,29 +73,32 @@ struct WaveGPU {
     /* wave-uniform write: one lane stores */
     static CBC_FN void write_uni(uint32_t *p, uint32_t idx, uint32_t val) { if (lane() == 0) p[idx] = val; }
 
-    /* floor(range * c / n) for range <= 2^26, c <= n < 2^21 (so the quotient is < 2^27), exact, with
-     * one shared f32 reciprocal and two f32 estimates; everything else is 32-bit scalar integer work.
-     *   rinv = rcp((float)n), relative error <= 2^-22 (v_rcp_f32 is 1 ulp; (float)n is exact)
-     *   q0   = trunc((float)(p >> 16) * 65536 * rinv):  |q0 - p/n| <= 2^16/n + 33
-     *   r0   = p - q0*n  (|r0| < 2^18 + 34 n < 2^27: the low 32 bits are the whole value)
-     *   q1   = floor((float)r0 * rinv): within 1 of floor(r0 / n)
-     *   q    = q0 + q1, then one step of fix-up in either direction on r1 = r0 - q1*n.
-     * readfirstlane after each float->int conversion keeps the integer side on the scalar unit
-     * (the empty asm in to_scalar stops the optimiser from commuting it in front of the cvt). */
-    static CBC_FN uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, float rinv)
+    /* qh = floor(range * hi / n) and ql = floor(range * lo / n) for range <= 2^26, lo < hi <= n < 2^21
+     * (quotients < 2^27), exact.  The two divisions run side by side in lanes 0 and 1 of one VALU
+     * instruction stream; `inv` = rcp((float)n), relative error <= 2^-22 (v_rcp_f32 is 1 ulp, (float)n
+     * is exact).  Per lane, with p = range * c:
+     *   q0 = trunc((float)(p >> 16) * 65536 * inv):   |q0 - p/n| <= 2^16/n + 33
+     *   r0 = p - q0*n   (|r0| < 2^18 + 34 n < 2^27: the low 32 bits are the whole value)
+     *   q1 = floor((float)r0 * inv): within 1 of floor(r0 / n)
+     *   q  = q0 + q1, then one step of fix-up in either direction on r1 = r0 - q1*n.
+     * The results go back to SGPRs through readlane so the coder recurrence stays on the scalar unit. */
+    static CBC_FN void muldiv2(uint32_t range, uint32_t lo, uint32_t hi, uint32_t n, float inv,
+                               uint32_t &ql, uint32_t &qh)
     {
-        uint64_t p = (uint64_t)range * c;
-        float pf = (float)(uint32_t)(p >> 16) * 65536.0f;
-        uint32_t q0 = to_scalar((uint32_t)(pf * rinv));
-        int32_t r0 = (int32_t)((uint32_t)p - q0 * n);
-        int32_t q1 = (int32_t)to_scalar((uint32_t)(int32_t)__builtin_floorf((float)r0 * rinv));
+        uint32_t c = lane() == 0u ? hi : lo;
+        uint32_t plo = range * c, phi = __umulhi(range, c);
+        float pf = (float)((phi << 16) | (plo >> 16)) * 65536.0f;
+        uint32_t q0 = (uint32_t)(pf * inv);
+        int32_t r0 = (int32_t)(plo - q0 * n);
+        int32_t q1 = (int32_t)__builtin_floorf((float)r0 * inv);
         int32_t r1 = r0 - q1 * (int32_t)n;
-        uint32_t q = q0 + (uint32_t)q1;
-        q -= (uint32_t)(r1 < 0);                  /* arithmetic, not an if-chain: keeps it on the SALU */
-        q += (uint32_t)(r1 >= (int32_t)n);
-        return q;
+        uint32_t q = q0 + (uint32_t)q1 - (uint32_t)(r1 < 0) + (uint32_t)(r1 >= (int32_t)n);
+        qh = (uint32_t)__builtin_amdgcn_readlane((int)q, 0);
+        ql = (uint32_t)__builtin_amdgcn_readlane((int)q, 1);
     }
-    static CBC_FN float recip(uint32_t n) { return __builtin_amdgcn_rcpf((float)n); }
+    /* reciprocals of all queued totals at once (lane k = k-th pending symbol) */
+    static CBC_FN V32 recip_v(V32 n) { float r = __builtin_amdgcn_rcpf((float)n); return __builtin_bit_cast(uint32_t, r); }
+    static CBC_FN float lane_float(V32 v, uint32_t k) { return __builtin_bit_cast(float, readlane(v, k)); }
 
     static CBC_FN uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }       /* x != 0 */
     static CBC_FN uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }     /* x != 0 */

@@ -85,29 +85,34 @@ struct WaveEmu {
     /* same f32 two-estimate formula as the GPU policy, cross-checked against exact integer division
      * on every call.  The reciprocal is deliberately perturbed by up to +-2 ulp (v_rcp_f32 is a 1-ulp
      * approximation, the CPU's 1.0f/x is correctly rounded) so the fix-up logic is exercised. */
-    static uint32_t muldiv(uint32_t range, uint32_t c, uint32_t n, float rinv)
+    static uint32_t muldiv1(uint32_t range, uint32_t c, uint32_t n, float inv)
     {
         uint64_t p = (uint64_t)range * c;
-        float pf = (float)(uint32_t)(p >> 16) * 65536.0f;
-        uint32_t q0 = (uint32_t)(pf * rinv);
-        int32_t r0 = (int32_t)((uint32_t)p - q0 * n);
-        int32_t q1 = (int32_t)__builtin_floorf((float)r0 * rinv);
+        uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
+        float pf = (float)((phi << 16) | (plo >> 16)) * 65536.0f;
+        uint32_t q0 = (uint32_t)(pf * inv);
+        int32_t r0 = (int32_t)(plo - q0 * n);
+        int32_t q1 = (int32_t)__builtin_floorf((float)r0 * inv);
         int32_t r1 = r0 - q1 * (int32_t)n;
-        uint32_t q = q0 + (uint32_t)q1;
-        if (r1 < 0) q -= 1u;
-        else if (r1 >= (int32_t)n) q += 1u;
+        uint32_t q = q0 + (uint32_t)q1 - (uint32_t)(r1 < 0) + (uint32_t)(r1 >= (int32_t)n);
         if (q != (uint32_t)(p / n)) emu_oob("muldiv f32 two-estimate mismatch");
         return q;
     }
-    static float recip(uint32_t n)
+    static void muldiv2(uint32_t range, uint32_t lo, uint32_t hi, uint32_t n, float inv, uint32_t &ql, uint32_t &qh)
+    { qh = muldiv1(range, hi, n, inv); ql = muldiv1(range, lo, n, inv); }
+    static V32 recip_v(const V32 &n)
     {
-        float r = 1.0f / (float)n;
-        static unsigned tick = 0;
-        uint32_t bits; memcpy(&bits, &r, 4);
-        bits += (uint32_t)((int)(tick++ % 5u) - 2);          /* -2..+2 ulp */
-        memcpy(&r, &bits, 4);
+        V32 r;
+        for (int i = 0; i < 64; i++) {
+            float f = n.v[i] ? 1.0f / (float)n.v[i] : 0.0f;
+            uint32_t bits; memcpy(&bits, &f, 4);
+            static unsigned tick = 0;
+            if (n.v[i]) bits += (uint32_t)((int)(tick++ % 5u) - 2);          /* -2..+2 ulp */
+            r.v[i] = bits;
+        }
         return r;
     }
+    static float lane_float(const V32 &v, uint32_t k) { float f; uint32_t b = readlane(v, k); memcpy(&f, &b, 4); return f; }
     static uint32_t clz32(uint32_t x) { if (!x) emu_oob("clz32(0)"); return (uint32_t)__builtin_clz(x); }
     static uint32_t ctz64(uint64_t x) { if (!x) emu_oob("ctz64(0)"); return (uint32_t)__builtin_ctzll(x); }
     static uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
