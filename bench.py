@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--block-reads", type=int, default=4096)
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real path); gloo = rehearsal of the N>1 host logic when "
+                         "several ranks must share one GPU (payloads take a detour through host memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -58,18 +61,27 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the cbc hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d GPUs; RCCL needs one GPU per rank (use --backend gloo to rehearse)"
+                         % (world, ndev))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     # ---- workload: this rank's shard (cfg2 shape), packed on the host, then made resident ----
     t0 = time.time()
     pb = host.synth(0xCBC00002 + rank, args.contig_len, args.reads, args.read_len, 0.003, 0.02, b"chr1",
                     block_reads=args.block_reads)
     t_gen = time.time() - t0
-    enc = gpu.Encoder(local_rank)
+    enc = gpu.Encoder(dev_index)
     L = gpu.lib()
     blocks = pb.blocks.copy()
     scratch_bytes = int(L.cbc_gpu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data))
@@ -101,7 +113,7 @@ def main():
         enc.compact_device(d_out.data_ptr(), d_blocks.data_ptr(), d_res.data_ptr(), n_blocks, d_offs.data_ptr(),
                            d_packed.data_ptr(), packed_cap, stream)
         if world > 1:
-            dist.gather(d_packed[:gather_cap], gather_list, dst=0)
+            dist.gather(d_packed[:gather_cap].to(cdev), gather_list, dst=0)
 
     # first launch: check every block finished and size the gather
     enc.encode_device(db, stream)
@@ -115,11 +127,11 @@ def main():
     payload_bytes = int(d_offs[-1].item())
     n_symbols = int(res["n_symbols"].sum())
     if world > 1:
-        m = torch.tensor([payload_bytes], dtype=torch.int64, device=dev)
+        m = torch.tensor([payload_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         gather_cap = min(packed_cap, (int(m.item()) + 4095) // 4096 * 4096)
         if rank == 0:
-            gather_list = [torch.empty(gather_cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+            gather_list = [torch.empty(gather_cap, dtype=torch.uint8, device=cdev) for _ in range(world)]
 
     for _ in range(args.warmup):
         step()
@@ -138,10 +150,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_bases, n_recs], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_bases, n_recs], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bases, total_recs = int(tot[0].item()), int(tot[1].item())
     else:
@@ -152,6 +164,19 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     alg_bytes = (2 * args.read_len + 18) * n_recs          # per launch, this rank
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3
+    # passes of this same command (profiles/README.md) are reported when the workload is the default one.
+    traffic, traffic_src = None, None
+    if args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+        if cands:
+            try:
+                traffic = json.load(open(cands[-1])).get("hbm_bytes_per_launch")
+                traffic_src = os.path.relpath(cands[-1], ROOT)
+            except Exception:
+                traffic = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -180,10 +205,10 @@ def main():
                        "lds_bytes_per_wave": lds_bytes, "payload_bytes_per_gpu": payload_bytes,
                        "bits_per_read": round(payload_bytes * 8.0 / n_recs, 3),
                        "symbols_per_read": round(n_symbols / n_recs, 3),
-                       "parallelism": "blocks sharded over %d GPU(s), gather of bitstreams to rank 0" % world,
+                       "parallelism": "blocks sharded over %d GPU(s), gather of bitstreams to rank 0 (%s)" % (world, args.backend),
                        "host_pack_seconds": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "cbc_encode_blocks_kernel", "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
