@@ -1,0 +1,671 @@
+/*
+ * cbc_decode_body.h -- one arithmetic stream per wavefront, decode direction.
+ *
+ * Mirror of cbc_encode_body.h: the same sparse/exact model tables, evolved by the same updates, but
+ * every symbol is FOUND from the coder's target value instead of looked up:
+ *   read_value_from_as()        src/stream_model.c:78-117      (linear search -> wave-parallel search)
+ *   arithmetic_get_symbol_range src/Arithmetic_stream.c:373-381
+ *   arithmetic_decoder_step     src/Arithmetic_stream.c:389-454 (E1/E2 + E3 loops in closed form)
+ *   decompress_rname / _read / _pos / _flag / reconstruct_read
+ *                               src/id_compression.c:67-94, src/read_decompression.c:59-529
+ * It is the exact inverse of this repository's encoder (same contexts, same snpInRef marks) and
+ * writes one reconstructed SEQ per record (what print_line, src/compression.c:16-40, ends up printing:
+ * the reference reverse-complements reverse-strand reads twice).  It does not reproduce the
+ * reference decoder's own quirks (header-length reads, the deltaPos rule of :365-369).
+ *
+ * Search for a symbol given the target t in [0, n): with e = count-1 and cum(x) = x + sum_{s<x} e[s],
+ * a SEEN symbol s owns [cum(s), cum(s)+1+e[s]) and an unseen symbol x owns the single value cum(x);
+ * so either t falls into a seen symbol's interval, or x = t - (sum of e over seen symbols that lie
+ * entirely below t).  Both tests are one compare per table entry + a ballot / wave sum.
+ */
+#ifndef CBC_DECODE_BODY_H
+#define CBC_DECODE_BODY_H
+
+#include <stdint.h>
+#include "../../include/cbc_gpu.h"
+#include "cbc_encode_body.h"      /* constants, lane-table map, cbc_basepair, cbc_le64 */
+
+/* LDS words of the decoder: the encoder's tables, then 4 x 256 pos_alpha byte histograms, three
+ * 256-entry edit lists, and a 320-byte scratch read */
+#define CBC_DLDS_HIST    CBC_LDS_FIXED                 /* 1024: registered POS deltas per byte value */
+#define CBC_DLDS_DELS    (CBC_LDS_FIXED + 1024u)       /* 256: deletion positions (matched coords)  */
+#define CBC_DLDS_INS     (CBC_LDS_FIXED + 1280u)       /* 256: (output index << 8) | base char      */
+#define CBC_DLDS_TMP     (CBC_LDS_FIXED + 1536u)       /* 80 words: insertion-free read, bytes      */
+#define CBC_DLDS_FIXED   (CBC_LDS_FIXED + 1616u)
+/* then pos_val[cap_pos], pos_cnt[cap_pos], var_ev[cap_var] */
+
+struct cbc_dec_args {
+    const uint8_t            *in;         /* payload bytes of all blocks                    */
+    const cbc_dec_block_desc *blocks;
+    const uint8_t            *ref;
+    cbc_read_rec             *recs;       /* out: pos (block-local), flag, rlen, seq_off    */
+    uint8_t                  *seq;        /* out: bases, seq_stride bytes reserved per read */
+    cbc_block_result         *results;
+    uint64_t in_bytes, ref_bytes, n_recs, seq_bytes;
+    uint32_t n_blocks, cap_pos, cap_var;
+};
+
+template <class W>
+struct CbcDec {
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+
+    /* ---- range decoder + bit reader ---- */
+    uint32_t l, u, t;
+    uint64_t acc; uint32_t navail;
+    V32 wordv; uint32_t widx, nwords_in, tail_valid; const uint8_t *inb;
+    uint32_t status, nsym, fail_read, cur_read;
+
+    /* ---- models (same representations as CbcEnc) ---- */
+    V32 small, fkey, fexc, hkey, hexc, pval, pcnt;
+    uint32_t fcount, fn, hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;
+    uint32_t *lds;
+    uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, cap_var, L0;
+    uint32_t prevPos, prevM, prevChar;
+    uint64_t w0, w1, w2, w3;
+
+    CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
+    CBC_MFN uint32_t *tab(uint32_t off) { return lds + off; }
+    CBC_MFN uint32_t *pos_val_p() { return lds + CBC_DLDS_FIXED; }
+    CBC_MFN uint32_t *pos_cnt_p() { return lds + CBC_DLDS_FIXED + cap_pos; }
+    CBC_MFN uint32_t *var_ev_p() { return lds + CBC_DLDS_FIXED + 2u * cap_pos; }
+
+    /* ---- bit input: 64 big-endian words staged in a VGPR, refilled with one coalesced load ---- */
+    CBC_MFN void load_chunk()
+    {
+        V32 ln = W::lane();
+        V32 wi = ln + widx;
+        V32 w = W::load32_bytes(inb, wi * 4u, wi < nwords_in);       /* past the end: zeros */
+        /* the last word may be partial: bytes past the payload read as zero, like the reference's
+         * zero-filled buffer past EOF (the bytes there belong to the next block's payload) */
+        w = W::select((wi + 1u == nwords_in) & (W::splat(tail_valid) != 0u), w & ((1u << (tail_valid * 8u)) - 1u), w);
+        wordv = w;
+    }
+    CBC_MFN uint32_t take(uint32_t k)                   /* next k <= 26 bits, MSB first */
+    {
+        if (k == 0u) return 0u;
+        if (navail < k) {
+            if ((widx & 63u) == 0u) load_chunk();
+            uint32_t w = W::bswap32(W::readlane(wordv, widx & 63u));
+            widx++;
+            acc = (acc << 32) | (uint64_t)w; navail += 32u;
+        }
+        navail -= k;
+        return (uint32_t)(acc >> navail) & ((1u << k) - 1u);
+    }
+    /* arithmetic_get_symbol_range, Arithmetic_stream.c:373-381 */
+    CBC_MFN uint32_t target(uint32_t n)
+    {
+        uint32_t range = u - l + 1u, gap = t - l + 1u;
+        if (n == 0u || gap == 0u || gap > range) { fail(CBC_ST_ASSERT); return 0u; }
+        uint64_t p = (uint64_t)gap * n - 1u;
+        return W::divq(p, range);
+    }
+    /* arithmetic_decoder_step, Arithmetic_stream.c:389-454, loops in closed form (cf. CbcEnc::code1) */
+    CBC_MFN void step(uint32_t lo, uint32_t cnt, uint32_t n)
+    {
+        if (cnt == 0u || n == 0u || lo + cnt > n) { fail(CBC_ST_ASSERT); return; }
+        nsym++;
+        uint32_t range = u - l + 1u, qh, ql;
+        float inv = W::lane_float(W::recip_v(W::splat(n)), 0u);
+        W::muldiv2(range, lo, lo + cnt, n, inv, ql, qh);
+        u = l + qh - 1u;
+        l = l + ql;
+        uint32_t x = l ^ u;
+        uint32_t k1 = x ? (W::clz32(x) - 6u) : 26u;
+        if (k1) {
+            uint32_t bits = take(k1);
+            l = (uint32_t)(((uint64_t)l << k1) & CBC_M26);
+            u = (uint32_t)((((uint64_t)u << k1) & CBC_M26) | ((1ull << k1) - 1ull));
+            t = (uint32_t)((((uint64_t)t << k1) & CBC_M26) | bits);
+        }
+        uint32_t y = ((l & ~u) & CBC_M25) << 7;
+        uint32_t k3 = W::clz32(~y);
+        if (k3) {
+            uint32_t bits = take(k3);
+            l = (l << k3) & CBC_M25;
+            u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
+            t = (uint32_t)(((((uint64_t)t << k3) & CBC_M26) ^ (1u << 25)) | bits);
+        }
+    }
+
+    /* ---- lane-table literal models (match, same_ref, chars) ---- */
+    CBC_MFN uint32_t small_dec(uint32_t base, uint32_t card, uint32_t stp)
+    {
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < card; j++) n += W::readlane(small, base + j);
+        uint32_t tg = target(n), lo = 0, cnt = 0, x = 0, found = 0;
+        for (uint32_t j = 0; j < card; j++) {
+            uint32_t c = W::readlane(small, base + j);
+            if (!found && tg < lo + c) { found = 1; x = j; cnt = c; }
+            if (!found) lo += c;
+        }
+        if (!found) { fail(CBC_ST_ASSERT); return 0u; }
+        step(lo, cnt, n);
+        V32 ln = W::lane();
+        small = W::select(ln == base + x, small + stp, small);
+        if (n + stp >= CBC_RESCALE) {
+            Mask m = (ln >= base) & (ln < base + card);
+            small = W::select(m, (small >> 1) + 1u, small);
+        }
+        return x;
+    }
+
+    /* ---- generic search over (key, excess) pairs held one per lane ---- */
+    CBC_MFN uint32_t pairs_search(V32 key, V32 exc, Mask live, uint32_t first, uint32_t count, uint32_t tg,
+                                  uint32_t &lo, uint32_t &cnt, uint32_t &hit_lane, bool &hit)
+    {
+        /* A = cum(key) = key + sum of the excess of all smaller keys */
+        V32 A = key;
+        for (uint32_t j = 0; j < count; j++) {
+            uint32_t kj = W::readlane(key, first + j), ej = W::readlane(exc, first + j);
+            A = A + W::select(key > kj, W::splat(ej), W::splat(0u));
+        }
+        uint64_t hb = W::ballot(live & (A <= tg) & (W::splat(tg) - A <= exc));
+        if (hb) {
+            hit = true; hit_lane = W::ctz64(hb);
+            lo = W::readlane(A, hit_lane); cnt = 1u + W::readlane(exc, hit_lane);
+            return W::readlane(key, hit_lane);
+        }
+        hit = false; hit_lane = 0;
+        uint32_t S = W::reduce_add(W::select(live & (A < tg), exc, W::splat(0u)));   /* A + e < tg here */
+        lo = tg; cnt = 1u;
+        return tg - S;
+    }
+
+    /* ---- register-resident sparse model (flag, codebook) ---- */
+    CBC_MFN uint32_t regsparse_dec(V32 &key, V32 &exc, uint32_t base, uint32_t cap, uint32_t &count, uint32_t &n,
+                                   uint32_t card, uint32_t stp, uint32_t cap_status)
+    {
+        V32 ln = W::lane();
+        Mask live = (ln >= base) & (ln < base + count);
+        uint32_t tg = target(n), lo, cnt, hl; bool hit;
+        uint32_t x = pairs_search(key, exc, live, base, count, tg, lo, cnt, hl, hit);
+        if (x >= card) { fail(CBC_ST_ASSERT); return 0u; }
+        step(lo, cnt, n);
+        if (hit) exc = W::select(ln == hl, exc + stp, exc);
+        else {
+            if (count >= cap) { fail(cap_status); return 0u; }
+            uint32_t idx = base + count;
+            key = W::select(ln == idx, W::splat(x), key);
+            exc = W::select(ln == idx, W::splat(stp), exc);
+            count++;
+        }
+        n += stp;
+        if (n >= CBC_RESCALE) {
+            live = (ln >= base) & (ln < base + count);
+            exc = W::select(live, (exc + 1u) >> 1, exc);
+            n = card + W::reduce_add(W::select(live, exc, W::splat(0u)));
+        }
+        return x;
+    }
+
+    /* ---- dense-excess tables in LDS: 4 consecutive symbols per lane, one wave scan ---- */
+    /* symbols 4*lane .. 4*lane+3 with excess e0..e3: find the one whose interval holds tg */
+    CBC_MFN uint32_t search4(V32 e0, V32 e1, V32 e2, V32 e3, uint32_t card, uint32_t tg, uint32_t &lo, uint32_t &cnt)
+    {
+        V32 s0 = W::lane() * 4u;
+        V32 tot = e0 + e1 + e2 + e3;
+        V32 c0 = s0 + (W::scan_incl_add(tot) - tot);          /* cum(4*lane) */
+        V32 c1 = c0 + 1u + e0, c2 = c1 + 1u + e1, c3 = c2 + 1u + e2, c4 = c3 + 1u + e3;
+        uint64_t h0 = W::ballot((s0 < card) & (c0 <= tg) & (tg < c1));
+        uint64_t h1 = W::ballot(((s0 + 1u) < card) & (c1 <= tg) & (tg < c2));
+        uint64_t h2 = W::ballot(((s0 + 2u) < card) & (c2 <= tg) & (tg < c3));
+        uint64_t h3 = W::ballot(((s0 + 3u) < card) & (c3 <= tg) & (tg < c4));
+        uint32_t x;
+        if (h0) { uint32_t hl = W::ctz64(h0); x = hl * 4u; lo = W::readlane(c0, hl); cnt = 1u + W::readlane(e0, hl); }
+        else if (h1) { uint32_t hl = W::ctz64(h1); x = hl * 4u + 1u; lo = W::readlane(c1, hl); cnt = 1u + W::readlane(e1, hl); }
+        else if (h2) { uint32_t hl = W::ctz64(h2); x = hl * 4u + 2u; lo = W::readlane(c2, hl); cnt = 1u + W::readlane(e2, hl); }
+        else if (h3) { uint32_t hl = W::ctz64(h3); x = hl * 4u + 3u; lo = W::readlane(c3, hl); cnt = 1u + W::readlane(e3, hl); }
+        else { fail(CBC_ST_ASSERT); x = 0; lo = 0; cnt = 1; }
+        return x;
+    }
+    CBC_MFN uint32_t dense_search(const uint32_t *exc, uint32_t card, uint32_t mul, uint32_t tg, uint32_t &lo, uint32_t &cnt)
+    {
+        V32 s0 = W::lane() * 4u;
+        V32 e0 = W::load32(exc, s0, s0 < card, 0u) * mul, e1 = W::load32(exc, s0 + 1u, (s0 + 1u) < card, 0u) * mul;
+        V32 e2 = W::load32(exc, s0 + 2u, (s0 + 2u) < card, 0u) * mul, e3 = W::load32(exc, s0 + 3u, (s0 + 3u) < card, 0u) * mul;
+        return search4(e0, e1, e2, e3, card, tg, lo, cnt);
+    }
+    CBC_MFN void dense_rescale(uint32_t *exc, uint32_t card, uint32_t &n)
+    {
+        V32 ln = W::lane();
+        V32 a = W::splat(0u);
+        const uint32_t cb = W::uni(card);
+        for (uint32_t b = 0; b < cb; b += 64u) {
+            V32 i = ln + b; Mask m = i < card;
+            V32 e = (W::load32(exc, i, m, 0u) + 1u) >> 1;
+            W::store32(exc, i, e, m);
+            a = a + W::select(m, e, W::splat(0u));
+        }
+        n = card + W::reduce_add(a);
+    }
+    CBC_MFN uint32_t dense_dec(uint32_t *exc, uint32_t card, uint32_t stp, uint32_t &n)
+    {
+        uint32_t tg = target(n), lo, cnt;
+        uint32_t x = dense_search(exc, card, 1u, tg, lo, cnt);
+        if (status != CBC_ST_OK) return 0u;
+        step(lo, cnt, n);
+        W::write_uni(exc, x, cnt - 1u + stp);
+        n += stp;
+        if (n >= CBC_RESCALE) dense_rescale(exc, card, n);
+        return x;
+    }
+
+    /* ---- rname: gather the context's pairs into lanes, then the generic search ---- */
+    CBC_MFN uint32_t rname_dec(uint32_t ctx)
+    {
+        V32 ln = W::lane();
+        uint32_t *rkey = tab(CBC_LDS_RNKEY), *rexc = tab(CBC_LDS_RNEXC);
+        V32 gk = W::splat(0u), ge = W::splat(0u), gi = W::splat(0u);
+        uint32_t m = 0, nsum = 0;
+        const uint32_t rb = W::uni(rn_count);
+        for (uint32_t b = 0; b < rb; b += 64u) {
+            V32 i = ln + b; Mask mm = i < rn_count;
+            V32 k = W::load32(rkey, i, mm, 0xffffffffu);
+            V32 e = W::load32(rexc, i, mm, 0u);
+            uint64_t bb = W::ballot(mm & ((k >> 8) == ctx));
+            while (bb) {
+                uint32_t src = W::ctz64(bb); bb &= bb - 1u;
+                uint32_t kk = W::readlane(k, src) & 0xffu, ee = W::readlane(e, src);
+                if (m < 64u) {
+                    gk = W::select(ln == m, W::splat(kk), gk); ge = W::select(ln == m, W::splat(ee), ge);
+                    gi = W::select(ln == m, W::splat(b + src), gi);
+                }
+                m++; nsum += ee;
+            }
+        }
+        if (m > 64u) { fail(CBC_ST_CAP_NAME); return 0u; }
+        uint32_t n = 256u + nsum;
+        if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return 0u; }
+        uint32_t tg = target(n), lo, cnt, hl; bool hit;
+        uint32_t x = pairs_search(gk, ge, ln < m, 0u, m, tg, lo, cnt, hl, hit);
+        if (x >= 256u) { fail(CBC_ST_ASSERT); return 0u; }
+        step(lo, cnt, n);
+        if (hit) W::write_uni(rexc, W::readlane(gi, hl), cnt - 1u + 10u);
+        else {
+            if (rn_count >= CBC_CAP_NAME) { fail(CBC_ST_CAP_NAME); return 0u; }
+            W::write_uni(rkey, rn_count, (ctx << 8) | x);
+            W::write_uni(rexc, rn_count, 10u);
+            rn_count++;
+        }
+        return x;
+    }
+
+    /* ---- pos: literal counts, two tiers (cf. CbcEnc::pos_code) ---- */
+    CBC_MFN void pos_rescale()
+    {
+        V32 ln = W::lane();
+        Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
+        pcnt = W::select(m0, (pcnt >> 1) + 1u, pcnt);
+        V32 a = W::select(m0, pcnt, W::splat(0u));
+        const uint32_t pc = W::uni(pos_card);
+        for (uint32_t b = 64u; b < pc; b += 64u) {
+            V32 i = ln + b; Mask m = i < pos_card;
+            V32 c = (W::load32(pos_cnt_p(), i, m, 0u) >> 1) + 1u;
+            W::store32(pos_cnt_p(), i, c, m);
+            a = a + W::select(m, c, W::splat(0u));
+        }
+        pos_n = W::reduce_add(a);
+    }
+    CBC_MFN void pos_update(uint32_t idx)
+    {
+        if (idx < 64u) pcnt = W::select(W::lane() == idx, pcnt + 10u, pcnt);
+        else W::write_uni(pos_cnt_p(), idx, W::read_uni(pos_cnt_p(), idx) + 10u);
+        pos_n += 10u;
+        if (pos_n >= CBC_RESCALE) pos_rescale();
+    }
+    CBC_MFN uint32_t pos_alpha_dec(uint32_t k)           /* one byte of decompress_pos_alpha :144-181 */
+    {
+        uint32_t n = 256u + 10u * (pos_card - 1u);
+        if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return 0u; }
+        uint32_t tg = target(n), lo, cnt;
+        uint32_t x = dense_search(tab(CBC_DLDS_HIST) + 256u * k, 256u, 10u, tg, lo, cnt);
+        if (status != CBC_ST_OK) return 0u;
+        step(lo, cnt, n);
+        return x;
+    }
+    CBC_MFN uint32_t pos_dec()                           /* returns x = delta + 1 */
+    {
+        V32 ln = W::lane();
+        uint32_t tg = target(pos_n);
+        Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
+        V32 c = W::select(m0, pcnt, W::splat(0u));
+        V32 inc = W::scan_incl_add(c);
+        uint64_t hb = W::ballot(m0 & ((inc - c) <= tg) & (tg < inc));
+        uint32_t idx = 0, lo = 0, cnt = 0, found = 0;
+        if (hb) { idx = W::ctz64(hb); lo = W::readlane(inc, idx) - W::readlane(c, idx); cnt = W::readlane(c, idx); found = 1; }
+        else {
+            uint32_t base_sum = W::readlane(inc, 63u);
+            const uint32_t pc = W::uni(pos_card);
+            for (uint32_t b = 64u; b < pc && !found; b += 64u) {
+                V32 i = ln + b; Mask m = i < pos_card;
+                V32 cc = W::load32(pos_cnt_p(), i, m, 0u);
+                V32 ic = W::scan_incl_add(cc) + base_sum;
+                uint64_t h2 = W::ballot(m & ((ic - cc) <= tg) & (tg < ic));
+                if (h2) { uint32_t hl = W::ctz64(h2); idx = b + hl; lo = W::readlane(ic, hl) - W::readlane(cc, hl); cnt = W::readlane(cc, hl); found = 1; }
+                base_sum = W::readlane(ic, 63u);
+            }
+        }
+        if (!found) { fail(CBC_ST_ASSERT); return 0u; }
+        step(lo, cnt, pos_n);
+        pos_update(idx);
+        if (idx != 0u) return idx < 64u ? W::readlane(pval, idx) : W::read_uni(pos_val_p(), idx);
+        uint32_t b3 = pos_alpha_dec(0u), b2 = pos_alpha_dec(1u), b1 = pos_alpha_dec(2u), b0 = pos_alpha_dec(3u);
+        uint32_t x = (b3 << 24) | (b2 << 16) | (b1 << 8) | b0;
+        if (status != CBC_ST_OK) return 0u;
+        if (pos_card >= cap_pos) { fail(CBC_ST_CAP_POS); return 0u; }
+        uint32_t *hist = tab(CBC_DLDS_HIST);
+        W::write_uni(hist, b3, W::read_uni(hist, b3) + 1u);
+        W::write_uni(hist, 256u + b2, W::read_uni(hist, 256u + b2) + 1u);
+        W::write_uni(hist, 512u + b1, W::read_uni(hist, 512u + b1) + 1u);
+        W::write_uni(hist, 768u + b0, W::read_uni(hist, 768u + b0) + 1u);
+        if (pos_card < 64u) {
+            pval = W::select(ln == pos_card, W::splat(x), pval);
+            pcnt = W::select(ln == pos_card, W::splat(0u), pcnt);
+        } else {
+            W::write_uni(pos_val_p(), pos_card, x);
+            W::write_uni(pos_cnt_p(), pos_card, 0u);
+        }
+        pos_card++;
+        pos_update(pos_card - 1u);
+        return x;
+    }
+
+    /* ---- var: Bloom filter, then gather the context's events (each worth 10) into lanes ---- */
+    CBC_MFN uint32_t var_dec(uint32_t ctx)
+    {
+        if (ctx >= CBC_NVARCTX) { fail(CBC_ST_ASSERT); return 0u; }
+        V32 ln = W::lane();
+        uint32_t *bloom = tab(CBC_LDS_BLOOM), *ev = var_ev_p();
+        const uint32_t h = (ctx * 0x9E3779B1u) >> 19;
+        const uint32_t bw = W::read_uni(bloom, h >> 5), bbit = 1u << (h & 31u);
+        /* per-symbol excess of this context, 4 symbols per lane, built from the event list */
+        V32 e0 = W::splat(0u), e1 = W::splat(0u), e2 = W::splat(0u), e3 = W::splat(0u);
+        uint32_t m = 0;
+        if (bw & bbit) {
+            const uint32_t nb = W::uni(nev);
+            for (uint32_t b = 0; b < nb; b += 64u) {
+                V32 i = ln + b; Mask mm = i < nev;
+                V32 e = W::load32(ev, i, mm, 0xffffffffu);
+                uint64_t bb = W::ballot(mm & ((e >> 8) == ctx));
+                while (bb) {
+                    uint32_t src = W::ctz64(bb); bb &= bb - 1u;
+                    uint32_t kk = W::readlane(e, src) & 0xffu;
+                    Mask hitl = ln == (kk >> 2);
+                    uint32_t sub = kk & 3u;
+                    e0 = W::select(hitl & (sub == 0u), e0 + 10u, e0);
+                    e1 = W::select(hitl & (sub == 1u), e1 + 10u, e1);
+                    e2 = W::select(hitl & (sub == 2u), e2 + 10u, e2);
+                    e3 = W::select(hitl & (sub == 3u), e3 + 10u, e3);
+                    m++;
+                }
+            }
+        } else W::write_uni(bloom, h >> 5, bw | bbit);
+        uint32_t n = L0 + 10u * m;
+        uint32_t tg = target(n), x, lo, cnt;
+        if (m == 0u) { x = tg; lo = tg; cnt = 1u; }
+        else x = search4(e0, e1, e2, e3, L0, tg, lo, cnt);
+        if (status != CBC_ST_OK) return 0u;
+        if (x >= L0) { fail(CBC_ST_ASSERT); return 0u; }
+        step(lo, cnt, n);
+        if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return 0u; }
+        W::write_uni(ev, nev, (ctx << 8) | x);
+        nev++;
+        return x;
+    }
+
+    /* ---- snpInRef window (same as the encoder's) ---- */
+    CBC_MFN void win_clear() { w0 = w1 = w2 = w3 = 0; }
+    CBC_MFN void win_shift(uint32_t d)
+    {
+        if (d == 0u) return;
+        if (d >= 256u) { win_clear(); return; }
+        uint32_t wsh = d >> 6, bsh = d & 63u;
+        if (wsh == 1u) { w0 = w1; w1 = w2; w2 = w3; w3 = 0; }
+        else if (wsh == 2u) { w0 = w2; w1 = w3; w2 = 0; w3 = 0; }
+        else if (wsh == 3u) { w0 = w3; w1 = 0; w2 = 0; w3 = 0; }
+        if (bsh) {
+            uint32_t inv = 64u - bsh;
+            w0 = (w0 >> bsh) | (w1 << inv); w1 = (w1 >> bsh) | (w2 << inv);
+            w2 = (w2 >> bsh) | (w3 << inv); w3 = w3 >> bsh;
+        }
+    }
+    CBC_MFN uint32_t win_first(uint32_t p, uint32_t rl)
+    {
+        uint32_t out = rl + 2u;
+        if (p >= rl) return out;
+        uint32_t pw = p >> 6; uint64_t pm = ~0ull << (p & 63u);
+        uint64_t a0 = pw == 0u ? (w0 & pm) : 0ull;
+        uint64_t a1 = pw == 1u ? (w1 & pm) : (pw < 1u ? w1 : 0ull);
+        uint64_t a2 = pw == 2u ? (w2 & pm) : (pw < 2u ? w2 : 0ull);
+        uint64_t a3 = pw == 3u ? (w3 & pm) : w3;
+        uint32_t pos = 0xffffffffu;
+        if (a0) pos = W::ctz64(a0);
+        else if (a1) pos = 64u + W::ctz64(a1);
+        else if (a2) pos = 128u + W::ctz64(a2);
+        else if (a3) pos = 192u + W::ctz64(a3);
+        if (pos < rl) out = pos - p;
+        return out;
+    }
+    CBC_MFN void win_set(uint32_t k)
+    {
+        uint64_t bit = 1ull << (k & 63u); uint32_t kw = k >> 6;
+        w0 |= (kw == 0u) ? bit : 0ull; w1 |= (kw == 1u) ? bit : 0ull;
+        w2 |= (kw == 2u) ? bit : 0ull; w3 |= (kw == 3u) ? bit : 0ull;
+    }
+};
+
+CBC_FN uint32_t cbc_basechar(uint32_t b)             /* basepair2char sam_models.c:23-33 */
+{
+    return b == 0u ? 'A' : b == 1u ? 'C' : b == 2u ? 'G' : b == 3u ? 'T' : 'N';
+}
+
+/* ===========================================================================================
+ * cbc_decode_stream: decode block `blk` completely.
+ * =========================================================================================== */
+template <class W>
+CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
+{
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+    const V32 ln = W::lane();
+    const cbc_dec_block_desc *bd = A.blocks + blk;
+    CbcDec<W> D;
+
+    const uint64_t in_off = bd->in_off, ref_off = bd->ref_off, rec_base = bd->rec_base, seq_base = bd->seq_base;
+    const uint32_t in_bytes = bd->in_bytes, n_reads = bd->n_reads, L0 = bd->read_length, stride = bd->seq_stride;
+
+    D.status = CBC_ST_OK; D.nsym = 0; D.fail_read = 0; D.cur_read = 0;
+    D.l = 0; D.u = CBC_M26; D.t = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
+    D.inb = A.in + in_off;
+    D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = A.cap_var; D.L0 = L0;
+    /* the payload buffer must leave 3 spare bytes after the last payload (whole-dword reads) */
+    bool args_ok = cbc_le64(in_off + (((uint64_t)in_bytes + 3u) & ~3ull), A.in_bytes) && cbc_le64(rec_base + n_reads, A.n_recs) &&
+                   cbc_le64(seq_base + (uint64_t)n_reads * stride + 8u, A.seq_bytes) && (L0 >= 1u && L0 <= 256u) &&
+                   (stride >= 4u && stride <= 256u && (stride & 3u) == 0u) && cbc_le64(ref_off, A.ref_bytes);
+    D.nwords_in = (in_bytes + 3u) >> 2;
+    D.tail_valid = in_bytes & 3u;
+    if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
+
+    for (uint32_t b = 0; b < CBC_DLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_DLDS_FIXED);
+    D.rlen_n = 255u; D.rl123_c0 = 1u; D.rl123_n = 255u; D.snps_n = L0; D.indels_n = L0; D.rn_count = 0;
+    D.pos_card = 1u; D.pos_n = 1u; D.nev = 0;
+    D.pval = W::splat(0xffffffffu); D.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
+    D.fkey = W::splat(0u); D.fexc = W::splat(0u); D.fcount = 0; D.fn = 65536u;
+    D.hkey = W::splat(0u); D.hexc = W::splat(0u);
+    D.hc0 = D.hc1 = D.hc2 = D.hc3 = 0; D.hn0 = D.hn1 = D.hn2 = D.hn3 = 256u;
+    {
+        V32 s = W::select(ln < 10u, W::splat(1u), W::splat(0u));
+        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
+        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
+        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
+        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
+                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
+        cv = W::select(bump, cv + 8u, cv);
+        D.small = W::select(inch, cv, s);
+    }
+    D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
+
+    /* the tag: first 26 bits (alloc_arithmetic_stream, Arithmetic_stream.c:260-263) */
+    if (D.status == CBC_ST_OK) D.t = D.take(26u);
+
+    /* stream header: int(L0), 32 x int(WELL), int(8) */
+    for (uint32_t k = 0; k < 34u && D.status == CBC_ST_OK; k++) {
+        uint32_t v = D.regsparse_dec(D.hkey, D.hexc, 0u, 8u, D.hc0, D.hn0, 256u, 1u, CBC_ST_ASSERT) << 24;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 8u, 8u, D.hc1, D.hn1, 256u, 1u, CBC_ST_ASSERT) << 16;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 16u, 8u, D.hc2, D.hn2, 256u, 1u, CBC_ST_ASSERT) << 8;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 24u, 8u, D.hc3, D.hn3, 256u, 1u, CBC_ST_ASSERT);
+        if (D.status != CBC_ST_OK) break;
+        if (k == 0u && v != L0) D.fail(CBC_ST_ASSERT);            /* container and stream disagree */
+        if (k == 33u && v != 8u) D.fail(CBC_ST_UNSUPPORTED);       /* LOSSY streams are out of scope */
+    }
+
+    uint4 *recs4 = (uint4 *)(A.recs + rec_base);
+    uint8_t *seqo = A.seq + seq_base;
+    const uint8_t *refb = A.ref + ref_off;
+    const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
+    const uint32_t ref_lim = cbc_avail32(ref_avail, 0u);
+    uint8_t *tmpb = (uint8_t *)(lds + CBC_DLDS_TMP);
+    uint32_t *dels = lds + CBC_DLDS_DELS, *insl = lds + CBC_DLDS_INS;
+
+    for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) {
+        D.cur_read = r;
+        /* -- decompress_rname (id_compression.c:67-94) -- */
+        uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
+        if (D.status != CBC_ST_OK) break;
+        if (r == 0u) {
+            if (sr != 1u) { D.fail(CBC_ST_ASSERT); break; }
+            for (uint32_t q = 0; q < CBC_CAP_NAME && D.status == CBC_ST_OK; q++) {
+                uint32_t ch = D.rname_dec(D.prevChar);
+                if (ch == 0u) break;
+                if (ch == (uint32_t)'\n' && q == 0u) { D.fail(CBC_ST_ASSERT); break; }   /* empty block */
+                D.prevChar = ch;
+            }
+            D.prevPos = 0; D.win_clear();
+        } else if (sr != 0u) { D.fail(CBC_ST_ASSERT); break; }     /* one contig per block */
+        if (D.status != CBC_ST_OK) break;
+
+        /* -- read length (read_decompression.c:68-74): only the low byte carries information (Q1) -- */
+        uint32_t rl = D.dense_dec(D.tab(CBC_LDS_RLEN), 255u, 10u, D.rlen_n);
+        for (int k = 1; k < 4 && D.status == CBC_ST_OK; k++) {
+            uint32_t tg = D.target(D.rl123_n);
+            if (tg >= D.rl123_c0) { D.fail(CBC_ST_ASSERT); break; }
+            D.step(0u, D.rl123_c0, D.rl123_n);
+        }
+        D.rl123_c0 += 10u; D.rl123_n += 10u;
+        if (D.rl123_n >= CBC_RESCALE) { D.rl123_c0 = (D.rl123_c0 >> 1) + 1u; D.rl123_n = 254u + D.rl123_c0; }
+        if (D.status != CBC_ST_OK) break;
+        if (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride) { D.fail(CBC_ST_ASSERT); break; }
+
+        /* -- pos, flag -- */
+        uint32_t x = D.pos_dec();
+        if (D.status != CBC_ST_OK) break;
+        if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); break; }
+        uint32_t pos = D.prevPos + x - 1u;
+        D.win_shift(r == 0u ? 256u : x - 1u);
+        D.prevPos = pos;
+        uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
+        if (D.status != CBC_ST_OK) break;
+        const uint32_t strand = (flag >> 4) & 1u;
+        if (pos == 0u || pos + rl + 3u + 256u > ref_lim) { D.fail(CBC_ST_ASSERT); break; }
+
+        /* -- match -- */
+        uint32_t match = D.small_dec(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | D.prevM) * 2u, 2u, 1u);
+        if (D.status != CBC_ST_OK) break;
+        D.prevM = match;
+        uint8_t *dst = seqo + (uint64_t)r * stride;
+        V32 bo = ln * 4u;
+        if (match) {
+            V32 w = W::load32_bytes(refb + (pos - 1u), bo, bo < rl);
+            W::store32_bytes(dst, bo, w, bo < rl);                 /* stride >= rl rounded to 4 */
+        } else {
+            uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
+            if (D.status == CBC_ST_OK && nSnp == 0u) {
+                nSnp = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nDel = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nIns = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+            }
+            if (D.status != CBC_ST_OK) break;
+            if (nIns > rl) { D.fail(CBC_ST_ASSERT); break; }
+            const uint32_t T = rl - nIns;                          /* insertion-free length */
+            /* deletions: cumulative matched coordinate of each deleted base */
+            uint32_t p = 0;
+            for (uint32_t d = 0; d < nDel && D.status == CBC_ST_OK; d++) {
+                uint32_t g = D.var_dec((p << 1) | strand);
+                p += g;
+                W::write_uni(dels, d, p);
+            }
+            if (D.status != CBC_ST_OK) break;
+            /* insertion-free read from the reference: base m comes from ref[pos-1 + m + #{dels at <= m}] */
+            for (uint32_t b = 0; b < T; b += 64u) {
+                V32 m = ln + b;
+                V32 sh = W::splat(0u);
+                for (uint32_t d = 0; d < nDel; d++) { uint32_t dc = W::read_uni(dels, d); sh = sh + W::select(m >= dc, W::splat(1u), W::splat(0u)); }
+                V32 ch = W::load8(refb + (pos - 1u), m + sh, (m < T) & ((m + sh) < 512u));
+                W::store8(tmpb, m, ch, m < T);
+            }
+            /* SNPs (read_decompression.c:440-458) */
+            p = 0;
+            for (uint32_t s = 0; s < nSnp && D.status == CBC_ST_OK; s++) {
+                uint32_t dl = D.win_first(p, rl);
+                uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
+                if (D.status != CBC_ST_OK) break;
+                uint32_t at = p + g;
+                p += g + 1u;
+                D.win_set(p - 1u);
+                uint32_t refch = at < T ? ((W::read_uni(lds + CBC_DLDS_TMP, at >> 2) >> ((at & 3u) * 8u)) & 0xffu) : 0u;
+                uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
+                if (at < T) {
+                    uint32_t wv = W::read_uni(lds + CBC_DLDS_TMP, at >> 2), shf = (at & 3u) * 8u;
+                    W::write_uni(lds + CBC_DLDS_TMP, at >> 2, (wv & ~(0xffu << shf)) | (cbc_basechar(alt) << shf));
+                }
+            }
+            if (D.status != CBC_ST_OK) break;
+            /* insertions: output index = matched coordinate + number of earlier insertions */
+            p = 0;
+            for (uint32_t i = 0; i < nIns && D.status == CBC_ST_OK; i++) {
+                uint32_t g = D.var_dec((p << 1) | strand);
+                p += g;
+                uint32_t base = D.small_dec(CBC_LT_CHARS + 5u * 8u, 5u, 8u);
+                W::write_uni(insl, i, ((p + i) << 8) | cbc_basechar(base));
+            }
+            if (D.status != CBC_ST_OK) break;
+            for (uint32_t b = 0; b < rl; b += 64u) {
+                V32 q = ln + b;
+                V32 nb = W::splat(0u), isins = W::splat(0u), ich = W::splat(0u);
+                for (uint32_t i = 0; i < nIns; i++) {
+                    uint32_t e = W::read_uni(insl, i), oi = e >> 8;
+                    nb = nb + W::select(q > oi, W::splat(1u), W::splat(0u));
+                    Mask here = q == oi;
+                    isins = W::select(here, W::splat(1u), isins);
+                    ich = W::select(here, W::splat(e & 0xffu), ich);
+                }
+                V32 m = q - nb;
+                V32 ch = W::load8(tmpb, m, (q < rl) & (m < 320u) & (isins == 0u));
+                ch = W::select(isins != 0u, ich, ch);
+                W::store8(dst, q, ch, q < rl);
+            }
+        }
+        /* record */
+        V32 rv0 = W::splat(pos), rv1 = W::splat(flag | (rl << 16)), rv2 = W::splat(r * stride), rv3 = W::splat(0u);
+        W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
+    }
+
+    /* sentinel: same_ref(1), '\n', NUL (compression.c:152; decompress_rname returns -1 on it) */
+    if (D.status == CBC_ST_OK) {
+        D.cur_read = n_reads;
+        uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
+        if (D.status == CBC_ST_OK && sr != 1u) D.fail(CBC_ST_ASSERT);
+        if (D.status == CBC_ST_OK) {
+            uint32_t ch = D.rname_dec(D.prevChar);
+            if (D.status == CBC_ST_OK && ch != (uint32_t)'\n') D.fail(CBC_ST_ASSERT);
+            if (D.status == CBC_ST_OK && D.rname_dec((uint32_t)'\n') != 0u) D.fail(CBC_ST_ASSERT);
+        }
+    }
+    V32 resv = W::select(ln == 0u, W::splat(D.status == CBC_ST_OK ? n_reads : D.cur_read), W::select(ln == 1u, W::splat(D.status),
+               W::select(ln == 2u, W::splat(D.nsym), W::splat(D.fail_read))));
+    W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);
+}
+
+#endif /* CBC_DECODE_BODY_H */

@@ -14,6 +14,7 @@
 #include "../../include/cbc_gpu.h"
 #include "cbc_wave_gpu.h"
 #include "cbc_encode_body.h"
+#include "cbc_decode_body.h"
 #include "cbc_plan.h"
 
 #define API extern "C" __attribute__((visibility("default")))
@@ -32,6 +33,14 @@ cbc_encode_blocks_kernel(cbc_enc_args A)
     uint32_t blk = blockIdx.x;
     if (blk >= A.n_blocks) return;
     cbc_encode_stream<WaveGPU>(A, blk, cbc_lds);
+}
+
+__global__ void __launch_bounds__(64)
+cbc_decode_blocks_kernel(cbc_dec_args A)
+{
+    uint32_t blk = blockIdx.x;
+    if (blk >= A.n_blocks) return;
+    cbc_decode_stream<WaveGPU>(A, blk, cbc_lds);
 }
 
 /* exclusive scan of the per-block payload sizes -> offsets[n_blocks+1]; one workgroup */
@@ -115,6 +124,7 @@ API int cbc_gpu_init(int device_ordinal, cbc_gpu_ctx **out)
     }
     /* the kernel's dynamic LDS can exceed the 64 KiB default */
     (void)hipFuncSetAttribute((const void *)cbc_encode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)cbc_decode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return CBC_OK;
 }
@@ -278,5 +288,85 @@ done:
     if (d_recs) (void)hipFree(d_recs); if (d_seq) (void)hipFree(d_seq); if (d_tok) (void)hipFree(d_tok);
     if (d_names) (void)hipFree(d_names); if (d_blocks) (void)hipFree(d_blocks); if (d_out) (void)hipFree(d_out);
     if (d_res) (void)hipFree(d_res); if (d_off) (void)hipFree(d_off); if (d_packed) (void)hipFree(d_packed);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * decode direction
+ * ---------------------------------------------------------------------------------------------- */
+API uint32_t cbc_gpu_decode_lds_bytes(const cbc_lds_caps *caps) { return caps ? cbc_plan_dec_lds_bytes(caps) : 0; }
+
+API int cbc_gpu_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batch *b, void *hip_stream)
+{
+    if (!ctx || !b) return CBC_E_ARG;
+    if (b->n_blocks == 0) return CBC_OK;
+    if (!b->d_in || !b->d_blocks || !b->d_ref || !b->d_recs || !b->d_seq || !b->d_results)
+        return set_err(ctx, CBC_E_ARG, "null device pointer in cbc_dec_device_batch", hipSuccess);
+    if (b->caps.cap_pos < 2 || b->caps.cap_pos > 8192 || b->caps.cap_var < 1 || b->caps.cap_var > 32768)
+        return set_err(ctx, CBC_E_ARG, "lds caps out of range", hipSuccess);
+    const uint32_t lds = cbc_plan_dec_lds_bytes(&b->caps);
+    if (lds > 160u * 1024u) return set_err(ctx, CBC_E_ARG, "lds caps need more than 160 KiB", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    cbc_dec_args A;
+    A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
+    A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
+    A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
+    hipLaunchKernelGGL(cbc_decode_blocks_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
+    HIPCHK(hipGetLastError(), "launch cbc_decode_blocks_kernel");
+    HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
+    ctx->have_timing = 1;
+    return CBC_OK;
+}
+
+API int cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
+                              uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
+                              uint8_t *seq, uint64_t seq_bytes, cbc_block_result *results)
+{
+    if (!ctx || !in || !blocks || !caps || !recs || !seq) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    if (n_blocks == 0) return CBC_OK;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    void *d_in = NULL, *d_blocks = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL;
+    cbc_block_result *res = NULL;
+    int rc = CBC_OK;
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_in, in_bytes + 16), "hipMalloc in");
+    GO(hipMalloc(&d_blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc)), "hipMalloc blocks");
+    GO(hipMalloc(&d_recs, n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
+    GO(hipMalloc(&d_seq, seq_bytes + 16), "hipMalloc seq");
+    GO(hipMalloc(&d_res, (uint64_t)n_blocks * sizeof(cbc_block_result)), "hipMalloc results");
+    GO(hipMemsetAsync((uint8_t *)d_in + in_bytes, 0, 16, ctx->stream), "memset pad");
+    GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D payloads");
+    GO(hipMemcpyAsync(d_blocks, blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
+    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)n_blocks * sizeof(cbc_block_result), ctx->stream), "memset results");
+    GO(hipMemsetAsync(d_seq, 0, seq_bytes + 16, ctx->stream), "memset seq");
+    {
+        cbc_dec_device_batch db;
+        memset(&db, 0, sizeof db);
+        db.d_in = (const uint8_t *)d_in; db.in_bytes = in_bytes + 16; db.d_blocks = (const cbc_dec_block_desc *)d_blocks;
+        db.n_blocks = n_blocks; db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = (cbc_read_rec *)d_recs;
+        db.n_recs = n_recs; db.d_seq = (uint8_t *)d_seq; db.seq_bytes = seq_bytes + 16; db.d_results = (cbc_block_result *)d_res;
+        db.caps = *caps;
+        rc = cbc_gpu_decode_blocks_device(ctx, &db, NULL);
+        if (rc) goto done;
+    }
+    res = results ? results : (cbc_block_result *)malloc((size_t)n_blocks * sizeof(cbc_block_result));
+    if (!res) { rc = CBC_E_NOMEM; goto done; }
+    GO(hipMemcpyAsync(res, d_res, (uint64_t)n_blocks * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
+    GO(hipMemcpyAsync(recs, d_recs, n_recs * sizeof(cbc_read_rec), hipMemcpyDeviceToHost, ctx->stream), "D2H recs");
+    GO(hipMemcpyAsync(seq, d_seq, seq_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H seq");
+    GO(hipStreamSynchronize(ctx->stream), "decode kernel");
+    for (uint32_t b = 0; b < n_blocks; b++)
+        if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
+            snprintf(ctx->err, sizeof ctx->err, "block %u failed to decode with status %u at record %u", b, res[b].status, res[b].fail_read);
+            rc = CBC_E_BLOCK;
+        }
+done:
+#undef GO
+    if (res && res != results) free(res);
+    if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
+    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res);
     return rc;
 }

@@ -329,6 +329,7 @@ static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos
     memcpy(P->tok + P->n_tok, tk, sizeof(uint32_t) * nt); P->n_tok += nt;
     S->blk_reads++; S->blk_bases += rl; S->blk_prev_pos = pos;
     P->n_bases += rl;
+    if (rl > P->max_read_len) P->max_read_len = (uint32_t)rl;
     return 0;
 }
 
@@ -605,16 +606,18 @@ done:
 }
 
 /* ================================= block container ======================================== */
-/* layout (little-endian):
- *   u32 magic "CBCB", u32 version, u32 read_length, u32 n_contigs, u32 n_blocks, u32 names_bytes
+/* layout (little-endian), version 2:
+ *   u32 magic "CBCB", u32 version, u32 read_length, u32 n_contigs, u32 n_blocks, u32 names_bytes,
+ *   u32 cap_pos, u32 cap_var, u32 max_read_len                                   (36 bytes)
  *   names blob, padded to 4
  *   n_contigs x { u32 name_off, u32 reserved, u64 length }
  *   n_blocks  x { u32 contig, u32 n_reads, u64 window_start, u64 payload_off, u32 payload_bytes, u32 reserved }
  *   payloads, concatenated in block order
  */
+#define CBC_CONTAINER_HDR 36ull
 static uint64_t container_header_bytes(const cbc_packed *p)
 {
-    return 24ull + ((p->names_bytes + 3u) & ~3u) + 16ull * p->n_contigs + 32ull * p->n_blocks;
+    return CBC_CONTAINER_HDR + ((p->names_bytes + 3u) & ~3u) + 16ull * p->n_contigs + 32ull * p->n_blocks;
 }
 API int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets)
 {
@@ -632,6 +635,7 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
     uint8_t *d = dst;
     w32(&d, CBC_CONTAINER_MAGIC); w32(&d, CBC_CONTAINER_VERSION); w32(&d, p->read_length);
     w32(&d, p->n_contigs); w32(&d, p->n_blocks); w32(&d, p->names_bytes);
+    w32(&d, p->caps.cap_pos); w32(&d, p->caps.cap_var); w32(&d, p->max_read_len);
     uint32_t nb = (p->names_bytes + 3u) & ~3u;
     memset(d, 0, nb); memcpy(d, p->names, p->names_bytes); d += nb;
     for (uint32_t i = 0; i < p->n_contigs; i++) { w32(&d, p->contigs[i].name_off); w32(&d, 0); w64(&d, p->contigs[i].length); }
@@ -641,4 +645,91 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
     }
     memcpy(d, payloads, (size_t)out_offsets[p->n_blocks]);
     return (int64_t)total;
+}
+
+/* ================================= unpack side ============================================ */
+static uint32_t r32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t r64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+API void cbc_unpack_plan_free(cbc_unpack_plan *u)
+{
+    if (!u) return;
+    free(u->blocks); free(u->window_start); free(u->ref); free(u);
+}
+
+/* Parse a container, load the FASTA the way the packer does (contigs in file order, upper-cased,
+ * padded) and lay out the decode launch: one cbc_dec_block_desc per block. */
+API int cbc_unpack_plan_create(const uint8_t *blob, uint64_t len, const char *fasta, size_t fasta_len,
+                               cbc_unpack_plan **out, char *errbuf, size_t errlen)
+{
+    if (!blob || !fasta || !out) return CBC_E_ARG;
+    *out = NULL;
+    packer_t *S = (packer_t *)calloc(1, sizeof(packer_t));
+    cbc_unpack_plan *u = (cbc_unpack_plan *)calloc(1, sizeof(cbc_unpack_plan));
+    if (!S || !u) { free(S); free(u); return CBC_E_NOMEM; }
+    S->err = errbuf; S->errlen = errlen;
+    if (errbuf && errlen) errbuf[0] = 0;
+    int rc = 0;
+    S->P = (cbc_packed *)calloc(1, sizeof(cbc_packed));
+    if (!S->P) { rc = CBC_E_NOMEM; goto fail; }
+    if (len < CBC_CONTAINER_HDR || r32(blob) != CBC_CONTAINER_MAGIC) { rc = fail(S, CBC_E_INPUT, "not a cbc block container%s%lld", "", 0); goto fail; }
+    if (r32(blob + 4) != CBC_CONTAINER_VERSION) { rc = fail(S, CBC_E_INPUT, "unsupported container version %s%lld", "", r32(blob + 4)); goto fail; }
+    {
+        uint32_t L0 = r32(blob + 8), nc = r32(blob + 12), nb = r32(blob + 16), nbytes = r32(blob + 20);
+        uint32_t cap_pos = r32(blob + 24), cap_var = r32(blob + 28), max_rl = r32(blob + 32);
+        uint64_t names_pad = ((uint64_t)nbytes + 3u) & ~3ull;
+        uint64_t hdr = CBC_CONTAINER_HDR + names_pad + 16ull * nc + 32ull * nb;
+        if (hdr > len || L0 < 1 || L0 > 256 || max_rl < 1 || max_rl > CBC_MAX_READ_LEN || cap_pos < 2 || cap_pos > 8192 ||
+            cap_var < 1 || cap_var > 32768) { rc = fail(S, CBC_E_INPUT, "corrupt container header%s%lld", "", 0); goto fail; }
+        const uint8_t *ctab = blob + CBC_CONTAINER_HDR + names_pad, *btab = ctab + 16ull * nc, *pay = btab + 32ull * nb;
+        uint64_t pay_bytes = len - hdr;
+        rc = load_fasta(S, fasta, fasta_len);
+        if (rc) goto fail;
+        if (S->n_fasta < nc) { rc = fail(S, CBC_E_INPUT, "the FASTA has fewer records than the container has contigs%s%lld", "", 0); goto fail; }
+        for (uint32_t i = 0; i < nc; i++)
+            if (r64(ctab + 16ull * i + 8) != S->P->contigs[i].length) {
+                rc = fail(S, CBC_E_INPUT, "contig %s#%lld has a different length in the FASTA than at compression time", "", (long long)i + 1); goto fail; }
+        u->blocks = (cbc_dec_block_desc *)calloc(nb ? nb : 1, sizeof(cbc_dec_block_desc));
+        u->window_start = (uint64_t *)calloc(nb ? nb : 1, sizeof(uint64_t));
+        if (!u->blocks || !u->window_start) { rc = CBC_E_NOMEM; goto fail; }
+        uint32_t stride = (max_rl + 3u) & ~3u;
+        uint64_t nrec = 0;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint8_t *e = btab + 32ull * b;
+            uint32_t contig = r32(e), nreads = r32(e + 4), pbytes = r32(e + 24);
+            uint64_t w0 = r64(e + 8), poff = r64(e + 16);
+            if (contig >= nc || poff + pbytes > pay_bytes || w0 >= S->P->contigs[contig].length + 1) {
+                rc = fail(S, CBC_E_INPUT, "corrupt block index entry %s%lld", "", b); goto fail; }
+            cbc_dec_block_desc *d = &u->blocks[b];
+            d->in_off = poff; d->in_bytes = pbytes; d->ref_off = S->P->contigs[contig].ref_off + w0;
+            d->rec_base = nrec; d->seq_base = nrec * stride; d->n_reads = nreads; d->read_length = L0; d->seq_stride = stride;
+            u->window_start[b] = w0;
+            nrec += nreads;
+        }
+        u->n_blocks = nb; u->payloads = pay; u->payload_bytes = pay_bytes; u->caps.cap_pos = cap_pos; u->caps.cap_var = cap_var;
+        u->read_length = L0; u->seq_stride = stride; u->n_recs = nrec;
+        u->ref = S->P->ref; u->ref_bytes = S->P->ref_bytes; S->P->ref = NULL;
+    }
+    cbc_packed_free(S->P); free(S);
+    *out = u;
+    return 0;
+fail:
+    if (S->P) cbc_packed_free(S->P);
+    free(S); cbc_unpack_plan_free(u);
+    return rc;
+}
+
+/* One reconstructed read per line (print_line, src/compression.c:16-40). */
+API int64_t cbc_unpack_write_text(const cbc_unpack_plan *u, const cbc_read_rec *recs, const uint8_t *seq,
+                                  char *dst, uint64_t cap)
+{
+    if (!u || !recs || !seq || !dst) return CBC_E_ARG;
+    uint64_t n = 0;
+    for (uint64_t r = 0; r < u->n_recs; r++) {
+        uint32_t rl = recs[r].rlen;
+        if (rl > u->seq_stride || n + rl + 1 > cap) return CBC_E_ARG;
+        memcpy(dst + n, seq + r * u->seq_stride, rl); n += rl;
+        dst[n++] = '\n';
+    }
+    return (int64_t)n;
 }

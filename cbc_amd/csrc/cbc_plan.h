@@ -17,6 +17,14 @@ static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
     return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 2u * caps->cap_pos + caps->cap_var);
 }
 
+/* decoder: the encoder's fixed tables + pos_alpha histograms + edit lists + scratch read
+ * (must match CBC_DLDS_FIXED in cbc_decode_body.h) */
+#define CBC_PLAN_DLDS_FIXED_WORDS (CBC_PLAN_LDS_FIXED_WORDS + 1616u)
+static inline uint32_t cbc_plan_dec_lds_bytes(const cbc_lds_caps *caps)
+{
+    return 4u * (CBC_PLAN_DLDS_FIXED_WORDS + 2u * caps->cap_pos + caps->cap_var);
+}
+
 /* Upper bound on the payload of a block.  Every model total stays below 2^20, so one coded symbol
  * costs < 20 bits; 3 bytes per symbol leaves slack for the 26-bit flush.  Symbols per record:
  * same_ref 1 + rlength 4 + pos <=5 + flag 1 + match 1 = 12, plus for an imperfect read <= 4 count

@@ -52,6 +52,19 @@ struct WaveGPU {
         return (uint32_t)__builtin_amdgcn_readlane(x, 63);
     }
 
+    /* inclusive prefix sum over the lanes (the same DPP ladder as reduce_add, kept in every lane) */
+    static CBC_FN V32 scan_incl_add(V32 v)
+    {
+        int x = (int)v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+        return (uint32_t)x;
+    }
+
     /* per-lane gathers / scatters; `m` false = lane does not touch memory */
     static CBC_FN V32 load32(const uint32_t *p, V32 idx, Mask m, uint32_t other) { return m ? p[idx] : other; }
     static CBC_FN void store32(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) p[idx] = val; }
@@ -61,6 +74,10 @@ struct WaveGPU {
     {
         return m ? *(const u32_unaligned *)(p + byteoff) : 0u;
     }
+    static CBC_FN V32 load8(const uint8_t *p, V32 byteoff, Mask m) { return m ? (uint32_t)p[byteoff] : 0u; }
+    static CBC_FN void store8(uint8_t *p, V32 byteoff, V32 val, Mask m) { if (m) p[byteoff] = (uint8_t)val; }
+    static CBC_FN void store32_bytes(uint8_t *p, V32 byteoff, V32 val, Mask m) { if (m) *(u32_unaligned *)(p + byteoff) = val; }
+    static CBC_FN void store_rec(uint4 *p, V32 idx, Mask m, V32 a, V32 b, V32 c, V32 d) { if (m) p[idx] = make_uint4(a, b, c, d); }
     /* 16-byte record gather (cbc_read_rec) */
     static CBC_FN void load_rec(const uint4 *p, V32 idx, Mask m, V32 &a, V32 &b, V32 &c, V32 &d)
     {
@@ -95,6 +112,20 @@ struct WaveGPU {
         uint32_t q = q0 + (uint32_t)q1 - (uint32_t)(r1 < 0) + (uint32_t)(r1 >= (int32_t)n);
         qh = (uint32_t)__builtin_amdgcn_readlane((int)q, 0);
         ql = (uint32_t)__builtin_amdgcn_readlane((int)q, 1);
+    }
+    /* floor(p / d) for p < 2^47, 2^24 < d <= 2^26 and a quotient < 2^21 (the decoder's target,
+     * Arithmetic_stream.c:373-381), exact: same two-estimate scheme as muldiv2 with the divisor d.
+     * (float)d is rounded (d has up to 27 bits), which only adds 2^-24 to the relative error. */
+    static CBC_FN uint32_t divq(uint64_t p, uint32_t d)
+    {
+        float inv = __builtin_amdgcn_rcpf((float)d);
+        uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
+        float pf = (float)((phi << 16) | (plo >> 16)) * 65536.0f;
+        uint32_t q0 = to_scalar((uint32_t)(pf * inv));
+        int32_t r0 = (int32_t)(plo - q0 * d);
+        int32_t q1 = (int32_t)to_scalar((uint32_t)(int32_t)__builtin_floorf((float)r0 * inv));
+        int32_t r1 = r0 - q1 * (int32_t)d;
+        return q0 + (uint32_t)q1 - (uint32_t)(r1 < 0) + (uint32_t)(r1 >= (int32_t)d);
     }
     /* reciprocals of all queued totals at once (lane k = k-th pending symbol) */
     static CBC_FN V32 recip_v(V32 n) { float r = __builtin_amdgcn_rcpf((float)n); return __builtin_bit_cast(uint32_t, r); }

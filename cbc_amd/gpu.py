@@ -41,6 +41,18 @@ class DeviceBatch(ctypes.Structure):
     ]
 
 
+class DecDeviceBatch(ctypes.Structure):
+    _fields_ = [
+        ("d_in", ctypes.c_void_p), ("in_bytes", ctypes.c_uint64),
+        ("d_blocks", ctypes.c_void_p), ("n_blocks", ctypes.c_uint32),
+        ("d_ref", ctypes.c_void_p), ("ref_bytes", ctypes.c_uint64),
+        ("d_recs", ctypes.c_void_p), ("n_recs", ctypes.c_uint64),
+        ("d_seq", ctypes.c_void_p), ("seq_bytes", ctypes.c_uint64),
+        ("d_results", ctypes.c_void_p),
+        ("caps", host.LdsCaps),
+    ]
+
+
 class CbcGpuError(RuntimeError):
     pass
 
@@ -74,6 +86,14 @@ def lib():
         L.cbc_gpu_compact_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                              ctypes.c_void_p]
+        L.cbc_gpu_decode_blocks_device.restype = ctypes.c_int
+        L.cbc_gpu_decode_blocks_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(DecDeviceBatch), ctypes.c_void_p]
+        L.cbc_gpu_decode_blocks.restype = ctypes.c_int
+        L.cbc_gpu_decode_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                            ctypes.c_uint32, ctypes.POINTER(host.LdsCaps), ctypes.c_void_p,
+                                            ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        L.cbc_gpu_decode_lds_bytes.restype = ctypes.c_uint32
+        L.cbc_gpu_decode_lds_bytes.argtypes = [ctypes.POINTER(host.LdsCaps)]
         L.cbc_gpu_plan_output.restype = ctypes.c_uint64
         L.cbc_gpu_plan_output.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         L.cbc_gpu_lds_bytes.restype = ctypes.c_uint32
@@ -90,7 +110,8 @@ def lib():
 
 EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_gpu_shutdown", "cbc_gpu_last_error",
            "cbc_gpu_upload_reference", "cbc_gpu_encode_blocks", "cbc_gpu_encode_blocks_device", "cbc_gpu_compact_device",
-           "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_synchronize"]
+           "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_decode_blocks_device", "cbc_gpu_decode_blocks",
+           "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_synchronize"]
 
 
 class Encoder:
@@ -131,6 +152,24 @@ class Encoder:
             self._check(rc, "cbc_gpu_encode_blocks")
         payloads = [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)]
         return payloads, res, offs, out[:int(offs[nb])]
+
+    def decode_blocks(self, plan: "host.UnpackPlan"):
+        """Host-buffer decode of every block of an UnpackPlan.  Returns (recs, seq, results)."""
+        nb = plan.n_blocks
+        blocks = plan.blocks.copy()
+        recs = np.zeros(plan.n_recs, dtype=host.REC_DTYPE)
+        seq = np.zeros(plan.n_recs * plan.seq_stride + 8, dtype=np.uint8)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        caps = host.LdsCaps(plan.cap_pos, plan.cap_var)
+        pay = np.ascontiguousarray(plan.payloads)
+        rc = lib().cbc_gpu_decode_blocks(self._ctx, pay.ctypes.data, pay.size, blocks.ctypes.data, nb, ctypes.byref(caps),
+                                         recs.ctypes.data, plan.n_recs, seq.ctypes.data, seq.size, res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_decode_blocks")
+        return recs, seq, res
+
+    def decode_device(self, db: DecDeviceBatch, stream=None):
+        self._check(lib().cbc_gpu_decode_blocks_device(self._ctx, ctypes.byref(db), stream), "cbc_gpu_decode_blocks_device")
 
     def encode_device(self, db: DeviceBatch, stream=None):
         self._check(lib().cbc_gpu_encode_blocks_device(self._ctx, ctypes.byref(db), stream), "cbc_gpu_encode_blocks_device")

@@ -64,10 +64,26 @@ class Packed(ctypes.Structure):
         ("read_length", ctypes.c_uint32),
         ("n_bases", ctypes.c_uint64),
         ("n_skipped_unmapped", ctypes.c_uint64),
+        ("max_read_len", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
         ("cap_recs", ctypes.c_uint64), ("cap_seq", ctypes.c_uint64), ("cap_tok", ctypes.c_uint64),
         ("cap_ref", ctypes.c_uint64), ("cap_names", ctypes.c_uint32), ("cap_blocks", ctypes.c_uint32),
         ("cap_contigs", ctypes.c_uint32),
     ]
+
+
+class DecBlockDesc(ctypes.Structure):
+    _fields_ = [("in_off", ctypes.c_uint64), ("ref_off", ctypes.c_uint64), ("rec_base", ctypes.c_uint64),
+                ("seq_base", ctypes.c_uint64), ("in_bytes", ctypes.c_uint32), ("n_reads", ctypes.c_uint32),
+                ("read_length", ctypes.c_uint32), ("seq_stride", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4)]
+
+
+class UnpackPlanC(ctypes.Structure):
+    _fields_ = [("blocks", ctypes.POINTER(DecBlockDesc)), ("n_blocks", ctypes.c_uint32),
+                ("payloads", ctypes.POINTER(ctypes.c_uint8)), ("payload_bytes", ctypes.c_uint64),
+                ("ref", ctypes.POINTER(ctypes.c_uint8)), ("ref_bytes", ctypes.c_uint64),
+                ("window_start", ctypes.POINTER(ctypes.c_uint64)),
+                ("caps", LdsCaps), ("read_length", ctypes.c_uint32), ("seq_stride", ctypes.c_uint32),
+                ("n_recs", ctypes.c_uint64)]
 
 
 class PackOpts(ctypes.Structure):
@@ -113,6 +129,13 @@ def lib():
         L.cbc_container_write.restype = ctypes.c_int64
         L.cbc_container_write.argtypes = [ctypes.POINTER(Packed), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
                                           ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_unpack_plan_create.restype = ctypes.c_int
+        L.cbc_unpack_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t,
+                                             ctypes.POINTER(ctypes.POINTER(UnpackPlanC)), ctypes.c_char_p, ctypes.c_size_t]
+        L.cbc_unpack_plan_free.argtypes = [ctypes.POINTER(UnpackPlanC)]
+        L.cbc_unpack_write_text.restype = ctypes.c_int64
+        L.cbc_unpack_write_text.argtypes = [ctypes.POINTER(UnpackPlanC), ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint64]
         _lib = L
     return _lib
 
@@ -146,7 +169,11 @@ BLOCK_DTYPE = np.dtype([("rec_base", "<u8"), ("seq_base", "<u8"), ("tok_base", "
 RESULT_DTYPE = np.dtype([("nbytes", "<u4"), ("status", "<u4"), ("n_symbols", "<u4"), ("fail_read", "<u4")])
 INFO_DTYPE = np.dtype([("contig", "<u4"), ("n_reads", "<u4"), ("window_start", "<u8"), ("n_bases", "<u8")])
 CONTIG_DTYPE = np.dtype([("ref_off", "<u8"), ("length", "<u8"), ("name_off", "<u4"), ("reserved", "<u4")])
+DEC_BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("ref_off", "<u8"), ("rec_base", "<u8"), ("seq_base", "<u8"),
+                            ("in_bytes", "<u4"), ("n_reads", "<u4"), ("read_length", "<u4"), ("seq_stride", "<u4"),
+                            ("reserved", "<u4", (4,))])
 assert REC_DTYPE.itemsize == 16 and BLOCK_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
+assert DEC_BLOCK_DTYPE.itemsize == 64
 
 
 class PackedBatch:
@@ -242,3 +269,51 @@ def synth(seed, contig_len, n_reads, read_len=150, sub_rate=0.003, indel_frac=0.
     lib().cbc_free(sam_p)
     lib().cbc_free(fa_p)
     return pb, sam, fa
+
+
+class UnpackPlan:
+    """Container + FASTA -> decode launch plan (cbc_unpack_plan_create).  Keeps the container bytes alive."""
+
+    def __init__(self, container: bytes, fasta: bytes):
+        self._blob = np.frombuffer(container, dtype=np.uint8).copy()
+        out = ctypes.POINTER(UnpackPlanC)()
+        err = ctypes.create_string_buffer(512)
+        rc = lib().cbc_unpack_plan_create(self._blob.ctypes.data, self._blob.size, fasta, len(fasta),
+                                          ctypes.byref(out), err, 512)
+        if rc != 0:
+            raise CbcInputError("cbc_unpack_plan_create failed (%d): %s" % (rc, err.value.decode(errors="replace")))
+        self._ptr = out
+        p = out.contents
+        self.n_blocks = int(p.n_blocks)
+        self.n_recs = int(p.n_recs)
+        self.read_length = int(p.read_length)
+        self.seq_stride = int(p.seq_stride)
+        self.cap_pos, self.cap_var = int(p.caps.cap_pos), int(p.caps.cap_var)
+        self.blocks = _np_view(p.blocks, p.n_blocks, DEC_BLOCK_DTYPE)
+        self.payloads = _np_view(p.payloads, p.payload_bytes, np.uint8)
+        self.ref = _np_view(p.ref, p.ref_bytes, np.uint8)
+        self.window_start = _np_view(p.window_start, p.n_blocks, np.uint64)
+
+    def text(self, recs: np.ndarray, seq: np.ndarray) -> bytes:
+        """One reconstructed read per line (what `cbc -d` writes)."""
+        cap = int(self.n_recs) * (self.seq_stride + 1) + 16
+        dst = np.zeros(cap, dtype=np.uint8)
+        recs = np.ascontiguousarray(recs)
+        seq = np.ascontiguousarray(seq)
+        n = lib().cbc_unpack_write_text(self._ptr, recs.ctypes.data, seq.ctypes.data, dst.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("cbc_unpack_write_text failed: %d" % n)
+        return dst[:int(n)].tobytes()
+
+    def close(self):
+        if self._ptr is not None:
+            for k in ("blocks", "payloads", "ref", "window_start"):
+                setattr(self, k, None)
+            lib().cbc_unpack_plan_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -187,6 +187,39 @@ uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks,
 /* Dynamic LDS bytes one wavefront needs for `caps` (occupancy = 160 KiB / this). */
 uint32_t cbc_gpu_lds_bytes(const cbc_lds_caps *caps);
 
+/* ---- decode direction (replaces decompress(), src/compression.c:173-216,
+ *      decompress_read()/reconstruct_read(), src/read_decompression.c:59-529) ----------------------- */
+typedef struct cbc_dec_block_desc {
+    uint64_t in_off;       /* byte offset of the block's payload in in[]                          */
+    uint64_t ref_off;      /* byte offset in the device reference of the base that is POS 1       */
+    uint64_t rec_base;     /* index of the block's first output cbc_read_rec                      */
+    uint64_t seq_base;     /* byte offset of the block's output bases (n_reads * seq_stride)      */
+    uint32_t in_bytes;     /* payload bytes                                                       */
+    uint32_t n_reads;      /* records the container index says the block holds                    */
+    uint32_t read_length;  /* header read length L0 (checked against the stream)                  */
+    uint32_t seq_stride;   /* bytes reserved per read in seq_out: multiple of 4, >= longest read  */
+    uint32_t reserved[4];
+} cbc_dec_block_desc;      /* 64 bytes */
+
+typedef struct cbc_dec_device_batch {
+    const uint8_t            *d_in;      uint64_t in_bytes;   /* payloads + >= 3 spare bytes        */
+    const cbc_dec_block_desc *d_blocks;  uint32_t n_blocks;
+    const uint8_t            *d_ref;     uint64_t ref_bytes;
+    cbc_read_rec             *d_recs;    uint64_t n_recs;     /* out: pos (block-local), flag, rlen */
+    uint8_t                  *d_seq;     uint64_t seq_bytes;  /* out: bases; >= sum + 8             */
+    cbc_block_result         *d_results;                      /* nbytes = records decoded           */
+    cbc_lds_caps              caps;                           /* from the container header          */
+} cbc_dec_device_batch;
+
+int  cbc_gpu_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batch *batch, void *hip_stream);
+
+/* Host-buffer form: payloads in, records + bases out (recs[n_recs], seq[n_recs * seq_stride]). */
+int  cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes,
+                           cbc_dec_block_desc *blocks, uint32_t n_blocks, const cbc_lds_caps *caps,
+                           cbc_read_rec *recs, uint64_t n_recs, uint8_t *seq, uint64_t seq_bytes,
+                           cbc_block_result *results /* n_blocks or NULL */);
+uint32_t cbc_gpu_decode_lds_bytes(const cbc_lds_caps *caps);
+
 /* Timing of the most recent encode launch made through this context, measured with HIP events
  * recorded on the launch stream around the kernel (valid after the stream has been synchronised). */
 int  cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms);

@@ -45,6 +45,8 @@ typedef struct cbc_packed {
     uint32_t         read_length;                     /* header read length L0                    */
     uint64_t         n_bases;
     uint64_t         n_skipped_unmapped;
+    uint32_t         max_read_len;                    /* longest SEQ packed                        */
+    uint32_t         reserved0;
     /* allocation bookkeeping (private) */
     uint64_t cap_recs, cap_seq, cap_tok, cap_ref; uint32_t cap_names, cap_blocks, cap_contigs;
 } cbc_packed;
@@ -88,11 +90,28 @@ void cbc_free(void *p);
  * magic "CBCB", version, header read length, contig table, block index, then the payloads.
  * Every payload follows the reference's stream grammar byte for byte. */
 #define CBC_CONTAINER_MAGIC 0x42434243u   /* "CBCB" little-endian */
-#define CBC_CONTAINER_VERSION 1u
+#define CBC_CONTAINER_VERSION 2u
 
 int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets);
 int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
                             uint8_t *dst, uint64_t dst_cap);
+
+/* ---- unpack side: container + FASTA -> decode launch plan -> text ------------------------- */
+typedef struct cbc_unpack_plan {
+    cbc_dec_block_desc *blocks;   uint32_t n_blocks;
+    const uint8_t      *payloads; uint64_t payload_bytes;   /* points into the caller's container blob */
+    uint8_t            *ref;      uint64_t ref_bytes;       /* owned: contigs + pads, as the packer lays them out */
+    uint64_t           *window_start;                        /* per block: add to a decoded POS for the contig POS */
+    cbc_lds_caps        caps;
+    uint32_t            read_length, seq_stride;
+    uint64_t            n_recs;
+} cbc_unpack_plan;
+
+int     cbc_unpack_plan_create(const uint8_t *blob, uint64_t len, const char *fasta, size_t fasta_len,
+                               cbc_unpack_plan **out, char *errbuf, size_t errlen);
+void    cbc_unpack_plan_free(cbc_unpack_plan *u);
+int64_t cbc_unpack_write_text(const cbc_unpack_plan *u, const cbc_read_rec *recs, const uint8_t *seq,
+                              char *dst, uint64_t cap);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,18 @@ class DeviceBatch(ctypes.Structure):
     ]
 
 
+class DecDeviceBatch(ctypes.Structure):
+    _fields_ = [
+        ("d_in", ctypes.c_void_p), ("in_bytes", ctypes.c_uint64),
+        ("d_blocks", ctypes.c_void_p), ("n_blocks", ctypes.c_uint32),
+        ("d_ref", ctypes.c_void_p), ("ref_bytes", ctypes.c_uint64),
+        ("d_recs", ctypes.c_void_p), ("n_recs", ctypes.c_uint64),
+        ("d_seq", ctypes.c_void_p), ("seq_bytes", ctypes.c_uint64),
+        ("d_results", ctypes.c_void_p),
+        ("caps", host.LdsCaps),
+    ]
+
+
 _emu = None
 
 
@@ -35,6 +47,8 @@ def emu_lib():
         L = ctypes.CDLL(os.path.join(_EMU_DIR, "libcbc_emu.so"))
         L.emu_encode_blocks.restype = ctypes.c_int
         L.emu_encode_blocks.argtypes = [ctypes.POINTER(DeviceBatch)]
+        L.emu_decode_blocks.restype = ctypes.c_int
+        L.emu_decode_blocks.argtypes = [ctypes.POINTER(DecDeviceBatch)]
         L.emu_plan_output.restype = ctypes.c_uint64
         L.emu_plan_output.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         _emu = L
@@ -59,6 +73,29 @@ def emu_encode(pb):
         o = int(blocks[b]["out_off"])
         payloads.append(out[o:o + int(res[b]["nbytes"])].tobytes())
     return payloads, res
+
+
+def emu_decode(plan):
+    """Run the decoder body on the CPU wave emulation.  Returns (recs, seq, results)."""
+    L = emu_lib()
+    blocks = plan.blocks.copy()
+    pay = np.concatenate([np.ascontiguousarray(plan.payloads), np.zeros(16, dtype=np.uint8)])
+    recs = np.zeros(plan.n_recs, dtype=host.REC_DTYPE)
+    seq = np.zeros(plan.n_recs * plan.seq_stride + 16, dtype=np.uint8)
+    res = np.zeros(plan.n_blocks, dtype=host.RESULT_DTYPE)
+    db = DecDeviceBatch(pay.ctypes.data, pay.size, blocks.ctypes.data, plan.n_blocks, plan.ref.ctypes.data, len(plan.ref),
+                        recs.ctypes.data, plan.n_recs, seq.ctypes.data, seq.size, res.ctypes.data,
+                        host.LdsCaps(plan.cap_pos, plan.cap_var))
+    if L.emu_decode_blocks(ctypes.byref(db)) != 0:
+        raise RuntimeError("emulation reported an invariant violation")
+    return recs, seq, res
+
+
+def container_from_payloads(pb, payloads):
+    offs = np.zeros(len(payloads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(p) for p in payloads])
+    flat = np.frombuffer(b"".join(payloads), dtype=np.uint8) if payloads else np.zeros(0, dtype=np.uint8)
+    return pb.container(flat, offs)
 
 
 def emu_encode_blocks(pb, which):

@@ -7,6 +7,7 @@
 #include <vector>
 #include "wave_emu.h"
 #include "../../cbc_amd/csrc/cbc_encode_body.h"
+#include "../../cbc_amd/csrc/cbc_decode_body.h"
 #include "../../cbc_amd/csrc/cbc_plan.h"
 
 static int g_emu_errors = 0;
@@ -32,3 +33,19 @@ int emu_encode_blocks(const cbc_device_batch *b)
 extern "C" __attribute__((visibility("default")))
 uint64_t emu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_read_rec *recs, const uint32_t *tok)
 { return cbc_plan_output(blocks, n_blocks, recs, tok); }
+
+extern "C" __attribute__((visibility("default")))
+int emu_decode_blocks(const cbc_dec_device_batch *b)
+{
+    cbc_dec_args A;
+    A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
+    A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
+    A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    g_emu_errors = 0;
+    uint32_t words = cbc_plan_dec_lds_bytes(&b->caps) / 4;
+    for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
+        std::vector<uint32_t> lds(words, 0xdeadbeefu);
+        cbc_decode_stream<WaveEmu>(A, blk, lds.data());
+    }
+    return g_emu_errors ? -100 : 0;
+}

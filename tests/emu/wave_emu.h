@@ -45,7 +45,8 @@ static inline EmuV32 operator>>(const EmuV32 &a, uint32_t b) { EmuV32 r; for (in
 
 #define EMU_CMP(op)                                                                                     \
     static inline EmuMask operator op(const EmuV32 &a, const EmuV32 &b) { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = a.v[i] op b.v[i]; return r; } \
-    static inline EmuMask operator op(const EmuV32 &a, uint32_t b) { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = a.v[i] op b; return r; }
+    static inline EmuMask operator op(const EmuV32 &a, uint32_t b) { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = a.v[i] op b; return r; } \
+    static inline EmuMask operator op(uint32_t a, const EmuV32 &b) { EmuMask r; for (int i = 0; i < 64; i++) r.b[i] = a op b.v[i]; return r; }
 EMU_CMP(==) EMU_CMP(!=) EMU_CMP(<) EMU_CMP(<=) EMU_CMP(>) EMU_CMP(>=)
 #undef EMU_CMP
 
@@ -64,6 +65,27 @@ struct WaveEmu {
     static uint32_t readlane(const V32 &v, uint32_t k) { if (k >= 64) { emu_oob("readlane index"); return 0; } return v.v[k]; }
     static uint32_t reduce_add(const V32 &v) { uint32_t s = 0; for (int i = 0; i < 64; i++) s += v.v[i]; return s; }
 
+    static V32 scan_incl_add(const V32 &v) { V32 r; uint32_t s = 0; for (int i = 0; i < 64; i++) { s += v.v[i]; r.v[i] = s; } return r; }
+    static V32 load8(const uint8_t *p, const V32 &off, const Mask &m) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? p[off.v[i]] : 0u; return r; }
+    static void store8(uint8_t *p, const V32 &off, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[off.v[i]] = (uint8_t)val.v[i]; }
+    static void store32_bytes(uint8_t *p, const V32 &off, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) memcpy(p + off.v[i], &val.v[i], 4); }
+    static void store_rec(uint4 *p, const V32 &idx, const Mask &m, const V32 &a, const V32 &b, const V32 &c, const V32 &d)
+    { for (int i = 0; i < 64; i++) if (m.b[i]) { uint4 r = {a.v[i], b.v[i], c.v[i], d.v[i]}; p[idx.v[i]] = r; } }
+    static uint32_t divq(uint64_t p, uint32_t d)
+    {
+        float inv = 1.0f / (float)d;
+        static unsigned tick = 0;
+        uint32_t bits; memcpy(&bits, &inv, 4); bits += (uint32_t)((int)(tick++ % 5u) - 2); memcpy(&inv, &bits, 4);
+        uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
+        float pf = (float)((phi << 16) | (plo >> 16)) * 65536.0f;
+        uint32_t q0 = (uint32_t)(pf * inv);
+        int32_t r0 = (int32_t)(plo - q0 * d);
+        int32_t q1 = (int32_t)__builtin_floorf((float)r0 * inv);
+        int32_t r1 = r0 - q1 * (int32_t)d;
+        uint32_t q = q0 + (uint32_t)q1 - (uint32_t)(r1 < 0) + (uint32_t)(r1 >= (int32_t)d);
+        if (q != (uint32_t)(p / d)) emu_oob("divq two-estimate mismatch");
+        return q;
+    }
     static V32 load32(const uint32_t *p, const V32 &idx, const Mask &m, uint32_t other)
     { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? p[idx.v[i]] : other; return r; }
     static void store32(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m)

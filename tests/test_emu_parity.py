@@ -152,3 +152,79 @@ def test_variable_read_lengths(built):
     pb = host.pack_sam(sam, fa, block_reads=400)
     assert pb.read_length == 100
     _check(pb, sam)
+
+
+# ---- decode direction: kernel body through the emulation ----
+
+def _roundtrip(pb, sam, fa):
+    payloads, res = blockref.emu_encode(pb)
+    assert (res["status"] == 0).all()
+    blob = blockref.container_from_payloads(pb, payloads)
+    plan = host.UnpackPlan(blob, fa)
+    recs, seq, dres = blockref.emu_decode(plan)
+    assert (dres["status"] == 0).all(), dres[dres["status"] != 0]
+    assert (dres["n_symbols"] == res["n_symbols"]).all()           # same number of coder steps both ways
+    expect = b"".join(ln.split(b"\t")[9] + b"\n" for ln in sam.splitlines() if not ln.startswith(b"@"))
+    assert plan.text(recs, seq) == expect
+    # POS / FLAG come back too
+    lines = blockref.mapped_sam_lines(sam)
+    b0 = 0
+    for b in range(plan.n_blocks):
+        n = int(plan.blocks[b]["n_reads"])
+        w0 = int(plan.window_start[b])
+        for k in (0, n // 2, n - 1):
+            f = lines[b0 + k].split(b"\t")
+            assert int(recs[b0 + k]["pos"]) + w0 == int(f[3]) and int(recs[b0 + k]["flag"]) == int(f[1])
+        b0 += n
+    return plan, payloads
+
+
+@pytest.mark.parametrize("kw,L,br", [
+    (dict(sub_rate=0.0, indel_frac=0.0), 100, 1000),
+    (dict(), 150, 1024),
+    (dict(sub_rate=0.02, indel_frac=0.5, trailing_s_frac=0.2, dup_pos_frac=0.1), 100, 512),
+    (dict(sub_rate=0.05, indel_frac=0.0), 252, 300),
+    (dict(flags=(0, 16, 83, 99, 147, 163)), 150, 2048),
+])
+def test_decode_round_trip(built, kw, L, br):
+    fa, sam, _, _ = synth.dataset(5, [300000, 120000], [4000, 1500], L, **kw)
+    pb = host.pack_sam(sam, fa, block_reads=br)
+    _roundtrip(pb, sam, fa)
+
+
+def test_decode_equals_oracle_decoder_per_block(built):
+    """The oracle's restatement of the reference DEcoder, run on each block's payload, gives the same reads."""
+    fa, sam, _, _ = synth.dataset(6, [200000], [1500], 100, sub_rate=0.01, indel_frac=0.3)
+    pb = host.pack_sam(sam, fa, block_reads=500)
+    plan, payloads = _roundtrip(pb, sam, fa)
+    lines = blockref.mapped_sam_lines(sam)
+    for b in range(pb.n_blocks):
+        bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
+        text, nr = oracle.decode(payloads[b], bfa)
+        assert nr == int(pb.blocks[b]["n_reads"])
+        first = int(pb.blocks[b]["rec_base"])
+        assert text == b"".join(lines[first + k].split(b"\t")[9] + b"\n" for k in range(nr))
+
+
+def test_decode_variable_lengths_and_sparse_positions(built):
+    fa, sam = _variable_length_sam(23)
+    _roundtrip(host.pack_sam(sam, fa, block_reads=400), sam, fa)
+    fa, sam, _, _ = synth.dataset(12, [40_000_000], [1500], 100)
+    _roundtrip(host.pack_sam(sam, fa, block_reads=1000), sam, fa)
+
+
+def test_decode_rejects_corrupt_payload(built):
+    """Bit flips must end in a status (or different reads), never in an out-of-range access."""
+    fa, sam, _, _ = synth.dataset(7, [100000], [600], 100, sub_rate=0.01, indel_frac=0.2)
+    pb = host.pack_sam(sam, fa, block_reads=600)
+    payloads, res = blockref.emu_encode(pb)
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        bad = bytearray(payloads[0])
+        for _ in range(3):
+            i = int(rng.integers(70, len(bad)))
+            bad[i] ^= 1 << int(rng.integers(0, 8))
+        blob = blockref.container_from_payloads(pb, [bytes(bad)])
+        plan = host.UnpackPlan(blob, fa)
+        recs, seq, dres = blockref.emu_decode(plan)          # must simply return
+        assert int(dres[0]["status"]) in (0, 2, 3, 4, 5, 6, 7)

@@ -199,9 +199,10 @@ def test_container_layout(built):
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
     payload = np.arange(int(offs[-1]), dtype=np.uint64).astype(np.uint8)
     blob = pb.container(payload, offs)
-    magic, ver, L0, nc, nb, nbytes = struct.unpack_from("<6I", blob, 0)
-    assert magic == 0x42434243 and ver == 1 and L0 == 100 and nc == 2 and nb == pb.n_blocks
-    p = 24 + ((nbytes + 3) & ~3)
+    magic, ver, L0, nc, nb, nbytes, cap_pos, cap_var, max_rl = struct.unpack_from("<9I", blob, 0)
+    assert magic == 0x42434243 and ver == 2 and L0 == 100 and nc == 2 and nb == pb.n_blocks
+    assert (cap_pos, cap_var, max_rl) == (pb.cap_pos, pb.cap_var, 100)
+    p = 36 + ((nbytes + 3) & ~3)
     p += 16 * nc
     for b in range(nb):
         contig, nreads, w0, poff, pbytes, _ = struct.unpack_from("<IIQQII", blob, p + 32 * b)
@@ -217,3 +218,19 @@ def test_synth_is_seeded_and_sorted(built):
     assert a.seq.tobytes() == b.seq.tobytes() and a.recs.tobytes() == b.recs.tobytes()
     assert a.seq.tobytes() != c.seq.tobytes()
     assert a.n_bases == 5000 * 150 and set(np.unique(a.recs["flag"]).tolist()) <= {0, 16}
+
+
+def test_unpack_plan_matches_the_container(built):
+    fa, sam, _, _ = synth.dataset(3, [100000, 50000], [300, 100], 100)
+    pb = host.pack_sam(sam, fa, block_reads=128)
+    sizes = np.arange(10, 10 + pb.n_blocks, dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    payload = np.arange(int(offs[-1]), dtype=np.uint64).astype(np.uint8)
+    plan = host.UnpackPlan(pb.container(payload, offs), fa)
+    assert plan.n_blocks == pb.n_blocks and plan.n_recs == pb.n_recs and plan.seq_stride == 100
+    assert (plan.blocks["ref_off"] == pb.blocks["ref_off"]).all() and (plan.blocks["in_bytes"] == sizes).all()
+    assert plan.ref.tobytes() == pb.ref.tobytes()
+    with pytest.raises(host.CbcInputError):
+        host.UnpackPlan(b"nonsense" * 10, fa)
+    with pytest.raises(host.CbcInputError, match="different length"):
+        host.UnpackPlan(pb.container(payload, offs), fa.replace(b"A", b"", 1))
