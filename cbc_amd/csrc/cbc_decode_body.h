@@ -32,7 +32,7 @@
 #define CBC_DLDS_INS     (CBC_LDS_FIXED + 1280u)       /* 256: (output index << 8) | base char      */
 #define CBC_DLDS_TMP     (CBC_LDS_FIXED + 1536u)       /* 80 words: insertion-free read, bytes      */
 #define CBC_DLDS_FIXED   (CBC_LDS_FIXED + 1616u)
-/* then pos_val[cap_pos], pos_cnt[cap_pos], var_ev[cap_var] */
+/* then pos_val[cap_pos], pos_cnt[cap_pos]; the var-event list is in global scratch (cap_var words per block) */
 
 struct cbc_dec_args {
     const uint8_t            *in;         /* payload bytes of all blocks                    */
@@ -41,7 +41,8 @@ struct cbc_dec_args {
     cbc_read_rec             *recs;       /* out: pos (block-local), flag, rlen, seq_off    */
     uint8_t                  *seq;        /* out: bases, seq_stride bytes reserved per read */
     cbc_block_result         *results;
-    uint64_t in_bytes, ref_bytes, n_recs, seq_bytes;
+    uint32_t                 *var_scratch; /* n_blocks * cap_var words                        */
+    uint64_t in_bytes, ref_bytes, n_recs, seq_bytes, var_scratch_words;
     uint32_t n_blocks, cap_pos, cap_var;
 };
 
@@ -59,16 +60,17 @@ struct CbcDec {
     /* ---- models (same representations as CbcEnc) ---- */
     V32 small, fkey, fexc, hkey, hexc, pval, pcnt;
     uint32_t fcount, fn, hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;
-    uint32_t *lds;
+    uint32_t *lds, *evp;
     uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, cap_var, L0;
     uint32_t prevPos, prevM, prevChar;
+    uint32_t vtag0, vtag1, vsum0, vsum1;
     uint64_t w0, w1, w2, w3;
 
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
     CBC_MFN uint32_t *tab(uint32_t off) { return lds + off; }
     CBC_MFN uint32_t *pos_val_p() { return lds + CBC_DLDS_FIXED; }
     CBC_MFN uint32_t *pos_cnt_p() { return lds + CBC_DLDS_FIXED + cap_pos; }
-    CBC_MFN uint32_t *var_ev_p() { return lds + CBC_DLDS_FIXED + 2u * cap_pos; }
+    CBC_MFN uint32_t *var_ev_p() { return evp; }
 
     /* ---- bit input: 64 big-endian words staged in a VGPR, refilled with one coalesced load ---- */
     CBC_MFN void load_chunk()
@@ -376,6 +378,23 @@ struct CbcDec {
     CBC_MFN uint32_t var_dec(uint32_t ctx)
     {
         if (ctx >= CBC_NVARCTX) { fail(CBC_ST_ASSERT); return 0u; }
+        {   /* hot contexts: dense table, same claim rule as CbcEnc::var_code */
+            const uint32_t slot = ctx & 1u;
+            uint32_t tag = slot ? vtag1 : vtag0;
+            if (tag == CBC_NOMEMO) { tag = ctx; if (slot) vtag1 = ctx; else vtag0 = ctx; }
+            if (tag == ctx) {
+                uint32_t *exc = tab(CBC_LDS_VSLOT) + 256u * slot;
+                uint32_t sum = slot ? vsum1 : vsum0, n = L0 + sum;
+                if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_CAP_VAR); return 0u; }
+                uint32_t tg = target(n), lo, cnt;
+                uint32_t x = dense_search(exc, L0, 1u, tg, lo, cnt);
+                if (status != CBC_ST_OK) return 0u;
+                step(lo, cnt, n);
+                W::write_uni(exc, x, cnt - 1u + 10u);
+                if (slot) vsum1 = sum + 10u; else vsum0 = sum + 10u;
+                return x;
+            }
+        }
         V32 ln = W::lane();
         uint32_t *bloom = tab(CBC_LDS_BLOOM), *ev = var_ev_p();
         const uint32_t h = (ctx * 0x9E3779B1u) >> 19;
@@ -387,7 +406,7 @@ struct CbcDec {
             const uint32_t nb = W::uni(nev);
             for (uint32_t b = 0; b < nb; b += 64u) {
                 V32 i = ln + b; Mask mm = i < nev;
-                V32 e = W::load32(ev, i, mm, 0xffffffffu);
+                V32 e = W::load32_list(ev, i, mm, 0xffffffffu);
                 uint64_t bb = W::ballot(mm & ((e >> 8) == ctx));
                 while (bb) {
                     uint32_t src = W::ctz64(bb); bb &= bb - 1u;
@@ -410,7 +429,7 @@ struct CbcDec {
         if (x >= L0) { fail(CBC_ST_ASSERT); return 0u; }
         step(lo, cnt, n);
         if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return 0u; }
-        W::write_uni(ev, nev, (ctx << 8) | x);
+        W::append_list(ev, nev, (ctx << 8) | x);
         nev++;
         return x;
     }
@@ -480,10 +499,12 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     D.l = 0; D.u = CBC_M26; D.t = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
     D.inb = A.in + in_off;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = A.cap_var; D.L0 = L0;
+    D.evp = A.var_scratch + (uint64_t)blk * A.cap_var;
     /* the payload buffer must leave 3 spare bytes after the last payload (whole-dword reads) */
     bool args_ok = cbc_le64(in_off + (((uint64_t)in_bytes + 3u) & ~3ull), A.in_bytes) && cbc_le64(rec_base + n_reads, A.n_recs) &&
                    cbc_le64(seq_base + (uint64_t)n_reads * stride + 8u, A.seq_bytes) && (L0 >= 1u && L0 <= 256u) &&
-                   (stride >= 4u && stride <= 256u && (stride & 3u) == 0u) && cbc_le64(ref_off, A.ref_bytes);
+                   (stride >= 4u && stride <= 256u && (stride & 3u) == 0u) && cbc_le64(ref_off, A.ref_bytes) &&
+                   cbc_le64(((uint64_t)blk + 1u) * A.cap_var, A.var_scratch_words);
     D.nwords_in = (in_bytes + 3u) >> 2;
     D.tail_valid = in_bytes & 3u;
     if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
@@ -506,6 +527,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         D.small = W::select(inch, cv, s);
     }
     D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
+    D.vtag0 = D.vtag1 = CBC_NOMEMO; D.vsum0 = D.vsum1 = 0;
 
     /* the tag: first 26 bits (alloc_arithmetic_stream, Arithmetic_stream.c:260-263) */
     if (D.status == CBC_ST_OK) D.t = D.take(26u);

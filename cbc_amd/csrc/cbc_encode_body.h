@@ -39,6 +39,9 @@
 #define CBC_RESCALE   (1u << 20)
 #define CBC_NVARCTX   0xffffu
 #define CBC_NOMEMO    0xffffffffu
+#define CBC_ROLE_FUSED 0u      /* one wavefront does models and coder (CPU emulation)        */
+#define CBC_ROLE_MODEL 1u      /* wavefront 0 of the workgroup: models, produces symbol batches */
+#define CBC_ROLE_CODER 2u      /* wavefront 1: range coder, consumes them                        */
 
 /* lane map of the register-resident small models (one VGPR, `small`) */
 #define CBC_LT_MATCH   0u     /* 4 ctx x 2                 sam_models.c:204-241 */
@@ -52,8 +55,11 @@
 #define CBC_LDS_RNKEY   768u                       /* CBC_CAP_NAME: (ctx<<8)|char       */
 #define CBC_LDS_RNEXC   (768u + CBC_CAP_NAME)      /* CBC_CAP_NAME                      */
 #define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* 256 words = 8192-bit Bloom filter on var ctx */
-#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u)
-/* then pos_val[cap_pos], pos_cnt[cap_pos], var_ev[cap_var] */
+#define CBC_LDS_VSLOT   (768u + 2u * CBC_CAP_NAME + 256u) /* 2 x 256: dense excess of the two hot var contexts */
+#define CBC_LDS_BATCH   (768u + 2u * CBC_CAP_NAME + 256u + 512u)  /* 2 x 196: symbol batches producer -> coder wave */
+#define CBC_BATCH_WORDS 196u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record} */
+#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS)
+/* then pos_val[cap_pos], pos_cnt[cap_pos]; the var-event list lives in global memory (see var_code) */
 
 struct cbc_enc_args {
     const cbc_read_rec   *recs;
@@ -89,6 +95,7 @@ struct CbcEnc {
     V32 stage; uint32_t nwords; uint32_t *out32; uint32_t cap_words;
     uint32_t status, nsym, fail_read, cur_read;
     V32 q_lo, q_cnt, q_n; uint32_t q_len;   /* pending symbols: lane k = k-th queued (lo, cnt, n)      */
+    uint32_t role, batch_i; uint32_t *batch;  /* CBC_ROLE_*; hand-off buffers between the two waves     */
 #ifdef CBC_STAMP
     unsigned long long t_last, t_sum[16];
 #endif
@@ -105,6 +112,7 @@ struct CbcEnc {
     V32 pval, pcnt;                          /* pos alphabet entries 0..63 (value, count)        */
     uint32_t pos_card, pos_n, cap_pos;
     uint32_t nev, cap_var;
+    uint32_t vtag0, vtag1, vsum0, vsum1;     /* hot var contexts: tag (context) and total excess  */
     uint32_t L0;
 
     /* ---- cross-read state (T7/T8 of SURVEY.md) ---- */
@@ -155,7 +163,26 @@ struct CbcEnc {
         q_n = W::select(here, W::splat(n), q_n);
         q_len++;
     }
-    CBC_MFN void drain()
+    /* Run the pending symbols through the coder.  In the two-wavefront form (GPU) the model wave
+     * hands the batch to the coder wave through one of two LDS buffers and a workgroup barrier:
+     * batch b goes to buffer b&1; after barrier b the coder wave copies it into its own registers,
+     * so the model wave may refill that buffer as soon as barrier b+1 has passed.  Both waves execute
+     * exactly one barrier per batch and the model wave always ends with a batch flagged `last`. */
+    CBC_MFN void drain() { if (role == CBC_ROLE_MODEL) publish(0u); else drain_local(); }
+    CBC_MFN void publish(uint32_t flags)
+    {
+        V32 ln = W::lane();
+        uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
+        Mask m = ln < q_len;
+        W::store32(buf, ln, q_lo, m); W::store32(buf + 64u, ln, q_cnt, m); W::store32(buf + 128u, ln, q_n, m);
+        V32 hdr = W::select(ln == 0u, W::splat(q_len), W::select(ln == 1u, W::splat(flags),
+                  W::select(ln == 2u, W::splat(status), W::splat(status == CBC_ST_OK ? cur_read : fail_read))));
+        W::store32(buf + 192u, ln, hdr, ln < 4u);
+        W::barrier();
+        batch_i++;
+        q_len = 0;
+    }
+    CBC_MFN void drain_local()
     {
         V32 ln = W::lane();
         uint32_t m = W::uni(q_len);
@@ -169,6 +196,26 @@ struct CbcEnc {
         }
         if (bad) fail(CBC_ST_ASSERT);
         q_len = 0;
+    }
+    /* coder wave: take batches until the one flagged last; returns false when the model wave aborted */
+    CBC_MFN void consume_all()
+    {
+        V32 ln = W::lane();
+        for (;;) {
+            W::barrier();
+            const uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
+            V32 hdr = W::load32(buf + 192u, ln, ln < 4u, 0u);
+            const uint32_t len = W::readlane(hdr, 0u), flags = W::readlane(hdr, 1u);
+            const uint32_t pst = W::readlane(hdr, 2u), prec = W::readlane(hdr, 3u);
+            Mask m = ln < len;
+            q_lo = W::load32(buf, ln, m, 0u); q_cnt = W::load32(buf + 64u, ln, m, 1u); q_n = W::load32(buf + 128u, ln, m, 1u);
+            q_len = len > 64u ? 64u : len;
+            batch_i++;
+            cur_read = prec;
+            if (pst != CBC_ST_OK) { if (status == CBC_ST_OK) { status = pst; fail_read = prec; } }
+            else if (status == CBC_ST_OK) drain_local();
+            if (flags & 1u) break;
+        }
     }
     CBC_MFN void code1(uint32_t lo, uint32_t cnt, uint32_t n, float inv)
     {
@@ -443,6 +490,25 @@ struct CbcEnc {
     CBC_MFN void var_code(uint32_t ctx, uint32_t sym)
     {
         if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
+        /* Hot contexts.  The first SNP of a read with no known SNP ahead always has the same context
+         * (delta = L+2, prev = 0) per strand, so a block codes hundreds of symbols in it.  The first
+         * context seen on each strand claims a dense 256-entry excess table in LDS (exactly the
+         * snps/indels representation); only the other contexts go through the event list. */
+        {
+            const uint32_t slot = ctx & 1u;
+            uint32_t tag = slot ? vtag1 : vtag0;
+            if (tag == CBC_NOMEMO) { tag = ctx; if (slot) vtag1 = ctx; else vtag0 = ctx; }
+            if (tag == ctx) {
+                uint32_t *exc = bloom + 256u + 256u * slot;        /* CBC_LDS_VSLOT follows the Bloom filter */
+                uint32_t lo, cnt, sum = slot ? vsum1 : vsum0;
+                dense_lookup(exc, sym, lo, cnt);
+                encode(lo, cnt, L0 + sum);
+                W::write_uni(exc, sym, cnt - 1u + 10u);
+                if (slot) vsum1 = sum + 10u; else vsum0 = sum + 10u;
+                if (L0 + sum + 10u >= CBC_RESCALE) fail(CBC_ST_CAP_VAR);     /* unreachable within cap_var */
+                return;
+            }
+        }
         V32 ln = W::lane();
         uint32_t cn = 0, clo = 0, ceq = 0, key = (ctx << 8) | sym;
         const uint32_t h = (ctx * 0x9E3779B1u) >> 19;
@@ -451,10 +517,10 @@ struct CbcEnc {
             const uint32_t nb = W::uni(nev);
             for (uint32_t b = 0; b < nb; b += 256u) {
                 V32 i0 = ln * 4u + b;
-                V32 e0 = W::load32(var_ev, i0, i0 < nev, 0xffffffffu);
-                V32 e1 = W::load32(var_ev, i0 + 1u, (i0 + 1u) < nev, 0xffffffffu);
-                V32 e2 = W::load32(var_ev, i0 + 2u, (i0 + 2u) < nev, 0xffffffffu);
-                V32 e3 = W::load32(var_ev, i0 + 3u, (i0 + 3u) < nev, 0xffffffffu);
+                V32 e0 = W::load32_list(var_ev, i0, i0 < nev, 0xffffffffu);
+                V32 e1 = W::load32_list(var_ev, i0 + 1u, (i0 + 1u) < nev, 0xffffffffu);
+                V32 e2 = W::load32_list(var_ev, i0 + 2u, (i0 + 2u) < nev, 0xffffffffu);
+                V32 e3 = W::load32_list(var_ev, i0 + 3u, (i0 + 3u) < nev, 0xffffffffu);
                 uint64_t b0 = W::ballot((e0 >> 8) == ctx), b1 = W::ballot((e1 >> 8) == ctx);
                 uint64_t b2 = W::ballot((e2 >> 8) == ctx), b3 = W::ballot((e3 >> 8) == ctx);
                 if (b0 | b1 | b2 | b3) {
@@ -470,7 +536,7 @@ struct CbcEnc {
         } else W::write_uni(bloom, h >> 5, bw | bbit);
         encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
         if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
-        W::write_uni(var_ev, nev, key);
+        W::append_list(var_ev, nev, key);
         nev++;
     }
 
@@ -545,9 +611,10 @@ CBC_FN uint32_t cbc_basepair(uint32_t c)            /* char2basepair sam_models.
  * cbc_encode_stream: code block `blk` completely.  `lds` = this wavefront's table memory
  * (cbc_gpu_lds_bytes() bytes).
  * =========================================================================================== */
-template <class W>
+template <class W, uint32_t ROLE>
 CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds)
 {
+    const uint32_t role = ROLE;
     typedef typename W::V32 V32;
     typedef typename W::Mask Mask;
     const V32 ln = W::lane();
@@ -564,22 +631,41 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.l = 0; E.u = CBC_M26; E.scale3 = 0; E.acc = 0; E.nacc = 0; E.nwords = 0;
     E.stage = W::splat(0u);
     E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
+    E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH;
+    /* the block's out area: [0, payload_cap) payload, [payload_cap, out_cap) its var-event list */
+    const uint32_t payload_cap = bd->reserved;
     E.out32 = (uint32_t *)(A.out + out_off);
-    E.cap_words = out_cap >> 2;
-    bool args_ok = cbc_le64(out_off + out_cap, A.out_bytes) && ((out_off & 3u) == 0) &&
+    E.cap_words = payload_cap >> 2;
+    E.var_ev = (uint32_t *)(A.out + out_off + payload_cap);
+    E.cap_var = payload_cap <= out_cap ? (out_cap - payload_cap) >> 2 : 0u;
+    bool args_ok = cbc_le64(out_off + out_cap, A.out_bytes) && ((out_off & 3u) == 0) && ((payload_cap & 3u) == 0) &&
+                   (payload_cap <= out_cap) &&
                    cbc_le64(rec_base + n_reads, A.n_recs) && cbc_le64(tok_base + n_tok_blk, A.n_tok) &&
                    (L0 >= 1u && L0 <= 256u) && (name_off < A.names_bytes);
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
+
+    if (ROLE == CBC_ROLE_CODER) {
+        /* coder wavefront: nothing but the range coder, fed by the model wavefront's batches */
+        E.consume_all();
+        uint32_t nb = 0;
+        if (E.status == CBC_ST_OK) nb = E.finish();
+        if (E.status != CBC_ST_OK) nb = 0;
+        V32 rv = W::select(ln == 0u, W::splat(nb), W::select(ln == 1u, W::splat(E.status),
+                 W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
+        W::store32((uint32_t *)(A.results + blk), ln, rv, ln < 4u);
+        return;
+    }
 
     /* ---- model initialisation (alloc_read_models_t sam_models.c:562-586 etc.) ---- */
     E.L0 = L0;
     E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
     E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
     E.bloom = lds + CBC_LDS_BLOOM;
-    E.pos_val = lds + CBC_LDS_FIXED; E.pos_cnt = E.pos_val + A.cap_pos; E.var_ev = E.pos_cnt + A.cap_pos;
-    E.cap_pos = A.cap_pos; E.cap_var = A.cap_var;
+    E.pos_val = lds + CBC_LDS_FIXED; E.pos_cnt = E.pos_val + A.cap_pos;
+    E.cap_pos = A.cap_pos;
     for (uint32_t b = 0; b < 768u; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
-    for (uint32_t b = 0; b < 256u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());
+    for (uint32_t b = 0; b < 768u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* Bloom + 2 slots */
+    E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
     E.rlen_n = 255u; E.rlen_memo_x = CBC_NOMEMO; E.rlen_memo_lo = 0; E.rlen_memo_cnt = 0;
     E.rl123_c0 = 1u; E.rl123_n = 255u;
     E.snps_n = L0; E.indels_n = L0;
@@ -855,6 +941,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         E.rname_code(E.prevChar, (uint32_t)'\n');
         E.rname_code((uint32_t)'\n', 0u);
     }
+    if (ROLE == CBC_ROLE_MODEL) { E.publish(1u); return; }       /* last batch; carries the status if a model check failed */
     E.drain();
     if (E.status == CBC_ST_OK) nbytes = E.finish();
     if (E.status != CBC_ST_OK) nbytes = 0;

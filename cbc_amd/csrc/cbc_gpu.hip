@@ -24,15 +24,20 @@
  * ---------------------------------------------------------------------------------------------- */
 extern __shared__ uint32_t cbc_lds[];
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 cbc_encode_blocks_kernel(cbc_enc_args A)
 {
-    /* Workgroups are dealt round-robin to the 8 XCDs; blocks of one contig are neighbours in the
+    /* One workgroup = one block = one arithmetic stream, coded by TWO wavefronts in a pipeline:
+     * wavefront 0 runs the context models and produces (lo, cnt, n) batches in LDS, wavefront 1 runs
+     * the range coder on them (cbc_encode_body.h, CbcEnc::publish / consume_all).
+     * Workgroups are dealt round-robin to the 8 XCDs; blocks of one contig are neighbours in the
      * batch and share nothing but read-only reference lines, so the identity map is kept and the
      * per-XCD L2s each see a strided slice of the record stream. */
     uint32_t blk = blockIdx.x;
     if (blk >= A.n_blocks) return;
-    cbc_encode_stream<WaveGPU>(A, blk, cbc_lds);
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wid == 0u) cbc_encode_stream<WaveGPU, CBC_ROLE_MODEL>(A, blk, cbc_lds);
+    else cbc_encode_stream<WaveGPU, CBC_ROLE_CODER>(A, blk, cbc_lds);
 }
 
 __global__ void __launch_bounds__(64)
@@ -179,7 +184,7 @@ API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b
     A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
     A.names_bytes = 0x7fffffffu;   /* names are NUL-terminated; bounded by CBC_CAP_NAME in the kernel */
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
-    hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
+    hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(128), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_encode_blocks_kernel");
     HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
     ctx->have_timing = 1;
@@ -300,7 +305,7 @@ API int cbc_gpu_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batc
 {
     if (!ctx || !b) return CBC_E_ARG;
     if (b->n_blocks == 0) return CBC_OK;
-    if (!b->d_in || !b->d_blocks || !b->d_ref || !b->d_recs || !b->d_seq || !b->d_results)
+    if (!b->d_in || !b->d_blocks || !b->d_ref || !b->d_recs || !b->d_seq || !b->d_results || !b->d_var_scratch)
         return set_err(ctx, CBC_E_ARG, "null device pointer in cbc_dec_device_batch", hipSuccess);
     if (b->caps.cap_pos < 2 || b->caps.cap_pos > 8192 || b->caps.cap_var < 1 || b->caps.cap_var > 32768)
         return set_err(ctx, CBC_E_ARG, "lds caps out of range", hipSuccess);
@@ -312,6 +317,7 @@ API int cbc_gpu_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batc
     A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
     A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
     A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    A.var_scratch = b->d_var_scratch; A.var_scratch_words = b->var_scratch_words;
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
     hipLaunchKernelGGL(cbc_decode_blocks_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_decode_blocks_kernel");
@@ -328,10 +334,12 @@ API int cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
     if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
     if (n_blocks == 0) return CBC_OK;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    void *d_in = NULL, *d_blocks = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL;
+    void *d_in = NULL, *d_blocks = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL, *d_vs = NULL;
     cbc_block_result *res = NULL;
     int rc = CBC_OK;
+    const uint64_t vs_words = (uint64_t)n_blocks * caps->cap_var;
 #define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_vs, vs_words * 4 + 16), "hipMalloc var scratch");
     GO(hipMalloc(&d_in, in_bytes + 16), "hipMalloc in");
     GO(hipMalloc(&d_blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc)), "hipMalloc blocks");
     GO(hipMalloc(&d_recs, n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
@@ -348,7 +356,7 @@ API int cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
         db.d_in = (const uint8_t *)d_in; db.in_bytes = in_bytes + 16; db.d_blocks = (const cbc_dec_block_desc *)d_blocks;
         db.n_blocks = n_blocks; db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = (cbc_read_rec *)d_recs;
         db.n_recs = n_recs; db.d_seq = (uint8_t *)d_seq; db.seq_bytes = seq_bytes + 16; db.d_results = (cbc_block_result *)d_res;
-        db.caps = *caps;
+        db.caps = *caps; db.d_var_scratch = (uint32_t *)d_vs; db.var_scratch_words = vs_words;
         rc = cbc_gpu_decode_blocks_device(ctx, &db, NULL);
         if (rc) goto done;
     }
@@ -367,6 +375,6 @@ done:
 #undef GO
     if (res && res != results) free(res);
     if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
-    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res);
+    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vs) (void)hipFree(d_vs);
     return rc;
 }

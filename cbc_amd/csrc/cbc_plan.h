@@ -10,11 +10,14 @@
 #include "../../include/cbc_gpu.h"
 
 /* must match CBC_LDS_FIXED in cbc_encode_body.h */
-#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u)
+#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u + 392u)
 
+/* LDS per wavefront: fixed tables + the POS alphabet.  The var-event list is NOT in LDS: it lives in
+ * global memory behind the block's payload area (encode) / in the decode scratch, so caps->cap_var
+ * only sizes those areas. */
 static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
 {
-    return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 2u * caps->cap_pos + caps->cap_var);
+    return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 2u * caps->cap_pos);
 }
 
 /* decoder: the encoder's fixed tables + pos_alpha histograms + edit lists + scratch read
@@ -22,7 +25,7 @@ static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
 #define CBC_PLAN_DLDS_FIXED_WORDS (CBC_PLAN_LDS_FIXED_WORDS + 1616u)
 static inline uint32_t cbc_plan_dec_lds_bytes(const cbc_lds_caps *caps)
 {
-    return 4u * (CBC_PLAN_DLDS_FIXED_WORDS + 2u * caps->cap_pos + caps->cap_var);
+    return 4u * (CBC_PLAN_DLDS_FIXED_WORDS + 2u * caps->cap_pos);
 }
 
 /* Upper bound on the payload of a block.  Every model total stays below 2^20, so one coded symbol
@@ -35,18 +38,21 @@ static inline uint64_t cbc_plan_output(cbc_block_desc *blocks, uint32_t n_blocks
     uint64_t off = 0;
     for (uint32_t b = 0; b < n_blocks; b++) {
         cbc_block_desc *bd = &blocks[b];
-        uint64_t nsym = 136u + 2u * CBC_CAP_NAME + 16ull * bd->n_reads;
+        uint64_t nsym = 136u + 2u * CBC_CAP_NAME + 16ull * bd->n_reads, nev = 0;
         for (uint32_t r = 0; r < bd->n_reads; r++) {
             const cbc_read_rec *rr = &recs[bd->rec_base + r];
             const uint32_t *t = tok + bd->tok_base + rr->tok_off;
             uint32_t n_cig = t[0] & 0xffffu, n_md = t[0] >> 16;
             uint64_t ev = n_md;
             for (uint32_t k = 0; k < n_cig; k++) if ((t[2 + k] & 15u) != CBC_OP_M) ev += t[2 + k] >> 4;
-            nsym += 2 * ev;
+            nsym += 2 * ev; nev += ev;
         }
-        uint64_t cap = (3 * nsym + 256 + 255) & ~255ull;
-        if (cap > 0xffffff00ull) cap = 0xffffff00ull;
-        bd->out_off = off; bd->out_cap = (uint32_t)cap;
+        /* [0, payload_cap): payload; [payload_cap, out_cap): the block's var-event list (one word per
+         * var symbol), kept in HBM/L2 instead of LDS */
+        uint64_t payload_cap = (3 * nsym + 256 + 255) & ~255ull;
+        uint64_t cap = payload_cap + ((4 * (nev + 64) + 255) & ~255ull);
+        if (cap > 0xffffff00ull) { cap = 0xffffff00ull; payload_cap = cap / 2; payload_cap &= ~255ull; }
+        bd->out_off = off; bd->out_cap = (uint32_t)cap; bd->reserved = (uint32_t)payload_cap;
         off += cap;
     }
     return off;

@@ -23,6 +23,7 @@ struct WaveGPU {
     static CBC_FN V32 lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
     static CBC_FN V32 splat(uint32_t x) { return x; }
     static CBC_FN Mask all() { return true; }
+    static CBC_FN void barrier() { __syncthreads(); }          /* the two wavefronts of a block's workgroup */
     static CBC_FN V32 select(Mask m, V32 a, V32 b) { return m ? a : b; }
     static CBC_FN uint64_t ballot(Mask m) { return __ballot(m); }
     /* make a value the compiler cannot prove uniform a scalar (it IS uniform by construction) */
@@ -83,6 +84,18 @@ struct WaveGPU {
     {
         uint4 r = m ? p[idx] : make_uint4(0, 0, 0, 0);
         a = r.x; b = r.y; c = r.z; d = r.w;
+    }
+    /* A list in GLOBAL memory that the same wavefront appends to and re-reads (var events): reads
+     * bypass the CU's vector L1 (agent-scope relaxed atomic load = glc/sc1 load) and the appending lane
+     * drains its store before the next read can issue, so a lane never sees a stale line. */
+    static CBC_FN V32 load32_list(const uint32_t *p, V32 idx, Mask m, uint32_t other)
+    {
+        return m ? __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : other;
+    }
+    static CBC_FN void append_list(uint32_t *p, uint32_t idx, uint32_t val)
+    {
+        if (lane() == 0) __hip_atomic_store(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0f70);        /* vmcnt(0) */
     }
     /* wave-uniform reads (same address in every lane) */
     static CBC_FN uint32_t read_uni(const uint32_t *p, uint32_t idx) { return uni(p[idx]); }

@@ -49,6 +49,7 @@ class DecDeviceBatch(ctypes.Structure):
         ("d_recs", ctypes.c_void_p), ("n_recs", ctypes.c_uint64),
         ("d_seq", ctypes.c_void_p), ("seq_bytes", ctypes.c_uint64),
         ("d_results", ctypes.c_void_p),
+        ("d_var_scratch", ctypes.c_void_p), ("var_scratch_words", ctypes.c_uint64),
         ("caps", host.LdsCaps),
     ]
 

@@ -99,7 +99,8 @@ typedef struct cbc_block_desc {
     uint32_t name_off;     /* offset in names[] of the NUL-terminated contig name               */
     uint32_t read_length;  /* header read length L0 (get_read_length, sam_file_allocation.c:26) */
     uint32_t n_tok;        /* words of tok[] owned by this block (bounds the token prefetch)    */
-    uint32_t reserved;
+    uint32_t reserved;     /* set by cbc_gpu_plan_output: bytes of the out area that are payload; */
+                           /* the rest, up to out_cap, holds the block's var-event list          */
 } cbc_block_desc;
 
 typedef struct cbc_block_result {
@@ -118,8 +119,9 @@ typedef struct cbc_block_result {
 #define CBC_WELL_SEED      0x55555555u  /* sam_file_allocation.c:399, the -DDEBUG constant         */
 
 typedef struct cbc_lds_caps {
-    uint32_t cap_pos;      /* entries of the POS-delta alphabet (>= max distinct deltas + 1)     */
-    uint32_t cap_var;      /* var-symbol events (>= max var symbols per block)                   */
+    uint32_t cap_pos;      /* entries of the POS-delta alphabet in LDS (>= max distinct deltas + 1) */
+    uint32_t cap_var;      /* var symbols per block: sizes the event list, which lives in global    */
+                           /* memory (behind the payload area on encode, in d_var_scratch on decode) */
 } cbc_lds_caps;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -208,6 +210,7 @@ typedef struct cbc_dec_device_batch {
     cbc_read_rec             *d_recs;    uint64_t n_recs;     /* out: pos (block-local), flag, rlen */
     uint8_t                  *d_seq;     uint64_t seq_bytes;  /* out: bases; >= sum + 8             */
     cbc_block_result         *d_results;                      /* nbytes = records decoded           */
+    uint32_t                 *d_var_scratch; uint64_t var_scratch_words; /* n_blocks * caps.cap_var words */
     cbc_lds_caps              caps;                           /* from the container header          */
 } cbc_dec_device_batch;
 

@@ -33,6 +33,7 @@ class DecDeviceBatch(ctypes.Structure):
         ("d_recs", ctypes.c_void_p), ("n_recs", ctypes.c_uint64),
         ("d_seq", ctypes.c_void_p), ("seq_bytes", ctypes.c_uint64),
         ("d_results", ctypes.c_void_p),
+        ("d_var_scratch", ctypes.c_void_p), ("var_scratch_words", ctypes.c_uint64),
         ("caps", host.LdsCaps),
     ]
 
@@ -83,9 +84,10 @@ def emu_decode(plan):
     recs = np.zeros(plan.n_recs, dtype=host.REC_DTYPE)
     seq = np.zeros(plan.n_recs * plan.seq_stride + 16, dtype=np.uint8)
     res = np.zeros(plan.n_blocks, dtype=host.RESULT_DTYPE)
+    vs = np.zeros(max(plan.n_blocks * plan.cap_var, 1), dtype=np.uint32)
     db = DecDeviceBatch(pay.ctypes.data, pay.size, blocks.ctypes.data, plan.n_blocks, plan.ref.ctypes.data, len(plan.ref),
                         recs.ctypes.data, plan.n_recs, seq.ctypes.data, seq.size, res.ctypes.data,
-                        host.LdsCaps(plan.cap_pos, plan.cap_var))
+                        vs.ctypes.data, vs.size, host.LdsCaps(plan.cap_pos, plan.cap_var))
     if L.emu_decode_blocks(ctypes.byref(db)) != 0:
         raise RuntimeError("emulation reported an invariant violation")
     return recs, seq, res

@@ -26,7 +26,7 @@ int emu_encode_blocks(const cbc_device_batch *b)
     uint32_t words = cbc_plan_lds_bytes(&b->caps) / 4;
     for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
         std::vector<uint32_t> lds(words, 0xdeadbeefu);      /* LDS is not zero-initialised on the GPU either */
-        cbc_encode_stream<WaveEmu>(A, blk, lds.data());
+        cbc_encode_stream<WaveEmu, CBC_ROLE_FUSED>(A, blk, lds.data());
     }
     return g_emu_errors ? -100 : 0;
 }
@@ -41,6 +41,7 @@ int emu_decode_blocks(const cbc_dec_device_batch *b)
     A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
     A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
     A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    A.var_scratch = b->d_var_scratch; A.var_scratch_words = b->var_scratch_words;
     g_emu_errors = 0;
     uint32_t words = cbc_plan_dec_lds_bytes(&b->caps) / 4;
     for (uint32_t blk = 0; blk < b->n_blocks; blk++) {

@@ -58,6 +58,7 @@ struct WaveEmu {
 
     static V32 lane() { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)i; return r; }
     static V32 splat(uint32_t x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x; return r; }
+    static void barrier() { emu_oob("barrier reached in the fused emulation"); }
     static Mask all() { Mask m; for (int i = 0; i < 64; i++) m.b[i] = true; return m; }
     static V32 select(const Mask &m, const V32 &a, const V32 &b) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? a.v[i] : b.v[i]; return r; }
     static uint64_t ballot(const Mask &m) { uint64_t r = 0; for (int i = 0; i < 64; i++) if (m.b[i]) r |= 1ull << i; return r; }
@@ -100,6 +101,8 @@ struct WaveEmu {
             a.v[i] = r.x; b.v[i] = r.y; c.v[i] = r.z; d.v[i] = r.w;
         }
     }
+    static V32 load32_list(const uint32_t *p, const V32 &idx, const Mask &m, uint32_t other) { return load32(p, idx, m, other); }
+    static void append_list(uint32_t *p, uint32_t idx, uint32_t val) { p[idx] = val; }
     static uint32_t read_uni(const uint32_t *p, uint32_t idx) { return p[idx]; }
     static uint32_t read_uni8(const uint8_t *p, uint32_t idx) { return p[idx]; }
     static void write_uni(uint32_t *p, uint32_t idx, uint32_t val) { p[idx] = val; }
