@@ -57,6 +57,9 @@
 #define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* 256 words = 8192-bit Bloom filter on var ctx */
 #define CBC_LDS_VSLOT   (768u + 2u * CBC_CAP_NAME + 256u) /* 2 x 256: dense excess of the two hot var contexts */
 #define CBC_LDS_BATCH   (768u + 2u * CBC_CAP_NAME + 256u + 512u)  /* 2 x 196: symbol batches producer -> coder wave */
+#ifndef CBC_BATCH_MIN
+#define CBC_BATCH_MIN   40u    /* <= 64 - 12 (a record's fixed symbols) - 4 (edit counts) - slack: see the 56 checks */
+#endif
 #define CBC_BATCH_WORDS 196u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record} */
 #define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS)
 /* then pos_val[cap_pos], pos_cnt[cap_pos]; the var-event list lives in global memory (see var_code) */
@@ -928,7 +931,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
 #undef CBC_READ_BYTE
             }
             CBC_TS(5);                                        /* edits */
-            E.drain();                                        /* one coder instantiation per record */
+            if (E.q_len >= CBC_BATCH_MIN) E.drain();          /* hand over once a few records' symbols are pending */
             CBC_TS(6);                                        /* coder */
         }
     }
@@ -941,6 +944,10 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         E.rname_code(E.prevChar, (uint32_t)'\n');
         E.rname_code((uint32_t)'\n', 0u);
     }
+#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+    if (ROLE == CBC_ROLE_MODEL && E.cap_var >= 64u) for (int i = 0; i < 16; i++) {   /* diagnostic build: tail of the event area */
+        W::write_uni(E.var_ev + E.cap_var - 32u, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.var_ev + E.cap_var - 32u, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
+#endif
     if (ROLE == CBC_ROLE_MODEL) { E.publish(1u); return; }       /* last batch; carries the status if a model check failed */
     E.drain();
     if (E.status == CBC_ST_OK) nbytes = E.finish();
