@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--block-reads", type=int, default=4096)
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="encode", choices=["encode", "decode"],
+                    help="encode = BASELINE.json's metric (default); decode = the mirror kernel on the same workload "
+                         "(the payloads are produced by one untimed encode launch and checked to decode to the packed bases)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real path); gloo = rehearsal of the N>1 host logic when "
                          "several ranks must share one GPU (payloads take a detour through host memory)")
@@ -107,18 +110,23 @@ def main():
 
     gather_cap = None
     gather_list = None
+    dec = None
 
-    def step():
+    def encode_once():
         enc.encode_device(db, stream)
         enc.compact_device(d_out.data_ptr(), d_blocks.data_ptr(), d_res.data_ptr(), n_blocks, d_offs.data_ptr(),
                            d_packed.data_ptr(), packed_cap, stream)
+
+    def step():
+        if args.mode == "decode":
+            enc.decode_device(dec["db"], stream)
+            return
+        encode_once()
         if world > 1:
             dist.gather(d_packed[:gather_cap].to(cdev), gather_list, dst=0)
 
     # first launch: check every block finished and size the gather
-    enc.encode_device(db, stream)
-    enc.compact_device(d_out.data_ptr(), d_blocks.data_ptr(), d_res.data_ptr(), n_blocks, d_offs.data_ptr(),
-                       d_packed.data_ptr(), packed_cap, stream)
+    encode_once()
     torch.cuda.synchronize()
     res = d_res.cpu().numpy().view(host.RESULT_DTYPE)
     if (res["status"] != 0).any():
@@ -126,12 +134,45 @@ def main():
         raise SystemExit("block %d failed: status %d at record %d" % (bad, res[bad]["status"], res[bad]["fail_read"]))
     payload_bytes = int(d_offs[-1].item())
     n_symbols = int(res["n_symbols"].sum())
+    first_payload = d_packed[:payload_bytes].clone()       # every later step must reproduce these bytes
     if world > 1:
         m = torch.tensor([payload_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         gather_cap = min(packed_cap, (int(m.item()) + 4095) // 4096 * 4096)
         if rank == 0:
             gather_list = [torch.empty(gather_cap, dtype=torch.uint8, device=cdev) for _ in range(world)]
+
+    if args.mode == "decode":
+        # lay the decode launch out over the compacted payloads that are already resident
+        stride = (args.read_len + 3) // 4 * 4
+        offs = d_offs.cpu().numpy().astype(np.uint64)
+        dblocks = np.zeros(n_blocks, dtype=host.DEC_BLOCK_DTYPE)
+        dblocks["in_off"] = offs[:-1]
+        dblocks["in_bytes"] = (offs[1:] - offs[:-1]).astype(np.uint32)
+        dblocks["ref_off"] = blocks["ref_off"]
+        dblocks["n_reads"] = blocks["n_reads"]
+        rb = np.concatenate([[0], np.cumsum(blocks["n_reads"].astype(np.uint64))])[:-1]
+        dblocks["rec_base"] = rb
+        dblocks["seq_base"] = rb * stride
+        dblocks["read_length"] = args.read_len
+        dblocks["seq_stride"] = stride
+        dec = {"blocks": to_dev(dblocks),
+               "recs": torch.zeros(n_recs * 16, dtype=torch.uint8, device=dev),
+               "seq": torch.zeros(n_recs * stride + 16, dtype=torch.uint8, device=dev),
+               "res": torch.zeros(n_blocks * 16, dtype=torch.uint8, device=dev),
+               "vs": torch.zeros(max(n_blocks * pb.cap_var, 1), dtype=torch.int32, device=dev)}
+        dec["db"] = gpu.DecDeviceBatch(d_packed.data_ptr(), packed_cap, dec["blocks"].data_ptr(), n_blocks,
+                                       d_ref.data_ptr(), d_ref.numel(), dec["recs"].data_ptr(), n_recs,
+                                       dec["seq"].data_ptr(), dec["seq"].numel(), dec["res"].data_ptr(),
+                                       dec["vs"].data_ptr(), dec["vs"].numel(), caps)
+        enc.decode_device(dec["db"], stream)
+        torch.cuda.synchronize()
+        dres = dec["res"].cpu().numpy().view(host.RESULT_DTYPE)
+        if (dres["status"] != 0).any():
+            raise SystemExit("decode failed: %r" % (dres[dres["status"] != 0][:1],))
+        got = dec["seq"][:n_recs * stride].view(n_recs, stride)[:, :args.read_len].cpu().numpy()
+        if not (got == pb.seq[:n_recs * args.read_len].reshape(n_recs, args.read_len)).all():
+            raise SystemExit("decode does not reproduce the packed bases")
 
     for _ in range(args.warmup):
         step()
@@ -159,6 +200,11 @@ def main():
     else:
         total_bases, total_recs = n_bases, n_recs
 
+    if args.mode == "encode":
+        torch.cuda.synchronize()
+        if int(d_offs[-1].item()) != payload_bytes or not torch.equal(d_packed[:payload_bytes], first_payload):
+            raise SystemExit("bench.py: the timed launches did not reproduce the first launch's bitstreams")
+
     ms_per_step = elapsed * 1e3 / args.steps
     value = total_bases * args.steps / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
@@ -168,7 +214,7 @@ def main():
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3
     # passes of this same command (profiles/README.md) are reported when the workload is the default one.
     traffic, traffic_src = None, None
-    if args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096:
+    if args.mode == "encode" and args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
         if cands:
@@ -195,7 +241,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM",
+            "metric": "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM" if args.mode == "encode"
+                      else "Mbases/s decoded (round trip verified) on synthetic 150 bp SAM",
             "value": round(value, 2), "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
@@ -209,7 +256,7 @@ def main():
                        "host_pack_seconds": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "cbc_encode_blocks_kernel", "kernel_ms": round(k_ms, 3),
+                         "kernel": "cbc_%s_blocks_kernel" % args.mode, "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }

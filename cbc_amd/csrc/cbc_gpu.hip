@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdint.h>
 #include <new>
 
 #include "../../include/cbc_gpu.h"
@@ -18,6 +19,8 @@
 #include "cbc_plan.h"
 
 #define API extern "C" __attribute__((visibility("default")))
+/* internal marker: "use the context's own stream" (host-buffer entry points only) */
+#define CBC_CTX_STREAM ((void *)(uintptr_t)1)
 
 /* ------------------------------------------------------------------------------------------------
  * kernels
@@ -176,7 +179,7 @@ API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b
     const uint32_t lds = cbc_plan_lds_bytes(&b->caps);
     if (lds > 160u * 1024u) return set_err(ctx, CBC_E_ARG, "lds caps need more than 160 KiB", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t s = hip_stream == CBC_CTX_STREAM ? ctx->stream : (hipStream_t)hip_stream;
     cbc_enc_args A;
     A.recs = b->d_recs; A.seq = b->d_seq; A.tok = b->d_tok; A.names = b->d_names; A.blocks = b->d_blocks;
     A.ref = b->d_ref; A.out = b->d_out; A.results = b->d_results;
@@ -214,7 +217,7 @@ API int cbc_gpu_compact_device(cbc_gpu_ctx *ctx, const uint8_t *d_scratch, const
     if (!ctx || !d_scratch || !d_blocks || !d_results || !d_offsets || !d_packed) return CBC_E_ARG;
     if (n_blocks == 0) return CBC_OK;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t s = hip_stream == CBC_CTX_STREAM ? ctx->stream : (hipStream_t)hip_stream;
     hipLaunchKernelGGL(cbc_scan_sizes_kernel, dim3(1), dim3(1024), 0, s, d_results, d_offsets, n_blocks);
     HIPCHK(hipGetLastError(), "launch cbc_scan_sizes_kernel");
     hipLaunchKernelGGL(cbc_compact_kernel, dim3(n_blocks), dim3(256), 0, s, d_scratch, d_blocks,
@@ -263,12 +266,12 @@ API int cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_
         db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_out = (uint8_t *)d_out; db.out_bytes = scratch;
         db.d_results = (cbc_block_result *)d_res; db.seq_bytes = hb->seq_bytes; db.n_tok = ntok; db.n_recs = hb->n_recs;
         db.caps = hb->caps;
-        rc = cbc_gpu_encode_blocks_device(ctx, &db, NULL);
+        rc = cbc_gpu_encode_blocks_device(ctx, &db, CBC_CTX_STREAM);
         if (rc) goto done;
     }
     GO(hipMalloc(&d_packed, scratch), "hipMalloc packed");
     rc = cbc_gpu_compact_device(ctx, (const uint8_t *)d_out, (const cbc_block_desc *)d_blocks, (const cbc_block_result *)d_res,
-                                nb, (uint64_t *)d_off, (uint8_t *)d_packed, scratch, NULL);
+                                nb, (uint64_t *)d_off, (uint8_t *)d_packed, scratch, CBC_CTX_STREAM);
     if (rc) goto done;
     res = results ? results : (cbc_block_result *)malloc((size_t)nb * sizeof(cbc_block_result));
     if (!res) { rc = CBC_E_NOMEM; goto done; }
@@ -312,7 +315,7 @@ API int cbc_gpu_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batc
     const uint32_t lds = cbc_plan_dec_lds_bytes(&b->caps);
     if (lds > 160u * 1024u) return set_err(ctx, CBC_E_ARG, "lds caps need more than 160 KiB", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t s = hip_stream == CBC_CTX_STREAM ? ctx->stream : (hipStream_t)hip_stream;
     cbc_dec_args A;
     A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
     A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
@@ -357,7 +360,7 @@ API int cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
         db.n_blocks = n_blocks; db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = (cbc_read_rec *)d_recs;
         db.n_recs = n_recs; db.d_seq = (uint8_t *)d_seq; db.seq_bytes = seq_bytes + 16; db.d_results = (cbc_block_result *)d_res;
         db.caps = *caps; db.d_var_scratch = (uint32_t *)d_vs; db.var_scratch_words = vs_words;
-        rc = cbc_gpu_decode_blocks_device(ctx, &db, NULL);
+        rc = cbc_gpu_decode_blocks_device(ctx, &db, CBC_CTX_STREAM);
         if (rc) goto done;
     }
     res = results ? results : (cbc_block_result *)malloc((size_t)n_blocks * sizeof(cbc_block_result));

@@ -155,8 +155,10 @@ int  cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *batch,
                            cbc_block_result *results /* n_blocks or NULL */);
 
 /* Device-pointer entry point (what bench.py and the multi-GPU host use): every pointer is a
- * device address, the launch is asynchronous on `hip_stream` (a hipStream_t, NULL = the context's
- * own stream).  out_off/out_cap in d_blocks must already be set (cbc_gpu_plan_output). */
+ * device address, the launch is asynchronous on `hip_stream`, a hipStream_t used exactly as given
+ * (NULL is HIP's null stream, which is what torch's default stream is).  Everything the launch reads
+ * or overwrites must be ordered before it ON THAT STREAM by the caller.  out_off/out_cap in d_blocks
+ * must already be set (cbc_gpu_plan_output). */
 typedef struct cbc_device_batch {
     const cbc_read_rec   *d_recs;
     const uint8_t        *d_seq;
