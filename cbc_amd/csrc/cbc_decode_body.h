@@ -25,14 +25,17 @@
 #include "../../include/cbc_gpu.h"
 #include "cbc_encode_body.h"      /* constants, lane-table map, cbc_basepair, cbc_le64 */
 
-/* LDS words of the decoder: the encoder's tables, then 4 x 256 pos_alpha byte histograms, three
- * 256-entry edit lists, and a 320-byte scratch read */
-#define CBC_DLDS_HIST    CBC_LDS_FIXED                 /* 1024: registered POS deltas per byte value */
-#define CBC_DLDS_DELS    (CBC_LDS_FIXED + 1024u)       /* 256: deletion positions (matched coords)  */
-#define CBC_DLDS_INS     (CBC_LDS_FIXED + 1280u)       /* 256: (output index << 8) | base char      */
-#define CBC_DLDS_TMP     (CBC_LDS_FIXED + 1536u)       /* 80 words: insertion-free read, bytes      */
-#define CBC_DLDS_FIXED   (CBC_LDS_FIXED + 1616u)
+/* LDS words of the decoder: the encoder's tables (its batch area is reused here for the scratch read
+ * and the deletion list), then the 4 x 256 pos_alpha byte histograms as u16 pairs and the insertion list */
+#define CBC_DLDS_TMP     CBC_LDS_BATCH                 /* 80 words: insertion-free read, bytes      */
+#define CBC_DLDS_DELS    (CBC_LDS_BATCH + 80u)         /* 256: deletion positions (matched coords)  */
+#define CBC_DLDS_HIST    CBC_LDS_FIXED                 /* 512: registered POS deltas per byte value, u16 x 2 per word */
+#define CBC_DLDS_INS     (CBC_LDS_FIXED + 512u)        /* 256: (output index << 8) | base char      */
+#define CBC_DLDS_FIXED   (CBC_LDS_FIXED + 768u)
 /* then pos_val[cap_pos], pos_cnt[cap_pos]; the var-event list is in global scratch (cap_var words per block) */
+#if (80u + 256u) > 2u * CBC_BATCH_WORDS
+#error "decoder scratch does not fit the encoder's batch area"
+#endif
 
 struct cbc_dec_args {
     const uint8_t            *in;         /* payload bytes of all blocks                    */
@@ -322,10 +325,19 @@ struct CbcDec {
         uint32_t n = 256u + 10u * (pos_card - 1u);
         if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return 0u; }
         uint32_t tg = target(n), lo, cnt;
-        uint32_t x = dense_search(tab(CBC_DLDS_HIST) + 256u * k, 256u, 10u, tg, lo, cnt);
+        /* symbols 4*lane..4*lane+3 of context k = two words of u16 counts; excess = 10 per registered delta */
+        const uint32_t *h = tab(CBC_DLDS_HIST) + 128u * k;
+        V32 ln = W::lane();
+        V32 wa = W::load32(h, ln * 2u, W::all(), 0u), wb = W::load32(h, ln * 2u + 1u, W::all(), 0u);
+        uint32_t x = search4((wa & 0xffffu) * 10u, (wa >> 16) * 10u, (wb & 0xffffu) * 10u, (wb >> 16) * 10u, 256u, tg, lo, cnt);
         if (status != CBC_ST_OK) return 0u;
         step(lo, cnt, n);
         return x;
+    }
+    CBC_MFN void hist_inc(uint32_t k, uint32_t b)
+    {
+        uint32_t *h = tab(CBC_DLDS_HIST) + 128u * k;
+        W::write_uni(h, b >> 1, W::read_uni(h, b >> 1) + (1u << ((b & 1u) * 16u)));
     }
     CBC_MFN uint32_t pos_dec()                           /* returns x = delta + 1 */
     {
@@ -357,11 +369,7 @@ struct CbcDec {
         uint32_t x = (b3 << 24) | (b2 << 16) | (b1 << 8) | b0;
         if (status != CBC_ST_OK) return 0u;
         if (pos_card >= cap_pos) { fail(CBC_ST_CAP_POS); return 0u; }
-        uint32_t *hist = tab(CBC_DLDS_HIST);
-        W::write_uni(hist, b3, W::read_uni(hist, b3) + 1u);
-        W::write_uni(hist, 256u + b2, W::read_uni(hist, 256u + b2) + 1u);
-        W::write_uni(hist, 512u + b1, W::read_uni(hist, 512u + b1) + 1u);
-        W::write_uni(hist, 768u + b0, W::read_uni(hist, 768u + b0) + 1u);
+        hist_inc(0u, b3); hist_inc(1u, b2); hist_inc(2u, b1); hist_inc(3u, b0);
         if (pos_card < 64u) {
             pval = W::select(ln == pos_card, W::splat(x), pval);
             pcnt = W::select(ln == pos_card, W::splat(0u), pcnt);

@@ -22,7 +22,7 @@ static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
 
 /* decoder: the encoder's fixed tables + pos_alpha histograms + edit lists + scratch read
  * (must match CBC_DLDS_FIXED in cbc_decode_body.h) */
-#define CBC_PLAN_DLDS_FIXED_WORDS (CBC_PLAN_LDS_FIXED_WORDS + 1616u)
+#define CBC_PLAN_DLDS_FIXED_WORDS (CBC_PLAN_LDS_FIXED_WORDS + 768u)
 static inline uint32_t cbc_plan_dec_lds_bytes(const cbc_lds_caps *caps)
 {
     return 4u * (CBC_PLAN_DLDS_FIXED_WORDS + 2u * caps->cap_pos);
