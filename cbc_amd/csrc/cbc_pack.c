@@ -218,8 +218,54 @@ static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos
                     if (nt >= 2 * LINE_BUF) return fail(S, CBC_E_INPUT, "CIGAR %s too long%lld", cigar, 0);
                     tk[nt++] = ((uint32_t)v << 4) | op; n_cig++;
                     if (op == CBC_OP_STAR) return fail(S, CBC_E_INPUT, "CIGAR '*' on a mapped record at %s:%lld (the reference aborts on it)", rname, pos);
-                    if (op == CBC_OP_S && n_cig == 1)
-                        return fail(S, CBC_E_INPUT, "leading soft clip at %s:%lld is not supported (reference rebuilds MD in place, quirk Q6)", rname, pos);
+                    if (op == CBC_OP_S && n_cig == 1) {
+                        /* Leading soft clip (quirk Q6, read_compression.c:357-468).  For an imperfect read
+                         * the reference REBUILDS the MD string in place from the read and the reference
+                         * (over the ops that follow the clip), then treats the clipped bases exactly like an
+                         * insertion at matched coordinate 0 (Insers[].pos = 0, targetChar = read[ctrS], with
+                         * the add_snps_to_array early-return rule).  The rebuild is restated here on the
+                         * persistent MD buffer; the clip is then emitted as an I op, which the kernels
+                         * already code that way. */
+                        const uint8_t *refc = P->ref + ctg->ref_off;      /* reference[] of this contig, 0-based */
+                        if (memcmp(seq, refc + (pos - 1), rl) != 0) {      /* only reached when the match test fails */
+                            char *te = (char *)edits;
+                            uint32_t posRef = pos, posRead = (uint32_t)v, match = 0;
+                            const char *tc = seg + i + 1; int ti = 0;
+                            while (*tc != 0) {
+                                char c2 = tc[ti];
+                                if (c2 == 0) break;
+                                if (!isdigit((unsigned char)c2)) {
+                                    long tv = atoi(tc);
+                                    if (tv < 0 || tv > 4096) return fail(S, CBC_E_INPUT, "CIGAR %s: bad length %lld", cigar, tv);
+                                    if (c2 == 'M') {
+                                        for (long c3 = 0; c3 < tv; c3++) {
+                                            uint8_t rb = (size_t)(posRead + c3) < rl ? (uint8_t)seq[posRead + c3] : 0;
+                                            uint8_t fb = refc[posRef - 1 + c3];
+                                            if (rb == fb) match++;
+                                            else { te += sprintf(te, "%u", match); match = 0; *te++ = (char)fb; }
+                                            if (te - edits > 2 * LINE_BUF - 16) return fail(S, CBC_E_INPUT, "rebuilt MD too long at %s:%lld", rname, pos);
+                                        }
+                                        posRef += (uint32_t)tv; posRead += (uint32_t)tv; tc = tc + ti + 1; ti = -1;
+                                    } else if (c2 == 'I') { posRead += (uint32_t)tv; tc = tc + ti + 1; ti = -1; }
+                                    else if (c2 == 'D') {
+                                        if (match > 0) { te += sprintf(te, "%u", match); match = 0; }
+                                        *te++ = '^';
+                                        for (long c3 = 0; c3 < tv; c3++) *te++ = (char)toupper(refc[posRef + c3]);   /* sic: no -1 (:425) */
+                                        if (te - edits > 2 * LINE_BUF - 16) return fail(S, CBC_E_INPUT, "rebuilt MD too long at %s:%lld", rname, pos);
+                                        posRef += (uint32_t)tv; tc = tc + ti + 1; ti = -1;
+                                    } else if (c2 == 'S') {
+                                        if (match > 0) { te += sprintf(te, "%u", match); match = 0; }
+                                        tc = tc + ti + 1; ti = -1;
+                                    }
+                                }
+                                ti++;
+                            }
+                            if (match > 0) te += sprintf(te, "%u", match);
+                            /* ":460 tmpEdits = 0" nulls the pointer, not the string: the old MD's tail stays
+                             * unless the last thing written was a number (sprintf's own NUL) */
+                        }
+                        tk[nt - 1] = ((uint32_t)v << 4) | CBC_OP_I;
+                    }
                     if (op != CBC_OP_M) ev += (uint32_t)v;
                     seg = seg + i + 1; i = -1;
                 }

@@ -228,3 +228,45 @@ def test_decode_rejects_corrupt_payload(built):
         plan = host.UnpackPlan(blob, fa)
         recs, seq, dres = blockref.emu_decode(plan)          # must simply return
         assert int(dres[0]["status"]) in (0, 2, 3, 4, 5, 6, 7)
+
+
+def _soft_clip_sam(seed, n=600):
+    """Leading / trailing / double soft clips, with and without a mismatch (quirk Q6 path)."""
+    rng = np.random.default_rng(seed)
+    contig = synth.make_contig(rng, 50000)
+    recs, pos, L = [], 100, 100
+    A = synth._ACGT
+    for i in range(n):
+        pos += int(rng.integers(1, 40))
+        kind = i % 4
+        fl = 16 if i % 3 == 0 else 0
+        if kind == 0:
+            k = int(rng.integers(1, 6))
+            seq = np.concatenate([A[rng.integers(0, 4, size=k)], contig[pos - 1:pos - 1 + L - k]]).tobytes()
+            recs.append(dict(pos=pos, flag=fl, cigar="%dS%dM" % (k, L - k), seq=seq, md=str(L - k), nm=0))
+        elif kind == 1:
+            k = int(rng.integers(1, 6))
+            body = contig[pos - 1:pos - 1 + L - k].copy()
+            q = int(rng.integers(5, L - k - 5))
+            old = body[q]
+            body[q] = A[(int(np.where(A == old)[0][0]) + 1) % 4]
+            seq = np.concatenate([A[rng.integers(0, 4, size=k)], body]).tobytes()
+            recs.append(dict(pos=pos, flag=fl, cigar="%dS%dM" % (k, L - k), seq=seq,
+                             md="%d%s%d" % (q, chr(old), L - k - q - 1), nm=1))
+        elif kind == 2:
+            k, k2 = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+            seq = np.concatenate([A[rng.integers(0, 4, size=k)], contig[pos - 1:pos - 1 + L - k - k2],
+                                  A[rng.integers(0, 4, size=k2)]]).tobytes()
+            recs.append(dict(pos=pos, flag=fl, cigar="%dS%dM%dS" % (k, L - k - k2, k2), seq=seq, md=str(L - k - k2), nm=0))
+        else:
+            recs.append(dict(pos=pos, flag=fl, cigar="%dM" % L, seq=contig[pos - 1:pos - 1 + L].tobytes(), md=str(L), nm=0))
+    rbc = [("chrS", 50000, recs)]
+    return synth.fasta_text([("chrS", contig)]), synth.sam_text(rbc)
+
+
+def test_soft_clips_match_oracle_and_round_trip(built):
+    """Leading soft clips go through the packer's restatement of the reference's in-place MD rebuild."""
+    fa, sam = _soft_clip_sam(3)
+    pb = host.pack_sam(sam, fa, block_reads=256)
+    _check(pb, sam)
+    _roundtrip(pb, sam, fa)

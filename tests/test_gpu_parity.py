@@ -212,3 +212,11 @@ def test_cli_compress_decompress(built, tmp_path):
     payloads, res, offs, flat = enc.encode_blocks(pb)
     assert (tmp_path / "out.cbc").read_bytes() == pb.container(flat, offs)
     enc.close()
+
+
+def test_soft_clips(enc, built):
+    from test_emu_parity import _soft_clip_sam
+    fa, sam = _soft_clip_sam(3)
+    pb = host.pack_sam(sam, fa, block_reads=256)
+    _check_blocks(enc, pb, sam)
+    _gpu_roundtrip(enc, pb, sam, fa)

@@ -132,7 +132,6 @@ def test_unmapped_skipped_and_headers_ignored(built):
 
 @pytest.mark.parametrize("mutate,msg", [
     (lambda f: f.__setitem__(3, 0), "POS"),
-    (lambda f: f.__setitem__(5, "5S35M"), "leading soft clip"),
     (lambda f: f.__setitem__(5, "*"), "CIGAR '*'"),
     (lambda f: f.__setitem__(9, "A" * 253), "read length"),
 ])
