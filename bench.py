@@ -2,7 +2,7 @@
 """bench.py -- Mbases/s encoded (bit-exact) on synthetic 150 bp SAM, BASELINE.json's metric.
 
 One process per GPU.  A "step" is one pass of the hot path over one resident batch: the encode
-launch (one arithmetic stream per wavefront over every block) + the device-side compaction of the
+launch (one arithmetic stream per workgroup over every block: a model wavefront feeding a coder wavefront) + the device-side compaction of the
 per-block bitstreams, and for N > 1 the gather of every rank's bitstreams to rank 0 over RCCL
 (the path's one real exchange step).  Inputs are packed and resident in HBM before the timed
 region starts.  Work per GPU is fixed as N grows (each rank codes its own shard of `--reads`

@@ -1,6 +1,7 @@
 /*
- * cbc_encode_body.h -- one arithmetic stream per wavefront: the per-read encode loop of the
- * reference (compress_line .. encoder_last_step) as wave-cooperative code.
+ * cbc_encode_body.h -- one arithmetic stream per workgroup: the per-read encode loop of the
+ * reference (compress_line .. encoder_last_step) as wave-cooperative code, split over a model
+ * wavefront and a coder wavefront (CbcEnc::publish / consume_all); the CPU emulation runs it fused.
  *
  * Template parameter W supplies the 64-lane primitives (cbc_wave_gpu.h on the GPU).  Every
  * branch below is wave-uniform; per-lane data only flows through W::select / ballot / reduce_add /

@@ -1,9 +1,9 @@
 /*
  * cbc_gpu.hip -- libcbc_gpu.so: the HIP kernels and the C ABI of include/cbc_gpu.h (gfx950 only).
  *
- * Launch shape: one wavefront (64 threads) per block = per arithmetic stream; the wavefront's
- * model tables live in dynamic LDS (cbc_gpu_lds_bytes()), so occupancy is 160 KiB / that.  The
- * grid is the number of blocks (thousands), i.e. >> 256 CUs x waves per CU.
+ * Launch shape: one workgroup per block = per arithmetic stream (encode: 128 threads = model wavefront +
+ * coder wavefront; decode: 64 threads); the model tables live in dynamic LDS (cbc_gpu_lds_bytes()), so
+ * workgroups per CU = 160 KiB / that.  The grid is the number of blocks (thousands) >> 256 CUs.
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>

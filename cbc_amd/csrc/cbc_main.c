@@ -25,7 +25,7 @@ static void usage(const char *p)
     fprintf(stderr,
             "usage: %s -c [1] <in.sam> <out.cbc> <ref.fa>   compress the reads of a position-sorted SAM\n"
             "       %s -d|-x <in.cbc> <out.txt> <ref.fa>    reconstruct the reads, one per line\n"
-            "options: --block-reads N (default 4096)  --device N (default 0)\n", p, p);
+            "options: -l (header read length = longest read)  --block-reads N (default 4096)  --device N (default 0)\n", p, p);
 }
 
 static char *slurp(const char *path, size_t *len)
@@ -53,7 +53,7 @@ static int is_number(const char *s)
     return e && *e == 0;
 }
 
-static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device)
+static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length)
 {
     size_t sam_len = 0, fa_len = 0;
     char *sam = slurp(in, &sam_len), *fa = slurp(ref, &fa_len);
@@ -62,6 +62,7 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     char err[512];
     cbc_pack_opts po; cbc_pack_default_opts(&po);
     if (block_reads) po.block_reads = block_reads;
+    po.var_length = (uint32_t)var_length;
     cbc_packed *p = NULL;
     int rc = cbc_pack_sam(sam, sam_len, fa, fa_len, &po, &p, err, sizeof err);
     free(sam); free(fa);
@@ -100,7 +101,7 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, int dev
 int main(int argc, char **argv)
 {
     const char *files[3] = { 0, 0, 0 };
-    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0;
+    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0;
     uint32_t block_reads = 0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -128,7 +129,7 @@ int main(int argc, char **argv)
             break;
         case 'x': mode = 2; break;
         case 'd': mode = 2; break;                                /* README form: local decompress */
-        case 'l': fprintf(stderr, "cbc: -l (variable-length header) is accepted by the packer API, not by this CLI yet\n"); return 1;
+        case 'l': var_length = 1; break;                         /* src/main.c: header read length = longest SEQ */
         case 'u': case 's': case 'r': case 'D': case 'w': case 't': case 'v':
             fprintf(stderr, "cbc: option %s belongs to the reference's network / quality-value modes, which are out of scope\n", a);
             return 1;
@@ -145,6 +146,6 @@ int main(int argc, char **argv)
         fprintf(stderr, "cbc: user@host:file download mode (src/main.c:306-326) is out of scope\n");
         return 1;
     }
-    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device)
+    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length)
                      : cbc_cli_decompress(files[0], files[1], files[2], device);
 }

@@ -19,7 +19,8 @@
  * file the reference encoder (built with -DDEBUG, i.e. constant WELL seed) writes when it is run
  * on that block alone: a SAM holding just those records with the rebased POS and a one-contig
  * FASTA holding the reference window that starts at the block's first base.  One block is one
- * independent arithmetic stream and is coded by one wavefront.
+ * independent arithmetic stream, coded by one workgroup (encode: a model wavefront feeding a coder
+ * wavefront through LDS; decode: one wavefront).
  *
  * Plain C: pointers and sizes only, caller owns every buffer, no global state, every function
  * returns 0 on success or a negative CBC_E_* code.  One host thread per context.
@@ -189,7 +190,7 @@ int  cbc_gpu_compact_device(cbc_gpu_ctx *ctx, const uint8_t *d_scratch, const cb
 uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks,
                              const cbc_read_rec *recs, const uint32_t *tok);
 
-/* Dynamic LDS bytes one wavefront needs for `caps` (occupancy = 160 KiB / this). */
+/* Dynamic LDS bytes one block's workgroup needs for `caps` (workgroups per CU = 160 KiB / this). */
 uint32_t cbc_gpu_lds_bytes(const cbc_lds_caps *caps);
 
 /* ---- decode direction (replaces decompress(), src/compression.c:173-216,
