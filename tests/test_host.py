@@ -233,3 +233,50 @@ def test_unpack_plan_matches_the_container(built):
         host.UnpackPlan(b"nonsense" * 10, fa)
     with pytest.raises(host.CbcInputError, match="different length"):
         host.UnpackPlan(pb.container(payload, offs), fa.replace(b"A", b"", 1))
+
+
+def test_cli_argument_surface(built, tmp_path):
+    """`cbc` keeps the reference's argv conventions (src/main.c:85-204, README.md:58-72); on a box
+    without a GPU compression stops with a clear error instead of falling back to a CPU path."""
+    import subprocess
+    exe = os.path.join(ROOT, "cbc_amd", "csrc", "cbc")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "cbc_amd", "csrc"), "cbc"], stdout=subprocess.DEVNULL)
+    run = lambda *a: subprocess.run([exe, *a], capture_output=True, text=True)
+    r = run()
+    assert r.returncode == 1 and "Missing required filenames" in r.stderr and "usage:" in r.stderr
+    r = run("-u", "1", "a", "b", "c")
+    assert r.returncode == 1 and "out of scope" in r.stderr
+    r = run("-c", "0.5", "a", "b", "c")
+    assert r.returncode == 1 and "lossy" in r.stderr
+    r = run("-c", "a", "b", "c", "d")
+    assert r.returncode == 1 and "Garbage argument" in r.stderr
+    r = run("-d", "user@host:file", "b", "c")
+    assert r.returncode == 1 and "out of scope" in r.stderr
+    fa, sam, _, _ = synth.dataset(8, [50000], [200], 100)
+    (tmp_path / "in.sam").write_bytes(sam)
+    (tmp_path / "ref.fa").write_bytes(fa)
+    if gpu.lib().cbc_gpu_device_count() == 0:
+        for form in (["-c", "1"], ["-c"]):                       # main.c form and README form
+            r = run(*form, str(tmp_path / "in.sam"), str(tmp_path / "out.cbc"), str(tmp_path / "ref.fa"))
+            assert r.returncode == 1 and "no usable MI355X" in r.stderr and not (tmp_path / "out.cbc").exists()
+    bad = sam.replace(b"\t100M\t", b"\t*\t", 1)
+    (tmp_path / "bad.sam").write_bytes(bad)
+    r = run("-c", str(tmp_path / "bad.sam"), str(tmp_path / "out.cbc"), str(tmp_path / "ref.fa"))
+    assert r.returncode == 1 and "CIGAR" in r.stderr
+
+
+def test_cfg1_shape_round_trip_on_the_oracle(built):
+    """BASELINE.json configs[0]: chrI-sized contig (15 072 434 bp), 100 k x 100 bp reads, CPU encode + decode
+    round trip -- on the oracle, and the packer + kernel body agree with it on sampled blocks."""
+    import blockref
+    from oracle import oracle
+    pb, sam, fa = host.synth(0xCBC00001, 15_072_434, 100_000, 100, want_text=True, block_reads=4096)
+    stream, st = oracle.encode(sam, fa, return_stats=True)
+    assert st.n_records == 100_000 and st.read_length == 100
+    text, nr = oracle.decode(stream, fa)
+    assert nr == 100_000 and text == b"".join(ln.split(b"\t")[9] + b"\n" for ln in sam.splitlines())
+    lines = blockref.mapped_sam_lines(sam)
+    for b, payload, res in blockref.emu_encode_blocks(pb, [0, pb.n_blocks // 2, pb.n_blocks - 1]):
+        bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
+        assert int(res["status"]) == 0 and payload == oracle.encode(bsam, bfa)
