@@ -246,8 +246,10 @@ def main():
             "value": round(value, 2), "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "cfg2: synthetic %d bp SAM, %d reads per GPU vs a chr1-sized (%d bp) uniform-ACGT "
-                                   "contig, block-parallel encode" % (args.read_len, args.reads, args.contig_len),
+            "config": {"workload": "%s: synthetic %d bp SAM, %d reads per GPU vs a chr1-sized (%d bp) uniform-ACGT "
+                                   "contig, block-parallel %s" % (
+                                       {10_000_000: "cfg2", 49_791_284: "cfg3 (30x)"}.get(args.reads, "custom"),
+                                       args.read_len, args.reads, args.contig_len, args.mode),
                        "reads_per_gpu": n_recs, "blocks_per_gpu": n_blocks, "block_reads": args.block_reads,
                        "lds_bytes_per_wave": lds_bytes, "payload_bytes_per_gpu": payload_bytes,
                        "bits_per_read": round(payload_bytes * 8.0 / n_recs, 3),
