@@ -15,10 +15,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def built():
-    """Build the host library and the oracle (CPU only, seconds)."""
+    """Build the native pieces (no-op when up to date): host library, HIP library (hipcc cross-compiles
+    gfx950 without a GPU), the cbc program, and the oracle."""
     import subprocess
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cbc_amd", "csrc"), "libcbc_host.so"],
-                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cbc_amd", "csrc"), "all"], stdout=subprocess.DEVNULL)
     from oracle import oracle
     oracle.build()
     return True
