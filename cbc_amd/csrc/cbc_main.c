@@ -9,7 +9,8 @@
  *
  * Exactly three positional file names, in the reference's order (src/main.c:88-108, 200-204).
  * Network / QV modes of the reference (-u -s -r -D -w -t, and -d with user@host:file) are outside
- * the hot path and are refused with a message.  Extra options: --block-reads N, --device N.
+ * the hot path and are refused with a message.  Extra options: --block-reads N, --device N,
+ * --threads N, --verbose.
  * Exit status: 0 on success (the reference returns 1 on success, src/main.c:370 -- not reproduced).
  *
  * There is no CPU encoder or decoder in this program: without an MI355X it exits with an error.
@@ -18,6 +19,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include "../../include/cbc_host.h"
 
 static void usage(const char *p)
@@ -25,25 +31,28 @@ static void usage(const char *p)
     fprintf(stderr,
             "usage: %s -c [1] <in.sam> <out.cbc> <ref.fa>   compress the reads of a position-sorted SAM\n"
             "       %s -d|-x <in.cbc> <out.txt> <ref.fa>    reconstruct the reads, one per line\n"
-            "options: -l (header read length = longest read)  --block-reads N (default 4096)  --device N (default 0)\n", p, p);
+            "options: -l (header read length = longest read)  --block-reads N (default 4096)  --device N (default 0)\n"
+            "         --threads N (SAM parser threads, default one per CPU)  --verbose (stage times)\n", p, p);
 }
 
-static char *slurp(const char *path, size_t *len)
+/* Input files are mapped, not copied: the packer only ever reads [0, len). */
+static const char *map_file(const char *path, size_t *len)
 {
-    FILE *f = fopen(path, "rb");
-    if (!f) { fprintf(stderr, "cbc: cannot open %s: %s\n", path, strerror(errno)); return NULL; }
-    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return NULL; }
-    long n = ftell(f);
-    if (n < 0) { fclose(f); return NULL; }
-    rewind(f);
-    char *buf = (char *)malloc((size_t)n + 1);
-    if (!buf) { fclose(f); fprintf(stderr, "cbc: out of memory reading %s\n", path); return NULL; }
-    if (fread(buf, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(buf); fprintf(stderr, "cbc: short read on %s\n", path); return NULL; }
-    fclose(f);
-    buf[n] = 0;
-    *len = (size_t)n;
-    return buf;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) { fprintf(stderr, "cbc: cannot open %s: %s\n", path, strerror(errno)); return NULL; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { fprintf(stderr, "cbc: %s is not a regular file\n", path); close(fd); return NULL; }
+    *len = (size_t)st.st_size;
+    if (st.st_size == 0) { close(fd); return ""; }
+    void *p = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { fprintf(stderr, "cbc: cannot map %s: %s\n", path, strerror(errno)); return NULL; }
+    (void)madvise(p, (size_t)st.st_size, MADV_SEQUENTIAL);
+    return (const char *)p;
 }
+static void unmap_file(const char *p, size_t len) { if (p && len) munmap((void *)p, len); }
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 static int is_number(const char *s)
 {
@@ -53,19 +62,22 @@ static int is_number(const char *s)
     return e && *e == 0;
 }
 
-static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length)
+static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose)
 {
     size_t sam_len = 0, fa_len = 0;
-    char *sam = slurp(in, &sam_len), *fa = slurp(ref, &fa_len);
+    double t0 = now_s();
+    const char *sam = map_file(in, &sam_len), *fa = map_file(ref, &fa_len);
     if (!sam || !fa) return 1;
     printf("Compressing...\n");                                   /* src/compression.c:120 */
     char err[512];
     cbc_pack_opts po; cbc_pack_default_opts(&po);
     if (block_reads) po.block_reads = block_reads;
     po.var_length = (uint32_t)var_length;
+    po.n_threads = (uint32_t)threads;
     cbc_packed *p = NULL;
     int rc = cbc_pack_sam(sam, sam_len, fa, fa_len, &po, &p, err, sizeof err);
-    free(sam); free(fa);
+    unmap_file(sam, sam_len); unmap_file(fa, fa_len);
+    double t1 = now_s();
     if (rc) { fprintf(stderr, "cbc: %s\n", err); return 1; }
     cbc_gpu_ctx *ctx = NULL;
     rc = cbc_gpu_init(device, &ctx);
@@ -81,8 +93,10 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     uint8_t *payloads = (uint8_t *)malloc(cap ? cap : 1);
     uint64_t *offs = (uint64_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint64_t));
     if (!payloads || !offs) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
+    double t2 = now_s();
     rc = cbc_gpu_encode_blocks(ctx, &hb, payloads, cap, offs, NULL);
     if (rc) { fprintf(stderr, "cbc: encode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
+    double t3 = now_s();
     int64_t n = cbc_container_size(p, offs);
     uint8_t *blob = (uint8_t *)malloc((size_t)n);
     if (!blob || cbc_container_write(p, payloads, offs, blob, (uint64_t)n) != n) { fprintf(stderr, "cbc: container write failed\n"); return 1; }
@@ -90,6 +104,10 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     if (!fo || fwrite(blob, 1, (size_t)n, fo) != (size_t)n || fclose(fo) != 0) { fprintf(stderr, "cbc: cannot write %s\n", out); return 1; }
     printf("Final Size: %lld\n", (long long)n);                   /* src/compression.c:157 */
     printf("%llu reads in %u blocks, %llu bases\n", (unsigned long long)p->n_recs, p->n_blocks, (unsigned long long)p->n_bases);
+    float kms = 0; (void)cbc_gpu_last_kernel_ms(ctx, &kms);
+    if (verbose)
+        printf("time: pack %.3f s, device init + reference upload %.3f s, encode (H2D + kernel %.3f ms + D2H) %.3f s, write %.3f s\n",
+               t1 - t0, t2 - t1, (double)kms, t3 - t2, now_s() - t3);
     free(blob); free(payloads); free(offs);
     cbc_gpu_shutdown(ctx);
     cbc_packed_free(p);
@@ -101,7 +119,7 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, int dev
 int main(int argc, char **argv)
 {
     const char *files[3] = { 0, 0, 0 };
-    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0;
+    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0;
     uint32_t block_reads = 0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -112,6 +130,8 @@ int main(int argc, char **argv)
         }
         if (!strcmp(a, "--block-reads") && i + 1 < argc) { block_reads = (uint32_t)strtoul(argv[++i], NULL, 10); continue; }
         if (!strcmp(a, "--device") && i + 1 < argc) { device = atoi(argv[++i]); continue; }
+        if (!strcmp(a, "--threads") && i + 1 < argc) { threads = atoi(argv[++i]); if (threads < 0) threads = 0; continue; }
+        if (!strcmp(a, "--verbose")) { verbose = 1; continue; }
         if (!strcmp(a, "-h") || !strcmp(a, "--help")) { usage(argv[0]); return 0; }
         switch (a[1]) {
         case 'c':
@@ -146,6 +166,6 @@ int main(int argc, char **argv)
         fprintf(stderr, "cbc: user@host:file download mode (src/main.c:306-326) is out of scope\n");
         return 1;
     }
-    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length)
+    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose)
                      : cbc_cli_decompress(files[0], files[1], files[2], device);
 }

@@ -19,6 +19,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <time.h>
+#include <unistd.h>
 #include "../../include/cbc_host.h"
 
 #define LINE_BUF 1024              /* fgets(buffer, 1024, ...) in the reference */
@@ -83,7 +86,7 @@ static int load_fasta(packer_t *S, const char *fa, size_t len)
     uint64_t start = 0;
     S->n_fasta = 0;
     while (off < len) {
-        size_t e = off; while (e < len && fa[e] != '\n') e++;
+        size_t e; { const char *nl = (const char *)memchr(fa + off, '\n', len - off); e = nl ? (size_t)(nl - fa) : len; }
         size_t ll = e - off;
         if (ll >= LINE_BUF - 1) return fail(S, CBC_E_INPUT, "FASTA line longer than %s1022 bytes at offset %lld (reference loader limit)", "", (long long)off);
         int is_hdr = (ll > 0 && fa[off] == '>') || (first_line && off == 0);
@@ -100,7 +103,10 @@ static int load_fasta(packer_t *S, const char *fa, size_t len)
         } else {
             if (!in_contig) { in_contig = 1; start = P->ref_bytes; }
             if (grow((void **)&P->ref, &P->cap_ref, P->ref_bytes + ll, 1)) return CBC_E_NOMEM;
-            for (size_t i = 0; i < ll; i++) P->ref[P->ref_bytes + i] = (uint8_t)toupper((unsigned char)fa[off + i]);
+            {   /* toupper() in the C locale, written so that it vectorises */
+                uint8_t *d = P->ref + P->ref_bytes; const uint8_t *q = (const uint8_t *)fa + off;
+                for (size_t i = 0; i < ll; i++) { uint8_t ch = q[i]; d[i] = (uint8_t)(ch - (((uint8_t)(ch - 'a') < 26u) << 5)); }
+            }
             P->ref_bytes += ll;
         }
         first_line = 0;
@@ -170,38 +176,39 @@ static int delta_seen(packer_t *S, uint32_t x, int insert)
     }
 }
 
-/* One mapped record, fields exactly as load_sam_line leaves them in read_line_t. */
-static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos_i, const char *cigar,
-                      const char *seq, const char *edits)
+/* RNAME change (compress_rname strcmp, id_compression.c:46): the next FASTA record becomes current. */
+static int contig_open(packer_t *S, const char *rname, size_t nl)
 {
     cbc_packed *P = S->P;
-    size_t rl = strlen(seq);
+    close_block(S);
+    uint32_t ci = S->have_contig ? S->contig + 1 : 0;
+    char nm[64]; snprintf(nm, sizeof nm, "%.*s", (int)(nl < 60 ? nl : 60), rname);
+    if (ci >= S->n_fasta) return fail(S, CBC_E_INPUT, "RNAME %s is contig #%lld of the SAM but the FASTA has fewer records (contigs are consumed in FASTA order)", nm, (long long)ci + 1);
+    if (nl + 3 > CBC_CAP_NAME) return fail(S, CBC_E_INPUT, "RNAME %s longer than %lld characters", nm, (long long)CBC_CAP_NAME - 3);
+    if (grow32((void **)&P->names, &P->cap_names, (uint64_t)P->names_bytes + nl + 1, 1)) return CBC_E_NOMEM;
+    memcpy(P->names + P->names_bytes, rname, nl); P->names[P->names_bytes + nl] = 0;
+    P->contigs[ci].name_off = P->names_bytes;
+    P->names_bytes += (uint32_t)nl + 1;
+    S->contig = ci; S->have_contig = 1;
+    if (P->n_contigs < ci + 1) P->n_contigs = ci + 1;
+    return 0;
+}
+
+/* CIGAR + MD of one mapped record -> token words tk[0..*nt_out) and the record's var-symbol bound.
+ * Reads only shared, already final state (P->ref, the contig table), so worker threads may call it. */
+static int tokenise_record(packer_t *S, const cbc_contig_info *ctg, const char *rname, int32_t pos_i, const char *cigar,
+                           const char *seq, size_t rl, const char *edits, uint32_t *tk, uint32_t *nt_out, uint32_t *ev_out)
+{
+    cbc_packed *P = S->P;
     if (rl == 0 || rl > CBC_MAX_READ_LEN)
         return fail(S, CBC_E_INPUT, "read length %s%lld outside 1..252 (var-context limit of the reference, sam_models.c:317)", "", (long long)rl);
     if (pos_i < 1) return fail(S, CBC_E_INPUT, "POS %s%lld < 1", "", pos_i);
     uint32_t pos = (uint32_t)pos_i;
-
-    /* ---- contig change (compress_rname strcmp, id_compression.c:46) ---- */
-    if (!S->have_contig || strcmp(rname, S->prev_name) != 0) {
-        close_block(S);
-        uint32_t ci = S->have_contig ? S->contig + 1 : 0;
-        if (ci >= S->n_fasta) return fail(S, CBC_E_INPUT, "RNAME %s is contig #%lld of the SAM but the FASTA has fewer records (contigs are consumed in FASTA order)", rname, (long long)ci + 1);
-        size_t nl = strlen(rname);
-        if (nl + 3 > CBC_CAP_NAME) return fail(S, CBC_E_INPUT, "RNAME %s longer than %lld characters", rname, (long long)CBC_CAP_NAME - 3);
-        if (grow32((void **)&P->names, &P->cap_names, (uint64_t)P->names_bytes + nl + 1, 1)) return CBC_E_NOMEM;
-        memcpy(P->names + P->names_bytes, rname, nl + 1);
-        P->contigs[ci].name_off = P->names_bytes;
-        P->names_bytes += (uint32_t)nl + 1;
-        S->contig = ci; S->have_contig = 1;
-        if (P->n_contigs < ci + 1) P->n_contigs = ci + 1;
-        strcpy(S->prev_name, rname);
-    }
-    const cbc_contig_info *ctg = &P->contigs[S->contig];
     if ((uint64_t)pos - 1 + rl > ctg->length + CBC_REF_PAD - 8)
         return fail(S, CBC_E_INPUT, "record at %s POS %lld runs past the contig end + pad", rname, pos);
 
     /* ---- tokens: CIGAR ---- */
-    uint32_t *tk = S->tokbuf; uint32_t nt = 2, n_cig = 0, n_md = 0;
+    uint32_t nt = 2, n_cig = 0, n_md = 0;
     uint32_t ev = 0;                                    /* upper bound on var symbols of this record */
     {
         const char *seg = cigar; int i = 0;
@@ -330,8 +337,16 @@ static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos
     }
     ev += n_md;
     if (ev + 1 > S->o.max_cap_var) return fail(S, CBC_E_INPUT, "record at %s:%lld has more edits than max_cap_var", rname, pos);
+    *nt_out = nt; *ev_out = ev;
+    return 0;
+}
 
-    /* ---- block cut decision ---- */
+/* Block cut decision + the record's cbc_read_rec.  Advances P->seq_bytes / P->n_tok as counters; the
+ * caller stores the SEQ bytes and token words at the offsets they had on entry. */
+static int place_record(packer_t *S, uint32_t pos, uint32_t flag, size_t rl, uint32_t ev, uint32_t nt)
+{
+    cbc_packed *P = S->P;
+    const char *rname = (const char *)P->names + P->contigs[S->contig].name_off;
     int need_new = !S->blk_open;
     uint32_t x = 0;
     if (S->blk_open) {
@@ -361,21 +376,42 @@ static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos
     }
     S->blk_var += ev;
 
-    /* ---- append ---- */
+    /* ---- record ---- */
     cbc_block_desc *bd = &P->blocks[P->n_blocks];
     if (grow((void **)&P->recs, &P->cap_recs, P->n_recs + 1, sizeof(cbc_read_rec))) return CBC_E_NOMEM;
-    if (grow((void **)&P->seq, &P->cap_seq, P->seq_bytes + rl + 8, 1)) return CBC_E_NOMEM;
-    if (grow((void **)&P->tok, &P->cap_tok, P->n_tok + nt, sizeof(uint32_t))) return CBC_E_NOMEM;
     cbc_read_rec *r = &P->recs[P->n_recs++];
     r->pos = (uint32_t)((uint64_t)pos - S->blk_first_pos + 1);
     r->flag = (uint16_t)flag; r->rlen = (uint16_t)rl;
     r->seq_off = (uint32_t)(P->seq_bytes - bd->seq_base);
     r->tok_off = (uint32_t)(P->n_tok - bd->tok_base);
-    memcpy(P->seq + P->seq_bytes, seq, rl); P->seq_bytes += rl;
-    memcpy(P->tok + P->n_tok, tk, sizeof(uint32_t) * nt); P->n_tok += nt;
+    P->seq_bytes += rl; P->n_tok += nt;
     S->blk_reads++; S->blk_bases += rl; S->blk_prev_pos = pos;
     P->n_bases += rl;
     if (rl > P->max_read_len) P->max_read_len = (uint32_t)rl;
+    return 0;
+}
+
+/* One mapped record, fields exactly as load_sam_line leaves them in read_line_t (single-thread path). */
+static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos_i, const char *cigar,
+                      const char *seq, const char *edits)
+{
+    cbc_packed *P = S->P;
+    size_t rl = strlen(seq);
+    if (!S->have_contig || strcmp(rname, S->prev_name) != 0) {
+        int rc = contig_open(S, rname, strlen(rname));
+        if (rc) return rc;
+        snprintf(S->prev_name, sizeof S->prev_name, "%s", rname);
+    }
+    uint32_t nt = 0, ev = 0;
+    int rc = tokenise_record(S, &P->contigs[S->contig], rname, pos_i, cigar, seq, rl, edits, S->tokbuf, &nt, &ev);
+    if (rc) return rc;
+    uint64_t so = P->seq_bytes, to = P->n_tok;
+    if (grow((void **)&P->seq, &P->cap_seq, so + rl + 8, 1)) return CBC_E_NOMEM;
+    if (grow((void **)&P->tok, &P->cap_tok, to + nt, sizeof(uint32_t))) return CBC_E_NOMEM;
+    rc = place_record(S, (uint32_t)pos_i, flag, rl, ev, nt);
+    if (rc) return rc;
+    memcpy(P->seq + so, seq, rl);
+    memcpy(P->tok + to, S->tokbuf, sizeof(uint32_t) * nt);
     return 0;
 }
 
@@ -418,7 +454,7 @@ static void packer_release(packer_t *S) { free(S->dset); free(S->dstamp); }
 
 API void cbc_pack_default_opts(cbc_pack_opts *o)
 {
-    o->block_reads = 4096; o->max_cap_pos = 2048; o->max_cap_var = 8192; o->var_length = 0;
+    o->block_reads = 4096; o->max_cap_pos = 2048; o->max_cap_var = 8192; o->var_length = 0; o->n_threads = 0;
 }
 
 API void cbc_packed_free(cbc_packed *p)
@@ -463,6 +499,282 @@ static uint32_t header_read_length(const char *sam, size_t len, size_t *body_off
     return result;
 }
 
+/* One text line (NUL-terminated, with its '\n' as fgets leaves it) -> the 11 compulsory columns by
+ * strtok("\t") and the MD/XD aux field copied into S->edits, which otherwise keeps the previous
+ * line's value (read_line_t.edits persists, sam_file_allocation.c:437-529).
+ * Returns 1 = record, 0 = nothing on the line, < 0 = error. */
+static int split_line(packer_t *S, char *buffer, size_t off_after, char **f, uint32_t *flag, int32_t *pos, int *md_seen)
+{
+    char *save = NULL; int nf = 0;
+    *md_seen = 0;
+    while (nf < 11) {
+        char *t = strtok_r(nf ? NULL : buffer, "\t", &save);
+        if (!t) break;
+        f[nf++] = t;
+    }
+    if (nf == 0) return 0;
+    if (nf < 11) return fail(S, CBC_E_INPUT, "SAM record with fewer than 11 columns near offset %s%lld", "", (long long)off_after);
+    *flag = (uint16_t)atoi(f[1]);
+    *pos = atoi(f[3]);
+    int auxCnt = 0;
+    for (char *t = strtok_r(NULL, "\t", &save); t; t = strtok_r(NULL, "\t", &save)) {
+        if ((t[0] == 'M' || t[0] == 'X') && t[1] == 'D') {
+            size_t tl = strlen(t);
+            strcpy(S->edits, tl >= 5 ? t + 5 : "");
+            *md_seen = 1;
+        } else { auxCnt++; if (auxCnt == 20) break; }
+    }
+    return 1;
+}
+
+/* =============================== multi-threaded text path ================================= */
+/* The SAM body is cut into one chunk per thread at line boundaries.
+ *   phase 1 (parallel)   RNAME changes inside each chunk (mapped records only)
+ *   phase 1b (serial)    contig numbering across chunks, names table
+ *   phase 2 (parallel)   split + tokenise every line into chunk-local record / SEQ / token pools
+ *   phase 3 (serial)     block cutting over the 16-byte record summaries  } run
+ *   phase 4 (parallel)   pools -> the final SEQ / token arrays             } concurrently
+ * The result is identical, array for array, to the serial path.  A chunk whose first lines carry no
+ * MD/XD field would need the previous chunk's (possibly rewritten) MD text: that case, which real
+ * aligner output does not produce, returns MT_FALLBACK and the serial path runs instead. */
+#define MT_FALLBACK   1000
+#define MT_MAX_THREADS 64
+#define MT_MIN_BYTES  (1u << 20)
+
+typedef struct { uint32_t pos; uint16_t flag, rl; uint32_t nt_ev; uint32_t contig; } lrec_t;   /* nt | ev << 16 */
+typedef struct { uint64_t ord; const char *name; uint32_t len, contig; } chg_t;
+
+typedef struct chunk {
+    packer_t *S;                       /* thread-local parse state; S->P is the shared result */
+    const char *sam; size_t beg, end;
+    /* phase 1 */
+    uint64_t n_lines, n_mapped, seq_pred;
+    chg_t *chg; uint64_t n_chg, cap_chg;
+    const char *first_name, *last_name; uint32_t first_len, last_len;
+    /* phase 1b */
+    uint32_t contig0;                  /* contig of the chunk's first mapped record */
+    /* phase 2 */
+    lrec_t *lr; uint64_t n_lr;
+    uint8_t *seq; uint64_t n_seq;      /* written in place: P->seq + seq_dst, seq_pred bytes */
+    uint32_t *tok; uint64_t n_tok, cap_tok;
+    uint64_t n_unmapped;
+    int rc; char err[512];
+    /* phase 4 */
+    uint64_t seq_dst, tok_dst;
+    int phase;
+} chunk_t;
+
+static inline const char *next_field(const char *p, const char *e, const char **tok_end)
+{   /* strtok("\t"): skip tabs, the token runs to the next tab or the line end */
+    while (p < e && *p == '\t') p++;
+    if (p >= e) return NULL;
+    const char *q = (const char *)memchr(p, '\t', (size_t)(e - p));
+    *tok_end = q ? q : e;
+    return p;
+}
+
+static void chunk_phase1(chunk_t *c)
+{
+    const char *p = c->sam + c->beg, *end = c->sam + c->end;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *e = nl ? nl + 1 : end;
+        c->n_lines++;
+        const char *t1e, *t2e, *t3e;
+        const char *t1 = next_field(p, e, &t1e);
+        const char *t2 = t1 ? next_field(t1e, e, &t2e) : NULL;
+        const char *t3 = t2 ? next_field(t2e, e, &t3e) : NULL;
+        if (t3 && t3e < e && *t3e == '\t') {
+            char num[16]; size_t l = (size_t)(t2e - t2); if (l > 15) l = 15;
+            memcpy(num, t2, l); num[l] = 0;
+            uint32_t flag = (uint16_t)atoi(num);
+            if ((flag & 4) != 4) {
+                const char *q = t3e, *qe = t3e, *t10 = NULL;
+                for (int k = 4; k <= 10 && q; k++) { t10 = next_field(qe, e, &qe); q = t10; }
+                if (t10 && qe < e && *qe == '\t') c->seq_pred += (uint64_t)(qe - t10);   /* an 11th column follows */
+                uint32_t len = (uint32_t)(t3e - t3);
+                if (c->n_mapped == 0) { c->first_name = t3; c->first_len = len; }
+                else if (len != c->last_len || memcmp(t3, c->last_name, len) != 0) {
+                    if (grow((void **)&c->chg, &c->cap_chg, c->n_chg + 1, sizeof(chg_t))) { c->rc = CBC_E_NOMEM; return; }
+                    c->chg[c->n_chg].ord = c->n_mapped; c->chg[c->n_chg].name = t3; c->chg[c->n_chg].len = len; c->chg[c->n_chg].contig = 0;
+                    c->n_chg++;
+                }
+                c->last_name = t3; c->last_len = len;
+                c->n_mapped++;
+            }
+        }
+        p = e;
+    }
+}
+
+static void chunk_phase2(chunk_t *c)
+{
+    packer_t *S = c->S; cbc_packed *P = S->P;
+    const char *sam = c->sam;
+    size_t off = c->beg;
+    char buffer[LINE_BUF];
+    int have_md = 0;
+    uint64_t ord = 0, k = 0; uint32_t contig = c->contig0;
+    c->lr = (lrec_t *)malloc(sizeof(lrec_t) * (size_t)(c->n_mapped ? c->n_mapped : 1));
+    if (!c->lr) { c->rc = CBC_E_NOMEM; return; }
+    while (off < c->end) {
+        size_t e = off; { const char *nl = (const char *)memchr(sam + off, '\n', c->end - off); e = nl ? (size_t)(nl - sam) : c->end; }
+        size_t ll = (e < c->end ? e + 1 : e) - off;
+        if (ll > LINE_BUF - 1) { c->rc = fail(S, CBC_E_INPUT, "SAM line longer than %s1023 bytes at offset %lld (reference fgets limit)", "", (long long)off); return; }
+        memcpy(buffer, sam + off, ll); buffer[ll] = 0;
+        off += ll;
+        char *f[11]; uint32_t flag; int32_t pos; int md_seen;
+        int r = split_line(S, buffer, off, f, &flag, &pos, &md_seen);
+        if (r < 0) { c->rc = r; return; }
+        if (r == 0) continue;
+        if (md_seen) have_md = 1;
+        else if (!have_md) { c->rc = MT_FALLBACK; return; }       /* would inherit MD text from before the chunk */
+        if ((flag & 4) == 4) { c->n_unmapped++; continue; }
+        if (ord >= c->n_mapped) { c->rc = fail(S, CBC_E_INPUT, "internal: chunk record count changed%s%lld", "", 0); return; }
+        if (k < c->n_chg && c->chg[k].ord == ord) contig = c->chg[k++].contig;
+        size_t rl = strlen(f[9]);
+        uint32_t nt = 0, ev = 0;
+        if (grow((void **)&c->tok, &c->cap_tok, c->n_tok + 4 * LINE_BUF, sizeof(uint32_t))) { c->rc = CBC_E_NOMEM; return; }
+        int rc = tokenise_record(S, &P->contigs[contig], f[2], pos, f[5], f[9], rl, S->edits, c->tok + c->n_tok, &nt, &ev);
+        if (rc) { c->rc = rc; return; }
+        if (c->n_seq + rl > c->seq_pred) { c->rc = fail(S, CBC_E_INPUT, "internal: chunk SEQ bytes changed%s%lld", "", 0); return; }
+        memcpy(c->seq + c->n_seq, f[9], rl);
+        c->n_seq += rl; c->n_tok += nt;
+        lrec_t *l = &c->lr[ord++];
+        l->pos = (uint32_t)pos; l->flag = (uint16_t)flag; l->rl = (uint16_t)rl; l->nt_ev = nt | (ev << 16); l->contig = contig;
+    }
+    c->n_lr = ord;
+}
+
+static void chunk_phase4(chunk_t *c)
+{
+    cbc_packed *P = c->S->P;
+    if (c->n_tok) memcpy(P->tok + c->tok_dst, c->tok, sizeof(uint32_t) * (size_t)c->n_tok);
+    free(c->tok); c->tok = NULL;
+}
+
+static void *chunk_run(void *arg)
+{
+    chunk_t *c = (chunk_t *)arg;
+    if (c->phase == 1) chunk_phase1(c); else if (c->phase == 2) chunk_phase2(c); else chunk_phase4(c);
+    return NULL;
+}
+
+static int run_phase(chunk_t *ch, pthread_t *th, int n, int phase, int wait)
+{
+    int started = 0;
+    for (int t = 0; t < n; t++) {
+        ch[t].phase = phase;
+        if (pthread_create(&th[t], NULL, chunk_run, &ch[t]) != 0) break;
+        started++;
+    }
+    for (int t = started; t < n; t++) chunk_run(&ch[t]);           /* could not spawn: do it here */
+    if (wait) for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    return started;
+}
+
+static double mt_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+static int pack_body_mt(packer_t *S, const char *sam, size_t off, size_t sam_len, int nthreads)
+{
+    cbc_packed *P = S->P;
+    chunk_t *ch = (chunk_t *)calloc((size_t)nthreads, sizeof(chunk_t));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    packer_t *ps = (packer_t *)calloc((size_t)nthreads, sizeof(packer_t));
+    int rc = 0, committed = 0;
+    if (!ch || !th || !ps) { rc = CBC_E_NOMEM; goto out; }
+    {   /* chunk boundaries at line starts */
+        size_t body = sam_len - off, b = off;
+        for (int t = 0; t < nthreads; t++) {
+            size_t e = (t == nthreads - 1) ? sam_len : off + body / (size_t)nthreads * (size_t)(t + 1);
+            if (e < b) e = b;
+            if (e < sam_len && t != nthreads - 1) {
+                const char *nl = (const char *)memchr(sam + e, '\n', sam_len - e);
+                e = nl ? (size_t)(nl - sam) + 1 : sam_len;
+            }
+            ch[t].sam = sam; ch[t].beg = b; ch[t].end = e; b = e;
+            ps[t].P = P; ps[t].o = S->o; ps[t].err = ch[t].err; ps[t].errlen = sizeof ch[t].err; ps[t].n_fasta = S->n_fasta;
+            ch[t].S = &ps[t];
+        }
+    }
+    double T0 = mt_now();
+    run_phase(ch, th, nthreads, 1, 1);
+    double T1 = mt_now();
+    for (int t = 0; t < nthreads; t++) if (ch[t].rc) { rc = ch[t].rc; goto out; }
+    /* phase 1b: contig numbering in file order */
+    {
+        const char *prev = NULL; uint32_t prev_len = 0;
+        uint32_t names0 = P->names_bytes;
+        for (int t = 0; t < nthreads && !rc; t++) {
+            chunk_t *c = &ch[t];
+            if (c->n_mapped == 0) { c->contig0 = S->contig; continue; }
+            if (!S->have_contig || c->first_len != prev_len || memcmp(c->first_name, prev, prev_len) != 0)
+                rc = contig_open(S, c->first_name, c->first_len);
+            c->contig0 = S->contig;
+            for (uint64_t k = 0; k < c->n_chg && !rc; k++) {
+                rc = contig_open(S, c->chg[k].name, c->chg[k].len);
+                c->chg[k].contig = S->contig;
+            }
+            prev = c->last_name; prev_len = c->last_len;
+        }
+        if (rc) goto out;           /* contig errors are input errors, not fallbacks */
+        (void)names0;
+    }
+    {   /* SEQ bytes go straight to their final place: phase 1 measured them */
+        uint64_t nseq = P->seq_bytes;
+        for (int t = 0; t < nthreads; t++) { ch[t].seq_dst = nseq; nseq += ch[t].seq_pred; }
+        if (grow((void **)&P->seq, &P->cap_seq, nseq + 8, 1)) { rc = CBC_E_NOMEM; goto out; }
+        for (int t = 0; t < nthreads; t++) ch[t].seq = P->seq + ch[t].seq_dst;
+    }
+    double T2 = mt_now();
+    run_phase(ch, th, nthreads, 2, 1);
+    double T3 = mt_now();
+    for (int t = 0; t < nthreads; t++) if (ch[t].rc == MT_FALLBACK) { rc = MT_FALLBACK; goto out; }
+    for (int t = 0; t < nthreads; t++) if (ch[t].rc) {
+        rc = ch[t].rc;
+        if (S->err && S->errlen) snprintf(S->err, S->errlen, "%s", ch[t].err);
+        goto out;
+    }
+    /* sizes -> final arrays */
+    {
+        uint64_t nrec = 0, nseq = 0, ntok = 0;
+        for (int t = 0; t < nthreads; t++) {
+            if (ch[t].n_seq != ch[t].seq_pred) { rc = fail(S, CBC_E_INPUT, "internal: chunk SEQ bytes changed%s%lld", "", 0); goto out; }
+            ch[t].tok_dst = ntok; nrec += ch[t].n_lr; nseq += ch[t].n_seq; ntok += ch[t].n_tok; P->n_skipped_unmapped += ch[t].n_unmapped;
+        }
+        if (grow((void **)&P->recs, &P->cap_recs, nrec + 1, sizeof(cbc_read_rec)) ||
+            grow((void **)&P->tok, &P->cap_tok, ntok + 1, sizeof(uint32_t))) { rc = CBC_E_NOMEM; goto out; }
+    }
+    committed = 1;
+    double T3b = mt_now();
+    {
+        int started = run_phase(ch, th, nthreads, 4, 0);
+        /* phase 3 on this thread while the pools are copied */
+        S->have_contig = 0;                              /* replay the contig sequence for block cutting */
+        uint32_t cur = 0;
+        for (int t = 0; t < nthreads && !rc; t++) {
+            const lrec_t *lr = ch[t].lr;
+            for (uint64_t i = 0; i < ch[t].n_lr; i++) {
+                const lrec_t *l = &lr[i];
+                if (!S->have_contig || l->contig != cur) { close_block(S); cur = l->contig; S->contig = cur; S->have_contig = 1; }
+                rc = place_record(S, l->pos, l->flag, l->rl, l->nt_ev >> 16, l->nt_ev & 0xffffu);
+                if (rc) break;
+            }
+        }
+        double T4 = mt_now();
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+        if (getenv("CBC_PACK_TIMES")) fprintf(stderr, "pack_mt: scan %.3f  contigs %.3f  tokenise %.3f  alloc %.3f  place %.3f  copy-wait %.3f s\n", T1 - T0, T2 - T1, T3 - T2, T3b - T3, T4 - T3b, mt_now() - T4);
+    }
+out:
+    if (ch) for (int t = 0; t < nthreads; t++) { free(ch[t].chg); free(ch[t].lr); free(ch[t].tok); }
+    free(ch); free(th); free(ps);
+    if (rc == MT_FALLBACK && !committed) {
+        /* undo phase 1b so that the serial path starts clean */
+        P->names_bytes = 0; P->n_contigs = 0; S->have_contig = 0; S->contig = 0; P->n_skipped_unmapped = 0;
+    }
+    return rc;
+}
+
 API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t fasta_len,
                      const cbc_pack_opts *opts, cbc_packed **out, char *errbuf, size_t errlen)
 {
@@ -478,6 +790,20 @@ API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t 
     if (S->P->read_length < 1 || S->P->read_length > 256) {
         rc = fail(S, CBC_E_INPUT, "header read length %s%lld outside 1..256", "", S->P->read_length); goto done;
     }
+    if (S->o.n_threads != 1) {
+        int nt = (int)S->o.n_threads;
+        if (nt == 0) {                                  /* auto: one per online CPU, serial for small inputs */
+            long nc = sysconf(_SC_NPROCESSORS_ONLN);
+            nt = nc < 1 ? 1 : nc > MT_MAX_THREADS ? MT_MAX_THREADS : (int)nc;
+            if (sam_len - off < MT_MIN_BYTES) nt = 1;
+        }
+        if (nt > MT_MAX_THREADS) nt = MT_MAX_THREADS;
+        if (nt > 1) {
+            rc = pack_body_mt(S, sam, off, sam_len, nt);
+            if (rc != MT_FALLBACK) { if (!rc) rc = finish_pack(S); goto done; }
+            rc = 0;                                     /* nothing was committed: run the serial path */
+        }
+    }
     char buffer[LINE_BUF];
     while (off < sam_len) {
         size_t e = off; while (e < sam_len && sam[e] != '\n') e++;
@@ -485,23 +811,10 @@ API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t 
         if (ll > LINE_BUF - 1) { rc = fail(S, CBC_E_INPUT, "SAM line longer than %s1023 bytes at offset %lld (reference fgets limit)", "", (long long)off); goto done; }
         memcpy(buffer, sam + off, ll); buffer[ll] = 0;
         off += ll;
-        char *save = NULL, *f[11]; int nf = 0;
-        while (nf < 11) {                              /* the 11 compulsory columns, strtok("\t") */
-            char *t = strtok_r(nf ? NULL : buffer, "\t", &save);
-            if (!t) break;
-            f[nf++] = t;
-        }
-        if (nf == 0) continue;
-        if (nf < 11) { rc = fail(S, CBC_E_INPUT, "SAM record with fewer than 11 columns near offset %s%lld", "", (long long)off); goto done; }
-        uint32_t flag = (uint16_t)atoi(f[1]);
-        int32_t pos = atoi(f[3]);
-        int auxCnt = 0;
-        for (char *t = strtok_r(NULL, "\t", &save); t; t = strtok_r(NULL, "\t", &save)) {
-            if ((t[0] == 'M' || t[0] == 'X') && t[1] == 'D') {
-                size_t tl = strlen(t);
-                strcpy(S->edits, tl >= 5 ? t + 5 : "");
-            } else { auxCnt++; if (auxCnt == 20) break; }
-        }
+        char *f[11]; uint32_t flag; int32_t pos; int md_seen;
+        int r = split_line(S, buffer, off, f, &flag, &pos, &md_seen);
+        if (r < 0) { rc = r; goto done; }
+        if (r == 0) continue;
         if ((flag & 4) == 4) { S->P->n_skipped_unmapped++; continue; }      /* compression.c:50-52 */
         rc = add_record(S, f[2], flag, pos, f[5], f[9], S->edits);
         if (rc) goto done;

@@ -88,7 +88,8 @@ class UnpackPlanC(ctypes.Structure):
 
 class PackOpts(ctypes.Structure):
     _fields_ = [("block_reads", ctypes.c_uint32), ("max_cap_pos", ctypes.c_uint32),
-                ("max_cap_var", ctypes.c_uint32), ("var_length", ctypes.c_uint32)]
+                ("max_cap_var", ctypes.c_uint32), ("var_length", ctypes.c_uint32),
+                ("n_threads", ctypes.c_uint32)]
 
 
 class SynthOpts(ctypes.Structure):
@@ -140,7 +141,7 @@ def lib():
     return _lib
 
 
-def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False):
+def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False, threads=None):
     o = PackOpts()
     lib().cbc_pack_default_opts(ctypes.byref(o))
     if block_reads is not None:
@@ -150,6 +151,8 @@ def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False
     if max_cap_var is not None:
         o.max_cap_var = max_cap_var
     o.var_length = 1 if var_length else 0
+    if threads is not None:
+        o.n_threads = threads                  # 0 = one per online CPU, 1 = serial text path
     return o
 
 

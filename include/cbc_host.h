@@ -56,6 +56,7 @@ typedef struct cbc_pack_opts {
     uint32_t max_cap_pos;   /* cut a block before it needs more POS-delta entries (default 2048)  */
     uint32_t max_cap_var;   /* cut a block before it can hold more var symbols (default 8192)     */
     uint32_t var_length;    /* reference's -l: header read length = max over the file             */
+    uint32_t n_threads;     /* text-path worker threads: 0 = one per online CPU, 1 = serial       */
 } cbc_pack_opts;
 
 void cbc_pack_default_opts(cbc_pack_opts *o);

@@ -280,3 +280,85 @@ def test_cfg1_shape_round_trip_on_the_oracle(built):
     for b, payload, res in blockref.emu_encode_blocks(pb, [0, pb.n_blocks // 2, pb.n_blocks - 1]):
         bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
         assert int(res["status"]) == 0 and payload == oracle.encode(bsam, bfa)
+
+
+# ---------------------------------------------------------------- multi-threaded text path
+def _packed_arrays(pb):
+    return [np.asarray(a).tobytes() for a in (pb.recs, pb.seq, pb.tok, pb.blocks, pb.names)] + [
+        np.asarray(pb.info).tobytes(), np.asarray(pb.contigs).tobytes(),
+        pb.n_recs, pb.n_blocks, pb.n_tok, pb.n_bases, pb.n_skipped_unmapped, pb.read_length, pb.cap_pos, pb.cap_var,
+        int(pb.c_ptr.contents.max_read_len)]
+
+
+@pytest.mark.parametrize("threads", [2, 3, 8, 64])
+def test_threaded_packer_equals_the_serial_one(built, threads):
+    """Three contigs (the second one tiny so a chunk sees two RNAME changes), unmapped records in between,
+    indels and trailing soft clips: every array of the threaded pack is the serial pack's."""
+    fa, sam, rbc, _ = synth.dataset(11, [30000, 600, 20000], [900, 7, 700], 100, indel_frac=0.2, trailing_s_frac=0.1,
+                                     sub_rate=0.01, dup_pos_frac=0.2)
+    lines = sam.split(b"\n")
+    unm = b"u\t4\t*\t0\t0\t*\t*\t0\t0\t" + b"A" * 100 + b"\t" + b"I" * 100 + b"\tMD:Z:100"
+    lines = lines[:40] + [unm] + lines[40:900] + [unm, unm] + lines[900:]
+    sam = b"\n".join(lines)
+    a = host.pack_sam(sam, fa, threads=1, block_reads=128)
+    b = host.pack_sam(sam, fa, threads=threads, block_reads=128)
+    assert a.n_skipped_unmapped == 3 and a.n_blocks > 12
+    assert _packed_arrays(a) == _packed_arrays(b)
+
+
+def test_threaded_packer_leading_soft_clips_and_stale_md(built):
+    """Leading soft clips rebuild the MD text in place (quirk Q6) and a record without MD inherits the
+    rebuilt text: same arrays whether the stale record's chunk saw an MD before it (threaded path) or a
+    chunk starts with it (falls back to the serial path)."""
+    rng = np.random.default_rng(5)
+    contig = synth.make_contig(rng, 5000)
+    recs = synth.make_reads(rng, contig, 300, 60, sub_rate=0.02, indel_frac=0.1)
+    out = []
+    for i, r in enumerate(recs):
+        seq = bytearray(r["seq"]); cigar = r["cigar"]; md = r["md"]
+        if i % 7 == 3 and cigar == "60M":
+            s0 = r["pos"] - 1                                  # clip + 56 aligned bases; the packer rebuilds MD for these
+            seq = bytearray(b"TTTT" + contig[s0:s0 + 56].tobytes()); seq[30] = ord("A") if seq[30] != ord("A") else ord("C")
+            cigar = "4S56M"; md = "26%s29" % chr(contig[s0 + 26])
+        tags = b"NM:i:0" if i % 11 == 5 else ("MD:Z:%s\tNM:i:%d" % (md, r["nm"])).encode()
+        out.append(b"r%d\t%d\tc\t%d\t60\t%s\t*\t0\t0\t%s\t%s\t%s\n" % (i, r["flag"], r["pos"], cigar.encode(), bytes(seq), b"I" * 60, tags))
+    fa = synth.fasta_text([("c", contig)])
+    sam = b"".join(out)
+    a = host.pack_sam(sam, fa, threads=1)
+    for th in (2, 5, 16):
+        assert _packed_arrays(host.pack_sam(sam, fa, threads=th)) == _packed_arrays(a)
+
+
+def test_threaded_packer_reports_the_same_input_errors(built):
+    seq = "A" * 40
+    good = lambda i, pos, name="c": ["r%d" % i, 0, name, pos, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"]
+    rows = [good(i, 1 + i) for i in range(200)]
+    fa_seq = "A" * 600
+    cases = []
+    bad = [list(r) for r in rows]; bad[150][3] = 3;                   cases.append((bad, "not sorted"))
+    bad = [list(r) for r in rows]; bad[120][5] = "*";                 cases.append((bad, "CIGAR '*'"))
+    bad = [list(r) for r in rows]; bad[199][2] = "d";                 cases.append((bad, "FASTA has fewer"))
+    bad = [list(r) for r in rows]; bad[77] = bad[77][:9];             cases.append((bad, "fewer than 11"))
+    bad = [list(r) for r in rows]; bad[60][11] = "MD:Z:10C40";        cases.append((bad, "inconsistent"))
+    for table, msg in cases:
+        sam, fa = _one(table, fa_seq=fa_seq)
+        for th in (1, 4):
+            with pytest.raises(host.CbcInputError, match=re.escape(msg)):
+                host.pack_sam(sam, fa, threads=th)
+
+
+def test_threaded_packer_tiny_inputs(built):
+    """More threads than lines, a body of one record, an empty body."""
+    seq = "A" * 40
+    row = ["r0", 0, "c", 1, 60, "40M", "*", 0, 0, seq, "I" * 40, "MD:Z:40"]
+    sam, fa = _one([row, row])
+    assert _packed_arrays(host.pack_sam(sam, fa, threads=8)) == _packed_arrays(host.pack_sam(sam, fa, threads=1))
+    sam1, _ = _one([row])
+    for s in (sam1, b"@HD\tVN:1.6\n"):
+        res = []
+        for th in (1, 8):
+            try:
+                res.append(_packed_arrays(host.pack_sam(s, fa, threads=th)))
+            except host.CbcInputError as e:
+                res.append(str(e))
+        assert res[0] == res[1]
