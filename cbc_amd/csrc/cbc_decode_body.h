@@ -411,6 +411,7 @@ struct CbcDec {
         V32 e0 = W::splat(0u), e1 = W::splat(0u), e2 = W::splat(0u), e3 = W::splat(0u);
         uint32_t m = 0;
         if (bw & bbit) {
+            W::list_fence();
             const uint32_t nb = W::uni(nev);
             for (uint32_t b = 0; b < nb; b += 64u) {
                 V32 i = ln + b; Mask mm = i < nev;

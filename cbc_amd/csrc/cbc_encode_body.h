@@ -15,7 +15,8 @@
  *   - POS-delta alphabet search: 64 candidates per compare + ballot       (read_compression.c:130)
  *   - var-context statistics: ballot + popcount over the block's var events
  *   - snpInRef window: a 256-bit sliding bitmap, first-set search         (read_compression.c:703-718)
- *   - output: 64 big-endian words staged in a VGPR, one coalesced 256-byte store per 2048 bits
+ *   - output: the bits of a batch of steps are placed in an LDS word ring by a prefix sum of their
+ *     lengths, one coalesced 256-byte store per 2048 bits
  *
  * Model tables are kept SPARSE and exact (SURVEY.md section 7 hard part 2): every symbol of the
  * big models starts at count 1 and rescaling maps 1 -> (1>>1)+1 = 1, so with e[s] = count[s]-1:
@@ -62,8 +63,14 @@
 #define CBC_BATCH_MIN   40u    /* <= 64 - 12 (a record's fixed symbols) - 4 (edit counts) - slack: see the 56 checks */
 #endif
 #define CBC_BATCH_WORDS 196u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record} */
-#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS)
-/* then pos_val[cap_pos], pos_cnt[cap_pos]; the var-event list lives in global memory (see var_code) */
+#define CBC_RING_WORDS  256u                       /* output bit ring of the coder wave (power of two) */
+#define CBC_LDS_RING    (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS)
+#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS + CBC_RING_WORDS)
+/* then pos_val[cap_pos], pos_occ[cap_pos], pos_pre[cap_pos]; the var-event list lives in global memory (see var_code) */
+
+#ifdef CBC_EMU_TRACE
+extern "C" void cbc_emu_trace(uint32_t read, uint32_t lo, uint32_t cnt, uint32_t n);
+#endif
 
 struct cbc_enc_args {
     const cbc_read_rec   *recs;
@@ -83,9 +90,15 @@ struct cbc_enc_args {
 #if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
 #define CBC_T0() do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); E.t_last = t_; } while (0)
 #define CBC_TS(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); E.t_sum[k] += t_ - E.t_last; E.t_last = t_; } while (0)
+#define CBC_TSM(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); t_sum[k] += t_ - t_last; t_last = t_; } while (0)
+#elif defined(CBC_MARKS) && defined(__HIP_DEVICE_COMPILE__)   /* diagnostic: section markers in the ISA listing */
+#define CBC_TSM(k) do {} while (0)
+#define CBC_T0() asm volatile("; ==== CBC_MARK start")
+#define CBC_TS(k) asm volatile("; ==== CBC_MARK " #k)
 #else
 #define CBC_T0() do {} while (0)
 #define CBC_TS(k) do {} while (0)
+#define CBC_TSM(k) do {} while (0)
 #endif
 
 template <class W>
@@ -95,8 +108,9 @@ struct CbcEnc {
 
     /* ---- range coder + bit writer (Arithmetic_stream.c:155-194, 274-371) ---- */
     uint32_t l, u, scale3;
-    uint64_t acc; uint32_t nacc;
-    V32 stage; uint32_t nwords; uint32_t *out32; uint32_t cap_words;
+    uint32_t bitpos, flushed;               /* bits produced; words already stored (multiple of 64)  */
+    uint32_t *ring;                         /* CBC_RING_WORDS of LDS, zero except for the pending bits */
+    uint32_t *out32; uint32_t cap_words;
     uint32_t status, nsym, fail_read, cur_read;
     V32 q_lo, q_cnt, q_n; uint32_t q_len;   /* pending symbols: lane k = k-th queued (lo, cnt, n)      */
     uint32_t role, batch_i; uint32_t *batch;  /* CBC_ROLE_*; hand-off buffers between the two waves     */
@@ -106,47 +120,95 @@ struct CbcEnc {
 
     /* ---- models ---- */
     V32 small;                              /* match / same_ref / chars lane table            */
-    V32 fkey, fexc; uint32_t fcount, fn;    /* flag: sparse, one entry per lane                */
+    V32 fkey, fexc; uint32_t fcount;        /* flag: sparse, one entry per lane                */
     V32 hkey, hexc; uint32_t hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;   /* codebook ctx 0..3: sparse, 8 lanes each */
-    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_cnt, *var_ev, *bloom;
-    uint32_t rlen_n, rlen_memo_x, rlen_memo_lo, rlen_memo_cnt;
-    uint32_t rl123_c0, rl123_n;             /* rlength[1..3]: only symbol 0 is ever coded (Q1)  */
+    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_occ, *pos_pre, *var_ev, *bloom;
     uint32_t snps_n, indels_n;
     uint32_t rn_count;
-    V32 pval, pcnt;                          /* pos alphabet entries 0..63 (value, count)        */
-    uint32_t pos_card, pos_n, cap_pos;
+    uint32_t pos_card, cap_pos;              /* pos alphabet: value / occurrences / prefix by index, in LDS */
     uint32_t nev, cap_var;
     uint32_t vtag0, vtag1, vsum0, vsum1;     /* hot var contexts: tag (context) and total excess  */
     uint32_t L0;
 
     /* ---- cross-read state (T7/T8 of SURVEY.md) ---- */
-    uint32_t prevPos, prevM, prevChar;
+    uint32_t prevPos, prevM, prevChar, win_pos;
     uint64_t w0, w1, w2, w3;                /* snpInRef[cumsumP-1 .. +255] as a 256-bit bitmap   */
 
     /* ======================================================================================= */
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
 
-    CBC_MFN void emit_word(uint32_t w)
+    /* ---- bit writer (stream_write_bits / stream_write_bit, io_functions.c; MSB first).  The stream is
+     * assembled in a ring of LDS words: a piece of <= 32 bits at bit offset `off` is OR-ed into one or two
+     * words, so the pieces of all symbols of a batch are placed at once, one lane each, at offsets from
+     * a prefix sum of their lengths.  Complete runs of 64 words leave as one coalesced 256-byte store. ---- */
+    CBC_MFN void place(const V32 &val, const V32 &len, const V32 &off, const Mask &m)
     {
-        V32 ln = W::lane();
-        stage = W::select(ln == (nwords & 63u), W::splat(W::bswap32(w)), stage);
-        nwords++;
-        if ((nwords & 63u) == 0u) {
-            if (nwords <= cap_words) W::store32(out32, ln + (nwords - 64u), stage, W::all());
+        const V32 aligned = val << (W::splat(32u) - len);             /* len 1..32: shift 31..0 */
+        const V32 sh = off & 31u, w = (off >> 5) & (CBC_RING_WORDS - 1u);
+        const Mask on = m & (len != 0u);
+        W::lds_or(ring, w, aligned >> sh, on);
+        W::lds_or(ring, (w + 1u) & (CBC_RING_WORDS - 1u), aligned << (W::splat(32u) - sh), on & (sh != 0u));
+    }
+    CBC_MFN void flush_full()
+    {
+        const V32 ln = W::lane();
+        while ((bitpos >> 5) - flushed >= 64u) {
+            const V32 idx = (ln + flushed) & (CBC_RING_WORDS - 1u);
+            const V32 wv = W::load32(ring, idx, W::all(), 0u);
+            if (flushed + 64u <= cap_words) W::store32(out32, ln + flushed, W::bswap_v(wv), W::all());
             else fail(CBC_ST_OUT_FULL);
+            W::store32(ring, idx, W::splat(0u), W::all());
+            flushed += 64u;
         }
     }
-    CBC_MFN void put(uint32_t v, uint32_t n)          /* n <= 32 bits, MSB first */
+    CBC_MFN void put(uint32_t v, uint32_t n)          /* n <= 32 bits, one piece, lane 0 places it */
     {
         if (n == 0) return;
-        acc = (acc << n) | (uint64_t)v; nacc += n;
-        if (nacc >= 32u) { nacc -= 32u; emit_word((uint32_t)(acc >> nacc)); }
+        place(W::splat(v), W::splat(n), W::splat(bitpos), W::lane() == 0u);
+        bitpos += n;
+        flush_full();
     }
     CBC_MFN void put_run(uint32_t bit, uint32_t n)    /* n copies of bit */
     {
         uint32_t pat = bit ? 0xffffffffu : 0u;
         while (n >= 32u) { put(pat, 32u); n -= 32u; }
         if (n) put(pat >> (32u - n), n);
+    }
+    /* the output of up to 64 coder steps: lane k holds step k's E1/E2 bits (k1 | bits << 5) and the E3
+     * count that was pending when they were shifted out (Arithmetic_stream.c:296-341: the first bit,
+     * then that many inverted copies, then the other k1 - 1 bits) */
+    CBC_MFN void pack(const V32 &rec_a, const V32 &rec_s, uint32_t m)
+    {
+        const V32 ln = W::lane();
+        const V32 k1 = rec_a & 31u, bits = rec_a >> 5;
+        const Mask act = (ln < m) & (k1 != 0u);
+        const V32 len = W::select(act, k1 + rec_s, W::splat(0u));
+#ifndef CBC_PACK_SERIAL_AT
+#define CBC_PACK_SERIAL_AT 32u                           /* tests lower it to exercise the piece-by-piece path */
+#endif
+        if (W::ballot(act & (len > CBC_PACK_SERIAL_AT))) {    /* a long E3 run: piece by piece */
+            for (uint32_t k = 0; k < m; k++) {
+                const uint32_t a = W::readlane(rec_a, k), sc = W::readlane(rec_s, k);
+                const uint32_t kk = a & 31u, bb = a >> 5;
+                if (kk == 0u) continue;
+                if (sc == 0u) put(bb, kk);
+                else {
+                    const uint32_t b0 = bb >> (kk - 1u);
+                    put(b0, 1u); put_run(b0 ^ 1u, sc);
+                    put(bb & ((1u << (kk - 1u)) - 1u), kk - 1u);
+                }
+            }
+            return;
+        }
+        const V32 incl = W::scan_incl_add(len);
+        const V32 km1 = (k1 - 1u) & 31u;                      /* inactive lanes: any in-range shift */
+        const V32 b0 = bits >> km1;
+        const V32 rest = bits & ((W::splat(1u) << km1) - 1u);
+        const V32 run = W::select(b0 != 0u, W::splat(0u), (W::splat(1u) << rec_s) - 1u);
+        const V32 val = (b0 << ((rec_s + km1) & 31u)) | (run << km1) | rest;
+        place(val, len, incl - len + bitpos, act);
+        bitpos += W::readlane(incl, 63u);
+        flush_full();
     }
 
     /* arithmetic_encoder_step, Arithmetic_stream.c:274-345, with the E1/E2 and E3 loops in
@@ -160,6 +222,9 @@ struct CbcEnc {
      * the model code. */
     CBC_MFN void encode(uint32_t lo, uint32_t cnt, uint32_t n)
     {
+#ifdef CBC_EMU_TRACE                     /* tests/emu debugging aid: log every symbol as the models emit it */
+        cbc_emu_trace(cur_read, lo, cnt, n);
+#endif
         V32 ln = W::lane();
         Mask here = ln == q_len;
         q_lo = W::select(here, W::splat(lo), q_lo);
@@ -193,11 +258,21 @@ struct CbcEnc {
         /* assert(cumCountX_1 < cumCountX) of every pending symbol at once (stream_model.c:71) */
         const uint64_t bad = W::ballot((ln < m) & ((q_cnt == 0u) | (q_n == 0u)));
         if (bad) m = W::ctz64(bad);
-        const V32 inv_v = W::recip_v(q_n);
+        /* the two divisions of a step, floor(range * c / n) for c = cum and c = cum + count, without a
+         * divide on the serial path: f = floor(c * 2^32 / n) is computed here for all pending symbols
+         * at once (one lane each), and code1() finishes with one multiply-high and a remainder test */
+        const V32 q_hi = q_lo + q_cnt;
+        const V32 f_lo = W::frac32(q_lo, q_n), f_hi = W::frac32(q_hi, q_n);
+        V32 rec_a = W::splat(0u), rec_s = W::splat(0u);
         for (uint32_t k = 0; k < m; k++) {
-            code1(W::readlane(q_lo, k), W::readlane(q_cnt, k), W::readlane(q_n, k), W::lane_float(inv_v, k));
-            if (status != CBC_ST_OK) break;
+            uint32_t k1, bits, sc;
+            code1(W::readlane(q_lo, k), W::readlane(q_hi, k), W::readlane(q_n, k), W::readlane(f_lo, k), W::readlane(f_hi, k),
+                  k1, bits, sc);
+            W::set_lane(rec_a, k, k1 | (bits << 5));
+            W::set_lane(rec_s, k, sc);
         }
+        nsym += m;
+        pack(rec_a, rec_s, m);
         if (bad) fail(CBC_ST_ASSERT);
         q_len = 0;
     }
@@ -206,7 +281,9 @@ struct CbcEnc {
     {
         V32 ln = W::lane();
         for (;;) {
+            CBC_TSM(9);                                       /* coder wave: coding */
             W::barrier();
+            CBC_TSM(10);                                      /* coder wave: waiting for a batch */
             const uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
             V32 hdr = W::load32(buf + 192u, ln, ln < 4u, 0u);
             const uint32_t len = W::readlane(hdr, 0u), flags = W::readlane(hdr, 1u);
@@ -221,29 +298,39 @@ struct CbcEnc {
             if (flags & 1u) break;
         }
     }
-    CBC_MFN void code1(uint32_t lo, uint32_t cnt, uint32_t n, float inv)
+    /* floor(range * c / n) given f = floor(c * 2^32 / n) (clamped to 2^32 - 1 when c == n):
+     * range <= 2^26, so range * f / 2^32 is below the true quotient by less than 2^-6 + 1: the
+     * multiply-high is the quotient or one less, and the remainder (< 2n < 2^22, so its low 32 bits are
+     * all of it) says which. */
+    static CBC_MFN uint32_t scaled_div(uint32_t range, uint32_t c, uint32_t n, uint32_t f)
     {
-        nsym++;
+        uint32_t q = (uint32_t)(((uint64_t)range * f) >> 32);
+        uint32_t r = range * c - q * n;
+        return q + (r >= n ? 1u : 0u);
+    }
+    /* one coder step without its output: the range update and the closed-form E1/E2 and E3 shifts.
+     * k1 bits (`bits`, MSB first) leave through E1/E2; `sc` is the E3 count pending at that moment. */
+    CBC_MFN void code1(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi,
+                       uint32_t &k1, uint32_t &bits, uint32_t &sc)
+    {
 #ifdef CBC_ABLATE_CODER          /* timing experiments only: keeps the operands live, skips the coder */
-        l ^= lo; u ^= cnt + n; return;
+        l ^= lo; u ^= hi + n; k1 = 0; bits = 0; sc = 0; return;
 #endif
 #ifdef __HIP_DEVICE_COMPILE__
-        asm volatile("" : "+s"(l), "+s"(u), "+s"(scale3), "+s"(nacc), "+s"(nwords));
+        asm volatile("" : "+s"(l), "+s"(u), "+s"(scale3));
 #endif
-        uint32_t range = u - l + 1u, qh, ql;
-        W::muldiv2(range, lo, lo + cnt, n, inv, ql, qh);
+        const uint32_t range = u - l + 1u;
+        const uint32_t ql = scaled_div(range, lo, n, flo), qh = scaled_div(range, hi, n, fhi);
+        W::expect_eq(ql, (uint32_t)((uint64_t)range * lo / n), "scaled_div(cum)");
+        W::expect_eq(qh, (uint32_t)((uint64_t)range * hi / n), "scaled_div(cum + count)");
         u = l + qh - 1u;
         l = l + ql;
         uint32_t x = l ^ u;
-        uint32_t k1 = x ? (W::clz32(x) - 6u) : 26u;
+        k1 = x ? (W::clz32(x) - 6u) : 26u;
+        bits = 0; sc = 0;
         if (k1) {
-            uint32_t bits = l >> (26u - k1);
-            if (scale3 == 0u) put(bits, k1);
-            else {
-                uint32_t b0 = bits >> (k1 - 1u);
-                put(b0, 1u); put_run(b0 ^ 1u, scale3); scale3 = 0u;
-                put(bits & ((1u << (k1 - 1u)) - 1u), k1 - 1u);
-            }
+            bits = l >> (26u - k1);
+            sc = scale3; scale3 = 0u;
             l = (uint32_t)(((uint64_t)l << k1) & CBC_M26);
             u = (uint32_t)((((uint64_t)u << k1) & CBC_M26) | ((1ull << k1) - 1ull));
         }
@@ -260,16 +347,15 @@ struct CbcEnc {
         uint32_t msb = l >> 25;
         put(msb, 1u); put_run(msb ^ 1u, scale3); scale3 = 0u;
         put(l & CBC_M25, 25u);
-        uint32_t total_bits = nwords * 32u + nacc;
-        uint32_t nbytes = (total_bits >> 3) + 1u;            /* +1: partial byte, or the extra 0x00 */
-        emit_word(nacc ? (uint32_t)(acc << (32u - nacc)) : 0u);
-        nacc = 0;
-        uint32_t rem = nwords & 63u;
-        if (rem) {
-            uint32_t base = nwords - rem;
-            V32 ln = W::lane();
-            if (nwords <= cap_words) W::store32(out32, ln + base, stage, ln < rem);
-            else fail(CBC_ST_OUT_FULL);
+        const uint32_t nbytes = (bitpos >> 3) + 1u;          /* +1: the partial byte, or the extra 0x00 */
+        const uint32_t nw = (nbytes + 3u) >> 2;              /* the ring is zero past the last bit */
+        const V32 ln = W::lane();
+        if (nw > cap_words) { fail(CBC_ST_OUT_FULL); return nbytes; }
+        while (flushed < nw) {
+            const V32 idx = (ln + flushed) & (CBC_RING_WORDS - 1u);
+            const V32 wv = W::load32(ring, idx, W::all(), 0u);
+            W::store32(out32, ln + flushed, W::bswap_v(wv), (ln + flushed) < nw);
+            flushed += 64u;
         }
         return nbytes;
     }
@@ -390,101 +476,213 @@ struct CbcEnc {
         }
     }
 
-    /* ---- pos (read_compression.c:113-159): dynamic alphabet, literal counts.
-     * Entries 0..63 (the escape symbol and the first 63 deltas to appear -- at usual coverage these
-     * are the frequent ones) live in two VGPRs, lane = alphabet index; later entries in LDS at their
-     * absolute index.  A hit in the first tier costs one compare + ballot and a masked wave sum, no
-     * LDS round trip. ---- */
-    CBC_MFN void pos_rescale()                           /* stream_model.c:41-48, literal counts */
+    /* ---- pos alphabet bytes: compress_pos_alpha (read_compression.c:75-108).  The four 256-symbol
+     * models only ever see the bytes of the values already registered in the alphabet, so their state
+     * is recomputed from it: count(b) = 1 + 10 * #{registered v : byte_k(v) == b}.  `card` is the
+     * alphabet size when the escape was coded (entries 1 .. card-1 are registered). ---- */
+    CBC_MFN void pos_alpha(uint32_t x, uint32_t card)
     {
         V32 ln = W::lane();
-        Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
-        pcnt = W::select(m0, (pcnt >> 1) + 1u, pcnt);
-        V32 a = W::select(m0, pcnt, W::splat(0u));
-        const uint32_t pc = W::uni(pos_card);
-        for (uint32_t b = 64u; b < pc; b += 64u) {
-            V32 i = ln + b; Mask m = i < pos_card;
-            V32 c = (W::load32(pos_cnt, i, m, 0u) >> 1) + 1u;
-            W::store32(pos_cnt, i, c, m);
-            a = a + W::select(m, c, W::splat(0u));
-        }
-        pos_n = W::reduce_add(a);
-    }
-    CBC_MFN void pos_update(uint32_t idx)
-    {
-        if (idx < 64u) pcnt = W::select(W::lane() == idx, pcnt + 10u, pcnt);
-        else W::write_uni(pos_cnt, idx, W::read_uni(pos_cnt, idx) + 10u);
-        pos_n += 10u;
-        if (pos_n >= CBC_RESCALE) pos_rescale();
-    }
-    /* one byte of compress_pos_alpha (:75-108).  The four 256-symbol models only ever see the
-     * bytes of the values already registered in the alphabet, so their state is recomputed from
-     * it: count(b) = 1 + 10 * #{registered v : byte_k(v) == b}. */
-    CBC_MFN void pos_alpha_byte(uint32_t shift, uint32_t byte)
-    {
-        V32 ln = W::lane();
-        Mask m0 = (ln != 0u) & (ln < (pos_card < 64u ? pos_card : 64u));
-        V32 v0 = (pval >> shift) & 0xffu;
-        uint32_t lt = W::popc64(W::ballot(m0 & (v0 < byte))), eq = W::popc64(W::ballot(m0 & (v0 == byte)));
-        const uint32_t pc = W::uni(pos_card);
-        for (uint32_t b = 64u; b < pc; b += 64u) {
-            V32 i = ln + b; Mask m = i < pos_card;
-            V32 v = (W::load32(pos_val, i, m, 0u) >> shift) & 0xffu;
-            lt += W::popc64(W::ballot(m & (v < byte)));
-            eq += W::popc64(W::ballot(m & (v == byte)));
-        }
-        uint32_t n = 256u + 10u * (pos_card - 1u);
-        if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return; }
-        encode(byte + 10u * lt, 1u + 10u * eq, n);
-    }
-    CBC_MFN void pos_code(uint32_t x)
-    {
-        V32 ln = W::lane();
-        Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
-        uint64_t eq0 = W::ballot(m0 & (ln != 0u) & (pval == x));
-        if (eq0) {                                            /* hit in the register tier */
-            uint32_t fl = W::ctz64(eq0);
-            uint32_t lo = W::reduce_add(W::select(ln < fl, pcnt, W::splat(0u)));
-            encode(lo, W::readlane(pcnt, fl), pos_n);
-            pos_update(fl);
-            return;
-        }
-        V32 a = W::select(m0, pcnt, W::splat(0u));
-        uint32_t found = 0;
-        const uint32_t pc = W::uni(pos_card);
-        for (uint32_t b = 64u; b < pc && !found; b += 64u) {
-            V32 i = ln + b; Mask m = i < pos_card;
+        uint32_t lt3 = 0, eq3 = 0, lt2 = 0, eq2 = 0, lt1 = 0, eq1 = 0, lt0 = 0, eq0 = 0;
+        const uint32_t b3 = x >> 24, b2 = (x >> 16) & 0xffu, b1 = (x >> 8) & 0xffu, b0 = x & 0xffu;
+        const uint32_t pc = W::uni(card);
+        for (uint32_t b = 0; b < pc; b += 64u) {
+            V32 i = ln + b; Mask m = (i != 0u) & (i < card);
             V32 v = W::load32(pos_val, i, m, 0u);
-            V32 c = W::load32(pos_cnt, i, m, 0u);
-            uint64_t eq = W::ballot(m & (v == x));
-            if (eq) {
-                uint32_t fl = W::ctz64(eq);
-                found = b + fl;
-                a = a + W::select(ln < fl, c, W::splat(0u));
-            } else a = a + c;
+            V32 v3 = v >> 24, v2 = (v >> 16) & 0xffu, v1 = (v >> 8) & 0xffu, v0 = v & 0xffu;
+            lt3 += W::popc64(W::ballot(m & (v3 < b3))); eq3 += W::popc64(W::ballot(m & (v3 == b3)));
+            lt2 += W::popc64(W::ballot(m & (v2 < b2))); eq2 += W::popc64(W::ballot(m & (v2 == b2)));
+            lt1 += W::popc64(W::ballot(m & (v1 < b1))); eq1 += W::popc64(W::ballot(m & (v1 == b1)));
+            lt0 += W::popc64(W::ballot(m & (v0 < b0))); eq0 += W::popc64(W::ballot(m & (v0 == b0)));
         }
-        if (found) {
-            uint32_t lo = W::reduce_add(a);
-            encode(lo, W::read_uni(pos_cnt, found), pos_n);
-            pos_update(found);
-        } else {
-            encode(0u, W::readlane(pcnt, 0u), pos_n);          /* escape symbol 0 */
-            pos_update(0u);
-            pos_alpha_byte(24u, x >> 24);
-            pos_alpha_byte(16u, (x >> 16) & 0xffu);
-            pos_alpha_byte(8u, (x >> 8) & 0xffu);
-            pos_alpha_byte(0u, x & 0xffu);
-            if (pos_card >= cap_pos) { fail(CBC_ST_CAP_POS); return; }
-            if (pos_card < 64u) {
-                pval = W::select(ln == pos_card, W::splat(x), pval);
-                pcnt = W::select(ln == pos_card, W::splat(0u), pcnt);
-            } else {
-                W::write_uni(pos_val, pos_card, x);
-                W::write_uni(pos_cnt, pos_card, 0u);
+        const uint32_t n = 256u + 10u * (card - 1u);
+        if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return; }
+        encode(b3 + 10u * lt3, 1u + 10u * eq3, n);
+        encode(b2 + 10u * lt2, 1u + 10u * eq2, n);
+        encode(b1 + 10u * lt1, 1u + 10u * eq1, n);
+        encode(b0 + 10u * lt0, 1u + 10u * eq0, n);
+    }
+
+    /* ---- the fixed symbols of 64 records at once, one lane per record ------------------------------
+     * A block never holds more than CBC_MAX_BLOCK_READS records, so none of the per-record models
+     * (rlength, pos, flag, match, same_ref) reaches its 2^20 rescale point inside a block and each
+     * is a pure COUNTING model: with occ(s) = how often s was coded before this record,
+     *     count(s) = init(s) + step * occ(s),  cum(s) = sum over s' < s,  n = n0 + step * records.
+     * "Before this record" splits into the carried tables (records of earlier groups) and the lower
+     * lanes of this group, which ballots / v_mbcnt count without any serial step.  What stays
+     * serial: one iteration per DISTINCT rlength / FLAG value and per NEW pos delta in the group.
+     *   rlength[0]  compress_rlength  read_compression.c:29-33   (quirk Q1: low byte only)
+     *   pos         compress_pos      read_compression.c:113-159 (alphabet in order of appearance)
+     *   flag        compress_flag     read_compression.c:50-70
+     *   match       compress_match    read_compression.c:204-228 (context: dx == 1, previous match)
+     * Results: per-lane (cum, count[, n]); `st` = the status the serial code would have stopped with
+     * at that record (CBC_ST_OK if none), `esc` = records whose pos delta is new (escape + 4 bytes). */
+    struct Fixed {
+        V32 rl_lo, rl_cnt, p_lo, p_cnt, p_card, fl_lo, fl_cnt, m_lo, m_cnt, m_n, st;
+        uint64_t esc, bad;
+    };
+    CBC_MFN void fixed_group(Fixed &F, uint32_t c0, uint32_t cn, const V32 &r_pos, const V32 &r_fl, uint64_t neq)
+    {
+        const V32 ln = W::lane();
+        const Mask live = ln < cn;
+        const V32 zero = W::splat(0u);
+        V32 st = W::splat((uint32_t)CBC_ST_OK);
+
+        /* -- pos delta: dx = pos - prevPos + 1, 1 <= dx < MAX_ALPHA (sam_block.h:54) -- */
+        const V32 prevp = W::shift_up1(r_pos, prevPos);
+        const V32 dxv = r_pos - prevp + 1u;
+        const Mask dxbad = live & ((((r_pos - prevp) >> 31) != 0u) | (dxv >= 5000000u));
+        prevPos = W::readlane(r_pos, cn - 1u);
+
+        /* -- flag (value-ordered sparse table, one entry per lane of fkey/fexc; step 8) -- */
+        const V32 flagv = r_fl & 0xffffu;
+        V32 fl_base = zero, fl_extra = zero, fl_cnt = zero;
+        Mask capflag = W::lane_bit(0ull);
+        V32 fexc_new = fexc;                                 /* lookups see the table as it was before the group */
+        {
+            uint64_t rem = W::ballot(live);
+            while (rem) {
+                const uint32_t v = W::readlane(flagv, W::ctz64(rem));
+                const Mask mv = live & (flagv == v);
+                const uint64_t m = W::ballot(mv);
+                rem &= ~m;
+                const Mask tl = ln < fcount;
+                const uint32_t lo0 = v + W::reduce_add(W::select(tl & (fkey < v), fexc, zero));
+                const uint64_t eq = W::ballot(tl & (fkey == v));
+                uint32_t idx, e0 = 0;
+                if (eq) { idx = W::ctz64(eq); e0 = W::readlane(fexc, idx); }
+                else {
+                    if (fcount >= CBC_CAP_FLAG) { capflag = capflag | mv; continue; }
+                    idx = fcount++;
+                    fkey = W::select(ln == idx, W::splat(v), fkey);
+                }
+                const V32 before = W::prefix_popc(m) * 8u;
+                fl_cnt = W::select(mv, before + (1u + e0), fl_cnt);
+                fl_base = W::select(mv, W::splat(lo0), fl_base);
+                fl_extra = fl_extra + W::select(live & (flagv > v), before, zero);
+                fexc_new = W::select(ln == idx, W::splat(e0 + 8u * W::popc64(m)), fexc_new);
             }
-            pos_card++;                                        /* update_model(P, alphabetCard++) :153 */
-            pos_update(pos_card - 1u);
         }
+        fexc = fexc_new;
+        F.fl_lo = fl_base + fl_extra; F.fl_cnt = fl_cnt;
+
+        /* -- rlength[0] (dense excess table in LDS; step 10) -- */
+        const V32 xv = (r_fl >> 16) & 0xffu;
+        const Mask rlbad = live & (xv >= 255u);            /* assert(x < alphabetCard) stream_model.c:62 */
+        V32 rl_base = zero, rl_extra = zero, rl_cnt = zero, rl_new = zero;
+        {
+            uint64_t rem = W::ballot(live & (xv < 255u));
+            while (rem) {
+                const uint32_t v = W::readlane(xv, W::ctz64(rem));
+                const Mask mv = live & (xv == v);
+                const uint64_t m = W::ballot(mv);
+                rem &= ~m;
+                uint32_t lo0, cnt0;
+                dense_lookup(rlen_exc, v, lo0, cnt0);
+                const V32 before = W::prefix_popc(m) * 10u;
+                rl_cnt = W::select(mv, before + cnt0, rl_cnt);
+                rl_base = W::select(mv, W::splat(lo0), rl_base);
+                rl_extra = rl_extra + W::select(live & (xv > v), before, zero);
+                rl_new = W::select(mv, W::splat(cnt0 - 1u + 10u * W::popc64(m)), rl_new);
+            }
+            /* the table is written after all lookups (they must see it as it was before the group);
+             * lanes with the same value store the same word */
+            W::store32(rlen_exc, xv, rl_new, live & (xv < 255u));
+        }
+        F.rl_lo = rl_base + rl_extra; F.rl_cnt = rl_cnt;
+
+        /* -- match: context = (dx == 1) * 2 + previous record's match; literal counts, step 1 -- */
+        {
+            const uint64_t mt = ~neq;
+            const Mask sym = W::lane_bit(mt), pm = W::lane_bit((mt << 1) | (uint64_t)(prevM & 1u));
+            const V32 ctx = W::select(dxv == 1u, W::splat(2u), zero) + W::select(pm, W::splat(1u), zero);
+            V32 m_lo = zero, m_cnt = zero, m_n = zero;
+            for (uint32_t c = 0; c < 4u; c++) {
+                const Mask inc = live & (ctx == c);
+                const uint64_t m0 = W::ballot(inc & !sym), m1 = W::ballot(inc & sym);
+                const uint32_t k0 = W::readlane(small, CBC_LT_MATCH + 2u * c), k1 = W::readlane(small, CBC_LT_MATCH + 2u * c + 1u);
+                const V32 b0 = W::prefix_popc(m0) + k0, b1 = W::prefix_popc(m1) + k1;
+                m_lo = W::select(inc, W::select(sym, b0, zero), m_lo);
+                m_cnt = W::select(inc, W::select(sym, b1, b0), m_cnt);
+                m_n = W::select(inc, b0 + b1, m_n);
+                small = W::select(ln == CBC_LT_MATCH + 2u * c, small + W::popc64(m0),
+                        W::select(ln == CBC_LT_MATCH + 2u * c + 1u, small + W::popc64(m1), small));
+            }
+            F.m_lo = m_lo; F.m_cnt = m_cnt; F.m_n = m_n;
+            prevM = (uint32_t)((mt >> (cn - 1u)) & 1ull);
+        }
+
+        /* -- pos: alphabet index of every delta (entry 0 = escape; pos_val[0] never matches) -- */
+        const uint32_t card0 = pos_card;
+        V32 kv = zero;
+        {
+            const uint32_t cb = W::uni(card0);
+            for (uint32_t b = 0; b < cb; b += 64u) {
+                const V32 av = W::load32(pos_val, ln + b, (ln + b) < card0, 0xffffffffu);
+                const uint32_t lim = card0 - b < 64u ? card0 - b : 64u;
+                for (uint32_t a = 0; a < lim; a++) kv = W::select(dxv == W::readlane(av, a), W::splat(b + a), kv);
+                if (W::ballot(live & (kv == 0u)) == 0ull) break;
+            }
+        }
+        /* deltas not in the alphabet yet: the first record with each becomes an escape and registers it */
+        Mask cappos = W::lane_bit(0ull);
+        uint64_t esc = 0;
+        {
+            uint64_t nf = W::ballot(live & !dxbad & (kv == 0u));
+            uint32_t t = 0;
+            while (nf) {
+                const uint32_t f = W::ctz64(nf);
+                const uint32_t v = W::readlane(dxv, f);
+                const Mask mv = live & (dxv == v);
+                nf &= ~W::ballot(mv);
+                if (card0 + t >= cap_pos) { cappos = cappos | mv; continue; }
+                kv = W::select(mv, W::splat(card0 + t), kv);
+                esc |= 1ull << f;
+                W::write_uni(pos_val, card0 + t, v);
+                t++;
+            }
+            pos_card = card0 + t;
+        }
+        /* occurrences of the same / of lower indices among the lower lanes */
+        V32 lt = zero, eqb = zero, eqa = zero;
+        for (uint32_t j = 0; j < cn; j++) {
+            const uint32_t kj = W::readlane(kv, j);
+            const Mask same = kv == kj;
+            eqa = eqa + W::select(same, W::splat(1u), zero);
+            eqb = eqb + W::select(same & (ln > j), W::splat(1u), zero);
+            lt = lt + W::select((kv > kj) & (ln > j), W::splat(1u), zero);
+        }
+        {
+            const Mask old = live & (kv != 0u) & (kv < card0);
+            const V32 occ0 = W::load32(pos_occ, kv, old, 0u);
+            const V32 pre0 = W::load32(pos_pre, kv, old, c0);          /* new entries: every earlier record lies below */
+            const V32 cardv = W::prefix_popc(esc) + card0;             /* alphabet size when this record is coded */
+            const V32 c_esc = (cardv - 1u) * 10u + 1u;                 /* count of the escape symbol then */
+            const Mask isesc = W::lane_bit(esc);
+            F.p_card = cardv;
+            F.p_lo = W::select(isesc, zero, c_esc + (pre0 + lt) * 10u);
+            F.p_cnt = W::select(isesc, c_esc, (occ0 + eqb) * 10u);
+            W::store32(pos_occ, kv, occ0 + eqa, live & (kv != 0u) & !dxbad);
+        }
+        {   /* prefix of the occurrence counts by alphabet index, for the next group */
+            uint32_t carry = 0;
+            const uint32_t cb = W::uni(pos_card);
+            for (uint32_t b = 0; b < cb; b += 64u) {
+                const V32 i = ln + b; const Mask m = (i != 0u) & (i < pos_card);
+                const V32 o = W::load32(pos_occ, i, m, 0u);
+                const V32 inc = W::scan_incl_add(o);
+                W::store32(pos_pre, i, inc - o + carry, i < pos_card);
+                carry += W::readlane(inc, 63u);
+            }
+        }
+
+        /* the status the record-by-record code stops with, in its order of checks */
+        st = W::select(capflag, W::splat((uint32_t)CBC_ST_CAP_FLAG), st);
+        st = W::select(cappos, W::splat((uint32_t)CBC_ST_CAP_POS), st);
+        st = W::select(dxbad, W::splat((uint32_t)CBC_ST_ASSERT), st);
+        st = W::select(rlbad, W::splat((uint32_t)CBC_ST_ASSERT), st);
+        F.st = st; F.esc = esc;
+        F.bad = W::ballot(live & (st != (uint32_t)CBC_ST_OK));
     }
 
     /* ---- var (read_compression.c:230-245): 65535 contexts x L0, kept as the list of events.
@@ -518,6 +716,7 @@ struct CbcEnc {
         const uint32_t h = (ctx * 0x9E3779B1u) >> 19;
         const uint32_t bw = W::read_uni(bloom, h >> 5), bbit = 1u << (h & 31u);
         if (bw & bbit) {
+            W::list_fence();
             const uint32_t nb = W::uni(nev);
             for (uint32_t b = 0; b < nb; b += 256u) {
                 V32 i0 = ln * 4u + b;
@@ -632,8 +831,10 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
 
     E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
-    E.l = 0; E.u = CBC_M26; E.scale3 = 0; E.acc = 0; E.nacc = 0; E.nwords = 0;
-    E.stage = W::splat(0u);
+    E.l = 0; E.u = CBC_M26; E.scale3 = 0; E.bitpos = 0; E.flushed = 0;
+    E.ring = lds + CBC_LDS_RING;
+    if (ROLE != CBC_ROLE_MODEL)
+        for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
     E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
     E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH;
     /* the block's out area: [0, payload_cap) payload, [payload_cap, out_cap) its var-event list */
@@ -650,10 +851,18 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
 
     if (ROLE == CBC_ROLE_CODER) {
         /* coder wavefront: nothing but the range coder, fed by the model wavefront's batches */
+#ifdef CBC_STAMP
+        for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
+        CBC_T0();
+#endif
         E.consume_all();
         uint32_t nb = 0;
         if (E.status == CBC_ST_OK) nb = E.finish();
         if (E.status != CBC_ST_OK) nb = 0;
+#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+        if (payload_cap >= 128u) for (int i = 0; i < 16; i++) {   /* diagnostic build: over the payload start */
+            W::write_uni(E.out32, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.out32, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
+#endif
         V32 rv = W::select(ln == 0u, W::splat(nb), W::select(ln == 1u, W::splat(E.status),
                  W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
         W::store32((uint32_t *)(A.results + blk), ln, rv, ln < 4u);
@@ -665,19 +874,17 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
     E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
     E.bloom = lds + CBC_LDS_BLOOM;
-    E.pos_val = lds + CBC_LDS_FIXED; E.pos_cnt = E.pos_val + A.cap_pos;
+    E.pos_val = lds + CBC_LDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = E.pos_occ + A.cap_pos;
     E.cap_pos = A.cap_pos;
     for (uint32_t b = 0; b < 768u; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
     for (uint32_t b = 0; b < 768u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* Bloom + 2 slots */
     E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
-    E.rlen_n = 255u; E.rlen_memo_x = CBC_NOMEMO; E.rlen_memo_lo = 0; E.rlen_memo_cnt = 0;
-    E.rl123_c0 = 1u; E.rl123_n = 255u;
     E.snps_n = L0; E.indels_n = L0;
     E.rn_count = 0;
-    E.pos_card = 1u; E.pos_n = 1u;                           /* initialize_stream_model_pos :132-162 */
-    E.pval = W::splat(0xffffffffu); E.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
+    E.pos_card = 1u;                                         /* initialize_stream_model_pos :132-162: the escape */
+    W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 0u); W::write_uni(E.pos_pre, 0u, 0u);
     E.nev = 0;
-    E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0; E.fn = 65536u;
+    E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
     E.hkey = W::splat(0u); E.hexc = W::splat(0u);
     E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
     {   /* lane table: match 1,1 (n=2); same_ref 1,1; chars rows (sam_models.c:372-401) */
@@ -693,7 +900,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         s = W::select(inch, cv, s);
         E.small = s;
     }
-    E.prevPos = 0; E.prevM = 0; E.prevChar = 0;
+    E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0;
     E.win_clear();
 
     /* ---- stream header: int(L0), 32 x int(WELL), int(LOSSLESS=8)  (sam_file_allocation.c:371,
@@ -720,10 +927,12 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
     CBC_T0();
 #endif
+    /* the closed forms of fixed_group() hold while no per-record model can reach its rescale point */
+    if (n_reads > CBC_MAX_BLOCK_READS) E.fail(CBC_ST_UNSUPPORTED);
     for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
         V32 r_pos, r_fl, r_seq, r_tok;
         W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
-        uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
+        const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
         {   /* validate the 64 records at once (one lane each) so the per-record loads below need no
              * clamping: read length 1..252, POS >= 1, bases and reference window inside the buffers */
             V32 vrl = r_fl >> 16;
@@ -734,37 +943,53 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             if (bb) { E.cur_read = c0 + W::ctz64(bb); E.fail(CBC_ST_ASSERT); break; }
         }
 
-        /* software prefetch of record j's bases, reference window and tokens one record ahead */
-        V32 nx_seq = W::splat(0u), nx_ref = W::splat(0u), nx_tok = W::splat(0u);
-        {
-            uint32_t pos = W::readlane(r_pos, 0u), fl = W::readlane(r_fl, 0u);
-            uint32_t so = W::readlane(r_seq, 0u), to = W::readlane(r_tok, 0u), rl = fl >> 16;
+        /* -- match test of every record of the group (read_compression.c:291-296): lane l compares
+         *    bases 4l..4l+3; the loads of 8 records are in flight together -- */
+        uint64_t neq = 0;
+        for (uint32_t j0 = 0; j0 < cn; j0 += 8u) {
+            V32 sv[8], rv[8]; uint32_t rls[8];
+            const V32 bo = ln * 4u;
+            for (uint32_t q = 0; q < 8u; q++) {                 /* lanes past cn hold zero records: nothing is loaded */
+                const uint32_t jj = (j0 + q) & 63u;
+                const uint32_t pos = W::readlane(r_pos, jj), so = W::readlane(r_seq, jj);
+                rls[q] = (j0 + q < cn) ? W::readlane(r_fl, jj) >> 16 : 0u;
+                sv[q] = W::load32_bytes(seqb + so, bo, bo < rls[q]);
+                rv[q] = W::load32_bytes(refb + (pos - 1u), bo, bo < rls[q]);
+            }
+            for (uint32_t q = 0; q < 8u; q++) {
+                const uint32_t rl = rls[q];
+                V32 bmask = W::select(bo + 4u <= rl, W::splat(0xffffffffu),
+                                      W::select(bo < rl, (W::splat(1u) << ((W::splat(rl) - bo) * 8u)) - 1u, W::splat(0u)));
+                if (W::ballot(((sv[q] ^ rv[q]) & bmask) != 0u)) neq |= 1ull << ((j0 + q) & 63u);
+            }
+        }
+        CBC_TS(0);                                            /* group loads + match test */
+
+        typename CbcEnc<W>::Fixed F;
+        E.fixed_group(F, c0, cn, r_pos, r_fl, neq);
+        CBC_TS(1);                                            /* fixed symbols of the group */
+
+        /* software prefetch: bases, reference window and tokens of the next imperfect record */
+        uint64_t todo = neq;
+        V32 nx_seq = W::splat(0u), nx_tok = W::splat(0u);
+        if (todo) {
+            const uint32_t jn = W::ctz64(todo);
+            const uint32_t so = W::readlane(r_seq, jn), to = W::readlane(r_tok, jn);
+            const uint32_t nrl = W::readlane(r_fl, jn) >> 16;
             V32 bo = ln * 4u;
-            nx_seq = W::load32_bytes(seqb + so, bo, bo < rl);
-            nx_ref = W::load32_bytes(refb + (pos - 1u), bo, bo < rl);
+            nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
             nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
         }
         for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
-            E.cur_read = c0 + j;
-            const uint32_t pos = W::readlane(r_pos, j), flw = W::readlane(r_fl, j);
-            const uint32_t flag = flw & 0xffffu, rl = flw >> 16;
-            const uint32_t tok_off = W::readlane(r_tok, j);
-            const V32 seqv = nx_seq, refv = nx_ref, tokv = nx_tok;
-            if (j + 1u < cn) {
-                uint32_t npos = W::readlane(r_pos, j + 1u), nfl = W::readlane(r_fl, j + 1u);
-                uint32_t so = W::readlane(r_seq, j + 1u), to = W::readlane(r_tok, j + 1u), nrl = nfl >> 16;
-                V32 bo = ln * 4u;
-                nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
-                nx_ref = W::load32_bytes(refb + (npos - 1u), bo, bo < nrl);
-                nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
-            }
-            CBC_TS(0);                                        /* loop top: readlanes + prefetch issue */
+            const uint32_t r = c0 + j;
+            E.cur_read = r;
+            if ((F.bad >> j) & 1ull) { E.fail(W::readlane(F.st, j)); break; }
 
-            /* -- compress_rname (id_compression.c:39-65); a block holds one contig -- */
-            const bool first = (c0 + j) == 0u;
-            if (!first) E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
+            /* -- compress_rname (id_compression.c:39-65); a block holds one contig.  same_ref is
+             *    (1,1) until record 0 codes symbol 1, after which only symbol 0 is coded -- */
+            if (r != 0u) E.encode(0u, 10u * r - 9u, 10u * r + 2u);
             else {
-                E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+                E.encode(1u, 1u, 2u);
                 for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
                     uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
                     E.rname_code(E.prevChar, ch);
@@ -772,73 +997,48 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                     if (ch == 0u) break;
                     E.prevChar = ch;
                 }
-                E.prevPos = 0;                                /* chr_change: compress_pos :123-124 */
-                E.win_clear();                                /* compression.c:62-63 */
             }
-
-            /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1) --
-             * rlength[0] is cached: while the same length repeats (fixed-length data: always) the
-             * symbol's (lo, count) live in scalars and the LDS table is not touched; the cached count
-             * is written back when another length shows up. */
+            /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1): rlength[0] from the group
+             *    pass; contexts 1..3 only ever code symbol 0, each once per record -- */
+            E.encode(W::readlane(F.rl_lo, j), W::readlane(F.rl_cnt, j), 255u + 10u * r);
+            E.encode(0u, 1u + 10u * r, 255u + 10u * r);
+            E.encode(0u, 1u + 10u * r, 255u + 10u * r);
+            E.encode(0u, 1u + 10u * r, 255u + 10u * r);
+            /* -- compress_pos: hit, or escape + the four bytes of the new delta -- */
             {
-                uint32_t x = rl & 0xffu;
-                if (x >= 255u) { E.fail(CBC_ST_ASSERT); break; }
-                if (x != E.rlen_memo_x) {
-                    if (E.rlen_memo_x != CBC_NOMEMO) W::write_uni(E.rlen_exc, E.rlen_memo_x, E.rlen_memo_cnt - 1u);
-                    uint32_t lo, cnt;
-                    E.dense_lookup(E.rlen_exc, x, lo, cnt);
-                    E.rlen_memo_x = x; E.rlen_memo_lo = lo; E.rlen_memo_cnt = cnt;
-                }
-                E.encode(E.rlen_memo_lo, E.rlen_memo_cnt, E.rlen_n);
-                E.rlen_memo_cnt += 10u; E.rlen_n += 10u;
-                if (E.rlen_n >= CBC_RESCALE) {                 /* rescale through the table, then re-read */
-                    W::write_uni(E.rlen_exc, x, E.rlen_memo_cnt - 1u);
-                    E.dense_rescale(E.rlen_exc, 255u, E.rlen_n);
-                    E.rlen_memo_x = CBC_NOMEMO;
-                }
-                for (int k = 1; k < 4; k++) {
-                    /* the three contexts evolve identically, but symbols interleave: k=1 sees the
-                     * state before this read's update, so code all three, then update once */
-                    E.encode(0u, E.rl123_c0, E.rl123_n);
-                }
-                E.rl123_c0 += 10u; E.rl123_n += 10u;
-                if (E.rl123_n >= CBC_RESCALE) { E.rl123_c0 = (E.rl123_c0 >> 1) + 1u; E.rl123_n = 254u + E.rl123_c0; }
+                const uint32_t card = W::readlane(F.p_card, j);
+                E.encode(W::readlane(F.p_lo, j), W::readlane(F.p_cnt, j), 10u * (card - 1u) + 10u * r + 1u);
+                if ((F.esc >> j) & 1ull) E.pos_alpha(W::read_uni(E.pos_val, card), card);
             }
-
-            CBC_TS(1);                                        /* rname + rlength */
-            /* -- compress_pos -- */
-            const int32_t dx = (int32_t)(pos - E.prevPos) + 1;
-            if (dx < 1 || (uint32_t)dx >= 5000000u) { E.fail(CBC_ST_ASSERT); break; }   /* MAX_ALPHA sam_block.h:54 */
-            E.win_shift(first ? 256u : (uint32_t)(dx - 1));
-#ifndef CBC_ABLATE_POS
-            E.pos_code((uint32_t)dx);
-#endif
-            E.prevPos = pos;
-
-            CBC_TS(2);                                        /* pos */
             /* -- compress_flag (read_compression.c:50-70) -- */
-#ifndef CBC_ABLATE_FLAG
-            E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, E.fn, 65536u, 8u, flag, CBC_ST_CAP_FLAG);
-#endif
-            const uint32_t strand = (flag >> 4) & 1u;
+            E.encode(W::readlane(F.fl_lo, j), W::readlane(F.fl_cnt, j), 65536u + 8u * r);
+            /* -- match flag -- */
+            E.encode(W::readlane(F.m_lo, j), W::readlane(F.m_cnt, j), W::readlane(F.m_n, j));
+            CBC_TS(2);                                        /* fixed symbols queued */
 
-            CBC_TS(3);                                        /* flag */
-            /* -- match test (read_compression.c:291-296) -- */
-            V32 bo = ln * 4u;
-            V32 bmask = W::select(bo + 4u <= rl, W::splat(0xffffffffu),
-                                  W::select(bo < rl, (W::splat(1u) << ((W::splat(rl) - bo) * 8u)) - 1u, W::splat(0u)));
-            uint64_t neq = W::ballot(((seqv ^ refv) & bmask) != 0u);
-            uint32_t match = neq ? 0u : 1u;
-            E.small_code(CBC_LT_MATCH + (((dx == 1) ? 2u : 0u) | E.prevM) * 2u, 2u, 1u, match);
-            E.prevM = match;
-#ifdef CBC_ABLATE_EDITS
-            match = 1u;
-#endif
-            CBC_TS(4);                                        /* match test + symbol (waits for the prefetch) */
-            if (!match && E.status == CBC_ST_OK) {
+            if (((todo >> j) & 1ull) && E.status == CBC_ST_OK) {
             /* -- compress_edits for an imperfect read (read_compression.c:308-600) --
              * The packer has already counted the edits (token word 1) and checked that the MD string is
              * consistent with the read, so every MD token becomes exactly one SNP: numSnps = n_md. */
+            const uint32_t pos = W::readlane(r_pos, j), flw = W::readlane(r_fl, j);
+            const uint32_t rl = flw >> 16, strand = (flw >> 4) & 1u;
+            const uint32_t tok_off = W::readlane(r_tok, j);
+            const V32 seqv = nx_seq, tokv = nx_tok;
+            todo &= ~(1ull << j);
+            if (todo) {
+                const uint32_t jn = W::ctz64(todo);
+                const uint32_t so = W::readlane(r_seq, jn), to = W::readlane(r_tok, jn);
+                const uint32_t nrl = W::readlane(r_fl, jn) >> 16;
+                V32 bo = ln * 4u;
+                nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
+                nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
+            }
+            {   /* snpInRef window: slide it to this record's POS (chr_change clears it, compression.c:62-63;
+                 * it is empty at the start of the block, so the first slide may be anything) */
+                const uint32_t d = pos - E.win_pos;
+                E.win_shift(d > 256u ? 256u : d);
+                E.win_pos = pos;
+            }
             const uint32_t hdr = W::readlane(tokv, 0u), hdr1 = W::readlane(tokv, 1u);
             const uint32_t n_cig = hdr & 0xffffu, n_md = hdr >> 16;
             const uint32_t nSnp = n_md, nDel = hdr1 & 0xffffu, nIns = hdr1 >> 16;
@@ -848,11 +1048,15 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
 #define CBC_TOK(i) ((i) < 64u ? W::readlane(tokv, (i)) : W::read_uni(tokb + tok_off, (i)))
 #define CBC_READ_BYTE(i) ((i) < rl ? ((W::readlane(seqv, (i) >> 2) >> (((i) & 3u) * 8u)) & 0xffu) : 0u)
 #define CBC_SNP(gap_, letter_, cum_, p_) do {                                                              \
+                CBC_TS(3);                                                                                  \
                 uint32_t d_ = E.win_first(p_, rl);                                                          \
+                CBC_TS(4);                                                                                  \
                 E.var_code(((((d_ << 7) + (p_)) << 1) | strand), (gap_));                                   \
+                CBC_TS(7);                                                                                  \
                 (p_) += (gap_) + 1u;                                                                        \
                 E.win_set((p_) - 1u);                     /* snpInRef[cumsumP+prev_pos-2] = 1  (:589) */     \
                 E.small_code(CBC_LT_CHARS + cbc_basepair(letter_) * 8u, 5u, 8u, cbc_basepair(CBC_READ_BYTE(cum_))); \
+                CBC_TS(8);                                                                                  \
             } while (0)
             if ((nDel | nIns) == 0u) {
                 /* SNP-only read (:557-558, :573-593): no insertion can interleave, so the MD tokens are
@@ -941,7 +1145,8 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     uint32_t nbytes = 0;
     if (E.status == CBC_ST_OK) {
         E.cur_read = n_reads;
-        E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+        if (n_reads) E.encode(10u * n_reads - 9u, 11u, 10u * n_reads + 2u);    /* same_ref symbol 1: counts (1 + 10 (n-1), 11) */
+        else E.encode(1u, 1u, 2u);
         E.rname_code(E.prevChar, (uint32_t)'\n');
         E.rname_code((uint32_t)'\n', 0u);
     }

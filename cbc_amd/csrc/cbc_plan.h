@@ -10,14 +10,14 @@
 #include "../../include/cbc_gpu.h"
 
 /* must match CBC_LDS_FIXED in cbc_encode_body.h */
-#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u + 392u)
+#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u + 392u + 256u)
 
 /* LDS per wavefront: fixed tables + the POS alphabet.  The var-event list is NOT in LDS: it lives in
  * global memory behind the block's payload area (encode) / in the decode scratch, so caps->cap_var
  * only sizes those areas. */
 static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
 {
-    return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 2u * caps->cap_pos);
+    return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 3u * caps->cap_pos);   /* pos_val, pos_occ, pos_pre */
 }
 
 /* decoder: the encoder's fixed tables + pos_alpha histograms + edit lists + scratch read

@@ -66,6 +66,41 @@ struct WaveGPU {
         return (uint32_t)x;
     }
 
+    /* number of set bits of `m` below this lane (v_mbcnt) */
+    static CBC_FN V32 prefix_popc(uint64_t m)
+    {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    }
+    /* lane i takes lane i-1's value, lane 0 takes `fill` (ds_bpermute: LDS crossbar, no memory) */
+    static CBC_FN V32 shift_up1(V32 v, uint32_t fill)
+    {
+        uint32_t l = lane();
+        uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l - 1u) << 2), (int)v);
+        return l == 0u ? fill : t;
+    }
+    /* bit `lane` of a wave-uniform 64-bit mask */
+    static CBC_FN Mask lane_bit(uint64_t m)
+    {
+        uint32_t l = lane();
+        uint32_t w = l < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
+        return ((w >> (l & 31u)) & 1u) != 0u;
+    }
+    /* floor(c * 2^32 / n), clamped to 2^32 - 1, per lane (c <= n < 2^21, n != 0).  The f64 quotient is
+     * correctly rounded (IEEE division) with 53 bits for a value <= 2^32, i.e. an error below 2^-21,
+     * while a non-integer c * 2^32 / n is at least 1/n > 2^-21 away from the next integer: the floor of
+     * the rounded quotient is the floor of the exact one. */
+    static CBC_FN V32 frac32(V32 c, V32 n)
+    {
+        double q = (double)c * 4294967296.0 / (double)(n ? n : 1u);
+        return q >= 4294967295.0 ? 0xffffffffu : (uint32_t)q;
+    }
+    /* OR into LDS words: lanes may name the same word (ds_or_b32) */
+    static CBC_FN void lds_or(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) __hip_atomic_fetch_or(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    static CBC_FN void set_lane(V32 &v, uint32_t k, uint32_t val) { v = lane() == k ? val : v; }
+    static CBC_FN V32 bswap_v(V32 x) { return __builtin_bswap32(x); }
+    /* emulation-only cross-check hook */
+    static CBC_FN void expect_eq(uint32_t, uint32_t, const char *) {}
+
     /* per-lane gathers / scatters; `m` false = lane does not touch memory */
     static CBC_FN V32 load32(const uint32_t *p, V32 idx, Mask m, uint32_t other) { return m ? p[idx] : other; }
     static CBC_FN void store32(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) p[idx] = val; }
@@ -86,8 +121,8 @@ struct WaveGPU {
         a = r.x; b = r.y; c = r.z; d = r.w;
     }
     /* A list in GLOBAL memory that the same wavefront appends to and re-reads (var events): reads
-     * bypass the CU's vector L1 (agent-scope relaxed atomic load = glc/sc1 load) and the appending lane
-     * drains its store before the next read can issue, so a lane never sees a stale line. */
+     * bypass the CU's vector L1 (agent-scope relaxed atomic load = glc/sc1 load) and list_fence()
+     * drains the appending lane's stores before a scan's first read, so a lane never sees a stale line. */
     static CBC_FN V32 load32_list(const uint32_t *p, V32 idx, Mask m, uint32_t other)
     {
         return m ? __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : other;
@@ -95,8 +130,10 @@ struct WaveGPU {
     static CBC_FN void append_list(uint32_t *p, uint32_t idx, uint32_t val)
     {
         if (lane() == 0) __hip_atomic_store(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0x0f70);        /* vmcnt(0) */
     }
+    /* before re-reading the list: every append of this wavefront has reached L2 (the appends themselves
+     * do not wait -- a scan is the rare case, an append happens for every var symbol) */
+    static CBC_FN void list_fence() { __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) */ }
     /* wave-uniform reads (same address in every lane) */
     static CBC_FN uint32_t read_uni(const uint32_t *p, uint32_t idx) { return uni(p[idx]); }
     static CBC_FN uint32_t read_uni8(const uint8_t *p, uint32_t idx) { return uni((uint32_t)p[idx]); }

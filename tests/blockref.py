@@ -45,7 +45,7 @@ def emu_lib():
     global _emu
     if _emu is None:
         subprocess.check_call(["make", "-C", _EMU_DIR, "libcbc_emu.so"], stdout=subprocess.DEVNULL)
-        L = ctypes.CDLL(os.path.join(_EMU_DIR, "libcbc_emu.so"))
+        L = ctypes.CDLL(os.environ.get("CBC_EMU_LIB") or os.path.join(_EMU_DIR, "libcbc_emu.so"))   # override: debugging builds
         L.emu_encode_blocks.restype = ctypes.c_int
         L.emu_encode_blocks.argtypes = [ctypes.POINTER(DeviceBatch)]
         L.emu_decode_blocks.restype = ctypes.c_int

@@ -11,6 +11,14 @@
 #include "../../cbc_amd/csrc/cbc_plan.h"
 
 static int g_emu_errors = 0;
+#ifdef CBC_EMU_TRACE
+extern "C" void cbc_emu_trace(uint32_t read, uint32_t lo, uint32_t cnt, uint32_t n)
+{
+    static FILE *f = NULL;
+    if (!f) { const char *p = getenv("CBC_EMU_TRACE_FILE"); f = fopen(p ? p : "/tmp/cbc_emu_trace.txt", "w"); }
+    if (f) { fprintf(f, "%u %u %u %u\n", read, lo, cnt, n); fflush(f); }
+}
+#endif
 extern "C" void emu_oob(const char *what) { fprintf(stderr, "[emu] invariant violated: %s\n", what); g_emu_errors++; }
 
 extern "C" __attribute__((visibility("default")))

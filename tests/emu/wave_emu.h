@@ -66,6 +66,27 @@ struct WaveEmu {
     static uint32_t readlane(const V32 &v, uint32_t k) { if (k >= 64) { emu_oob("readlane index"); return 0; } return v.v[k]; }
     static uint32_t reduce_add(const V32 &v) { uint32_t s = 0; for (int i = 0; i < 64; i++) s += v.v[i]; return s; }
 
+    static V32 prefix_popc(uint64_t m) { V32 r; uint32_t c = 0; for (int i = 0; i < 64; i++) { r.v[i] = c; c += (uint32_t)((m >> i) & 1u); } return r; }
+    static V32 shift_up1(const V32 &v, uint32_t fill) { V32 r; r.v[0] = fill; for (int i = 1; i < 64; i++) r.v[i] = v.v[i - 1]; return r; }
+    static Mask lane_bit(uint64_t m) { Mask r; for (int i = 0; i < 64; i++) r.b[i] = ((m >> i) & 1u) != 0; return r; }
+    static V32 frac32(const V32 &c, const V32 &n)
+    {
+        V32 r;
+        for (int i = 0; i < 64; i++) {
+            double q = (double)c.v[i] * 4294967296.0 / (double)(n.v[i] ? n.v[i] : 1u);
+            r.v[i] = q >= 4294967295.0 ? 0xffffffffu : (uint32_t)q;
+            if (n.v[i] && c.v[i] <= n.v[i]) {                       /* the f64 route must give the exact floor */
+                unsigned __int128 e = ((unsigned __int128)c.v[i] << 32) / n.v[i];
+                uint32_t want = e > 0xffffffffu ? 0xffffffffu : (uint32_t)e;
+                if (r.v[i] != want) emu_oob("frac32 is not the exact floor");
+            }
+        }
+        return r;
+    }
+    static void lds_or(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[idx.v[i]] |= val.v[i]; }
+    static void set_lane(V32 &v, uint32_t k, uint32_t val) { if (k >= 64) { emu_oob("set_lane index"); return; } v.v[k] = val; }
+    static V32 bswap_v(const V32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = __builtin_bswap32(x.v[i]); return r; }
+    static void expect_eq(uint32_t a, uint32_t b, const char *what) { if (a != b) emu_oob(what); }
     static V32 scan_incl_add(const V32 &v) { V32 r; uint32_t s = 0; for (int i = 0; i < 64; i++) { s += v.v[i]; r.v[i] = s; } return r; }
     static V32 load8(const uint8_t *p, const V32 &off, const Mask &m) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? p[off.v[i]] : 0u; return r; }
     static void store8(uint8_t *p, const V32 &off, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[off.v[i]] = (uint8_t)val.v[i]; }
@@ -103,6 +124,7 @@ struct WaveEmu {
     }
     static V32 load32_list(const uint32_t *p, const V32 &idx, const Mask &m, uint32_t other) { return load32(p, idx, m, other); }
     static void append_list(uint32_t *p, uint32_t idx, uint32_t val) { p[idx] = val; }
+    static void list_fence() {}
     static uint32_t read_uni(const uint32_t *p, uint32_t idx) { return p[idx]; }
     static uint32_t read_uni8(const uint8_t *p, uint32_t idx) { return p[idx]; }
     static void write_uni(uint32_t *p, uint32_t idx, uint32_t val) { p[idx] = val; }
