@@ -264,12 +264,24 @@ struct CbcEnc {
         const V32 q_hi = q_lo + q_cnt;
         const V32 f_lo = W::frac32(q_lo, q_n), f_hi = W::frac32(q_hi, q_n);
         V32 rec_a = W::splat(0u), rec_s = W::splat(0u);
-        for (uint32_t k = 0; k < m; k++) {
-            uint32_t k1, bits, sc;
-            code1(W::readlane(q_lo, k), W::readlane(q_hi, k), W::readlane(q_n, k), W::readlane(f_lo, k), W::readlane(f_hi, k),
-                  k1, bits, sc);
-            W::set_lane(rec_a, k, k1 | (bits << 5));
-            W::set_lane(rec_s, k, sc);
+        {   /* lanes past m hold the identity step (cum 0, cum + count = n: l and u keep their values and
+             * nothing is shifted out), so the loop runs two steps per trip without a remainder */
+            const Mask pad = !(ln < m);
+            const V32 p_n = W::select(pad, W::splat(1u), q_n);
+            const V32 p_lo = W::select(pad, W::splat(0u), q_lo), p_hi = W::select(pad, W::splat(1u), q_hi);
+            const V32 p_fl = W::select(pad, W::splat(0u), f_lo), p_fh = W::select(pad, W::splat(0xffffffffu), f_hi);
+            for (uint32_t k = 0; k < m; k += 2u) {
+                uint32_t k1, bits, sc;
+                code1(W::readlane(p_lo, k), W::readlane(p_hi, k), W::readlane(p_n, k), W::readlane(p_fl, k), W::readlane(p_fh, k),
+                      k1, bits, sc);
+                W::set_lane(rec_a, k, k1 | (bits << 5));
+                W::set_lane(rec_s, k, sc);
+                const uint32_t k2 = (k + 1u) & 63u;
+                code1(W::readlane(p_lo, k2), W::readlane(p_hi, k2), W::readlane(p_n, k2), W::readlane(p_fl, k2), W::readlane(p_fh, k2),
+                      k1, bits, sc);
+                W::set_lane(rec_a, k2, k1 | (bits << 5));
+                W::set_lane(rec_s, k2, sc);
+            }
         }
         nsym += m;
         pack(rec_a, rec_s, m);
@@ -325,22 +337,21 @@ struct CbcEnc {
         W::expect_eq(qh, (uint32_t)((uint64_t)range * hi / n), "scaled_div(cum + count)");
         u = l + qh - 1u;
         l = l + ql;
-        uint32_t x = l ^ u;
+        /* branch-free: a taken branch costs the lone wave more than the few operations it would skip.
+         * k1 = 0 makes the E1/E2 shifts the identity; after them bit 25 of l is 0 and of u is 1, so
+         * k3 = 0 makes the E3 update the identity too. */
+        const uint32_t x = l ^ u;
         k1 = x ? (W::clz32(x) - 6u) : 26u;
-        bits = 0; sc = 0;
-        if (k1) {
-            bits = l >> (26u - k1);
-            sc = scale3; scale3 = 0u;
-            l = (uint32_t)(((uint64_t)l << k1) & CBC_M26);
-            u = (uint32_t)((((uint64_t)u << k1) & CBC_M26) | ((1ull << k1) - 1ull));
-        }
-        uint32_t y = ((l & ~u) & CBC_M25) << 7;
-        uint32_t k3 = W::clz32(~y);                           /* ~y != 0: its low 7 bits are set */
-        if (k3) {
-            scale3 += k3;
-            l = (l << k3) & CBC_M25;
-            u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
-        }
+        bits = (uint32_t)(((uint64_t)l << k1) >> 26);            /* the k1 leading bits of l */
+        sc = k1 ? scale3 : 0u;
+        scale3 = k1 ? 0u : scale3;
+        l = (uint32_t)(((uint64_t)l << k1) & CBC_M26);
+        u = (uint32_t)((((uint64_t)u << k1) & CBC_M26) | ((1ull << k1) - 1ull));
+        const uint32_t y = ((l & ~u) & CBC_M25) << 7;
+        const uint32_t k3 = W::clz32(~y);                        /* ~y != 0: its low 7 bits are set */
+        scale3 += k3;
+        l = (l << k3) & CBC_M25;
+        u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
     }
     CBC_MFN uint32_t finish()                        /* encoder_last_step :348-363 + stream_finish_byte */
     {
