@@ -62,7 +62,7 @@
 #ifndef CBC_BATCH_MIN
 #define CBC_BATCH_MIN   40u    /* <= 64 - 12 (a record's fixed symbols) - 4 (edit counts) - slack: see the 56 checks */
 #endif
-#define CBC_BATCH_WORDS 196u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record} */
+#define CBC_BATCH_WORDS 200u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record, match mask x2} */
 #define CBC_RING_WORDS  256u                       /* output bit ring of the coder wave (power of two) */
 #define CBC_LDS_RING    (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS)
 #define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS + CBC_RING_WORDS)
@@ -107,13 +107,17 @@ struct CbcEnc {
     typedef typename W::Mask Mask;
 
     /* ---- range coder + bit writer (Arithmetic_stream.c:155-194, 274-371) ---- */
-    uint32_t l, u, scale3;
+    typedef typename W::Uv Uv;               /* a wave-uniform value kept in a VECTOR register (see cbc_wave_gpu.h) */
+    Uv l, u, scale3;
     uint32_t bitpos, flushed;               /* bits produced; words already stored (multiple of 64)  */
     uint32_t *ring;                         /* CBC_RING_WORDS of LDS, zero except for the pending bits */
     uint32_t *out32; uint32_t cap_words;
     uint32_t status, nsym, fail_read, cur_read;
     V32 q_lo, q_cnt, q_n; uint32_t q_len;   /* pending symbols: lane k = k-th queued (lo, cnt, n)      */
     uint32_t role, batch_i; uint32_t *batch;  /* CBC_ROLE_*; hand-off buffers between the two waves     */
+    /* coder wave: the batch taken from the model wave (lane k = its k-th symbol) and the read cursor */
+    V32 b_lo, b_hi, b_n, b_fl, b_fh; uint32_t b_len, b_pos, b_stop, b_flags, seen_last; uint64_t b_neq;
+    V32 rec_a, rec_s; uint32_t rec_n;       /* output of the coder steps not packed yet (see pack())   */
 #ifdef CBC_STAMP
     unsigned long long t_last, t_sum[16];
 #endif
@@ -232,132 +236,181 @@ struct CbcEnc {
         q_n = W::select(here, W::splat(n), q_n);
         q_len++;
     }
-    /* Run the pending symbols through the coder.  In the two-wavefront form (GPU) the model wave
-     * hands the batch to the coder wave through one of two LDS buffers and a workgroup barrier:
-     * batch b goes to buffer b&1; after barrier b the coder wave copies it into its own registers,
-     * so the model wave may refill that buffer as soon as barrier b+1 has passed.  Both waves execute
-     * exactly one barrier per batch and the model wave always ends with a batch flagged `last`. */
-    CBC_MFN void drain() { if (role == CBC_ROLE_MODEL) publish(0u); else drain_local(); }
-    CBC_MFN void publish(uint32_t flags)
+    /* ---- hand-off between the two wavefronts ------------------------------------------------------
+     * The coder wave owns the per-record ("fixed") models and codes their symbols straight from
+     * fixed_group()'s lanes; the model wave owns the edit models and produces everything else as
+     * SEGMENTS of the symbol stream, each closed by an END entry: the stream header, the contig name of
+     * record 0, the edits of one imperfect record, the end-of-stream sentinel.  Segments travel in
+     * batches of <= 64 entries through one of two LDS buffers and a workgroup barrier: batch b goes to
+     * buffer b & 1; after barrier b the coder copies it into registers, so the model wave may refill
+     * that buffer once barrier b + 1 has passed.  Per group of 64 records the model wave also sends one
+     * empty batch flagged GROUP that carries the group's match-test mask.  Both waves execute exactly
+     * one barrier per batch, and the model wave always ends with a batch flagged LAST (which carries
+     * its status): whatever happens, the coder takes batches until it has seen LAST. */
+#define CBC_FRAC(c, n) W::frac32(c, n)
+#define CBC_BF_LAST  1u
+#define CBC_BF_GROUP 2u
+#define CBC_END_N    0xffffffffu                     /* n of an END entry */
+    CBC_MFN void drain() { if (role == CBC_ROLE_MODEL) publish(0u, 0ull); else drain_q(); }
+    CBC_MFN void seg_end()
+    {
+        if (role != CBC_ROLE_MODEL) { drain_q(); return; }
+        if (q_len >= 64u) publish(0u, 0ull);
+        V32 ln = W::lane();
+        Mask here = ln == q_len;
+        q_lo = W::select(here, W::splat(0u), q_lo); q_cnt = W::select(here, W::splat(1u), q_cnt);
+        q_n = W::select(here, W::splat(CBC_END_N), q_n);
+        q_len++;
+    }
+    CBC_MFN void publish(uint32_t flags, uint64_t neq)
     {
         V32 ln = W::lane();
         uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
         Mask m = ln < q_len;
         W::store32(buf, ln, q_lo, m); W::store32(buf + 64u, ln, q_cnt, m); W::store32(buf + 128u, ln, q_n, m);
         V32 hdr = W::select(ln == 0u, W::splat(q_len), W::select(ln == 1u, W::splat(flags),
-                  W::select(ln == 2u, W::splat(status), W::splat(status == CBC_ST_OK ? cur_read : fail_read))));
-        W::store32(buf + 192u, ln, hdr, ln < 4u);
+                  W::select(ln == 2u, W::splat(status), W::select(ln == 3u, W::splat(status == CBC_ST_OK ? cur_read : fail_read),
+                  W::select(ln == 4u, W::splat((uint32_t)neq), W::splat((uint32_t)(neq >> 32)))))));
+        W::store32(buf + 192u, ln, hdr, ln < 6u);
+        CBC_TSM(5);
         W::barrier();
+        CBC_TSM(6);                                          /* model wave: waiting at the hand-off */
         batch_i++;
         q_len = 0;
     }
-    CBC_MFN void drain_local()
+    /* one symbol through the coder; the step's output waits in rec_a / rec_s for pack() */
+    CBC_MFN void step(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi)
+    {
+        Uv k1, bits, sc;
+        code1(lo, hi, n, flo, fhi, k1, bits, sc);
+        W::set_lane_uv(rec_a, rec_n, k1 | (bits << 5));
+        W::set_lane_uv(rec_s, rec_n, sc);
+        nsym++;
+        if (++rec_n == 64u) { pack(rec_a, rec_s, 64u); rec_n = 0; }
+    }
+    CBC_MFN void flush_recs() { if (rec_n) { pack(rec_a, rec_s, rec_n); rec_n = 0; } }
+    /* the symbols queued by this wavefront itself (fused form; in the coder wave: its own few queued ones).
+     * The two divisions of a step, floor(range * c / n) for c = cum and c = cum + count, need no divide on
+     * the serial path: f = floor(c * 2^32 / n) is computed for all queued symbols at once (one lane
+     * each), and code1() finishes with one multiply-high and a remainder test. */
+    CBC_MFN void drain_q()
     {
         V32 ln = W::lane();
         uint32_t m = W::uni(q_len);
         /* assert(cumCountX_1 < cumCountX) of every pending symbol at once (stream_model.c:71) */
         const uint64_t bad = W::ballot((ln < m) & ((q_cnt == 0u) | (q_n == 0u)));
         if (bad) m = W::ctz64(bad);
-        /* the two divisions of a step, floor(range * c / n) for c = cum and c = cum + count, without a
-         * divide on the serial path: f = floor(c * 2^32 / n) is computed here for all pending symbols
-         * at once (one lane each), and code1() finishes with one multiply-high and a remainder test */
         const V32 q_hi = q_lo + q_cnt;
-        const V32 f_lo = W::frac32(q_lo, q_n), f_hi = W::frac32(q_hi, q_n);
-        V32 rec_a = W::splat(0u), rec_s = W::splat(0u);
-        {   /* lanes past m hold the identity step (cum 0, cum + count = n: l and u keep their values and
-             * nothing is shifted out), so the loop runs two steps per trip without a remainder */
-            const Mask pad = !(ln < m);
-            const V32 p_n = W::select(pad, W::splat(1u), q_n);
-            const V32 p_lo = W::select(pad, W::splat(0u), q_lo), p_hi = W::select(pad, W::splat(1u), q_hi);
-            const V32 p_fl = W::select(pad, W::splat(0u), f_lo), p_fh = W::select(pad, W::splat(0xffffffffu), f_hi);
-            for (uint32_t k = 0; k < m; k += 2u) {
-                uint32_t k1, bits, sc;
-                code1(W::readlane(p_lo, k), W::readlane(p_hi, k), W::readlane(p_n, k), W::readlane(p_fl, k), W::readlane(p_fh, k),
-                      k1, bits, sc);
-                W::set_lane(rec_a, k, k1 | (bits << 5));
-                W::set_lane(rec_s, k, sc);
-                const uint32_t k2 = (k + 1u) & 63u;
-                code1(W::readlane(p_lo, k2), W::readlane(p_hi, k2), W::readlane(p_n, k2), W::readlane(p_fl, k2), W::readlane(p_fh, k2),
-                      k1, bits, sc);
-                W::set_lane(rec_a, k2, k1 | (bits << 5));
-                W::set_lane(rec_s, k2, sc);
-            }
-        }
-        nsym += m;
-        pack(rec_a, rec_s, m);
+        const V32 f_lo = CBC_FRAC(q_lo, q_n), f_hi = CBC_FRAC(q_hi, q_n);
+        for (uint32_t k = 0; k < m; k++)
+            step(W::readlane(q_lo, k), W::readlane(q_hi, k), W::readlane(q_n, k), W::readlane(f_lo, k), W::readlane(f_hi, k));
         if (bad) fail(CBC_ST_ASSERT);
         q_len = 0;
     }
-    /* coder wave: take batches until the one flagged last; returns false when the model wave aborted */
-    CBC_MFN void consume_all()
+    /* coder wave: take the next batch */
+    CBC_MFN void pull()
     {
         V32 ln = W::lane();
-        for (;;) {
-            CBC_TSM(9);                                       /* coder wave: coding */
-            W::barrier();
-            CBC_TSM(10);                                      /* coder wave: waiting for a batch */
-            const uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
-            V32 hdr = W::load32(buf + 192u, ln, ln < 4u, 0u);
-            const uint32_t len = W::readlane(hdr, 0u), flags = W::readlane(hdr, 1u);
-            const uint32_t pst = W::readlane(hdr, 2u), prec = W::readlane(hdr, 3u);
-            Mask m = ln < len;
-            q_lo = W::load32(buf, ln, m, 0u); q_cnt = W::load32(buf + 64u, ln, m, 1u); q_n = W::load32(buf + 128u, ln, m, 1u);
-            q_len = len > 64u ? 64u : len;
-            batch_i++;
-            cur_read = prec;
-            if (pst != CBC_ST_OK) { if (status == CBC_ST_OK) { status = pst; fail_read = prec; } }
-            else if (status == CBC_ST_OK) drain_local();
-            if (flags & 1u) break;
+        CBC_TSM(9);                                           /* coder wave: coding */
+        W::barrier();
+        CBC_TSM(10);                                          /* coder wave: waiting for a batch */
+        const uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
+        V32 hdr = W::load32(buf + 192u, ln, ln < 6u, 0u);
+        const uint32_t len = W::readlane(hdr, 0u);
+        const uint32_t pst = W::readlane(hdr, 2u), prec = W::readlane(hdr, 3u);
+        b_flags = W::readlane(hdr, 1u);
+        b_neq = (uint64_t)W::readlane(hdr, 4u) | ((uint64_t)W::readlane(hdr, 5u) << 32);
+        Mask m = ln < len;
+        b_lo = W::load32(buf, ln, m, 0u); b_n = W::load32(buf + 128u, ln, m, 1u);
+        const V32 cnt = W::load32(buf + 64u, ln, m, 1u);
+        b_hi = b_lo + cnt;
+        b_fl = CBC_FRAC(b_lo, b_n); b_fh = CBC_FRAC(b_hi, b_n);
+        b_len = len > 64u ? 64u : len; b_pos = 0;
+        const uint64_t bad = W::ballot(m & ((cnt == 0u) | (b_n == 0u)));
+        b_stop = bad ? W::ctz64(bad) : 64u;
+        batch_i++;
+        if (b_flags & CBC_BF_LAST) seen_last = 1u;
+        if (pst != CBC_ST_OK && status == CBC_ST_OK) { status = pst; fail_read = prec; }
+    }
+    /* coder wave: code the model wave's symbols up to the next END */
+    CBC_MFN void seg_consume()
+    {
+        while (status == CBC_ST_OK) {
+            if (b_pos == b_len) {
+                if (seen_last) { fail(CBC_ST_ASSERT); return; }                /* stream ended inside a segment */
+                pull();
+                if (b_flags & CBC_BF_GROUP) fail(CBC_ST_ASSERT);               /* protocol: group mark inside a segment */
+                continue;
+            }
+            const uint32_t k = b_pos++;
+            const uint32_t n = W::readlane(b_n, k);
+            if (n == CBC_END_N) return;
+            if (k == b_stop) { fail(CBC_ST_ASSERT); return; }                  /* zero count / total: stream_model.c:71 */
+            step(W::readlane(b_lo, k), W::readlane(b_hi, k), n, W::readlane(b_fl, k), W::readlane(b_fh, k));
         }
     }
+    /* coder wave: the next group's match mask (an empty batch flagged GROUP) */
+    CBC_MFN uint64_t pull_group()
+    {
+        if (status != CBC_ST_OK) return 0ull;
+        if (b_pos != b_len || seen_last) { fail(CBC_ST_ASSERT); return 0ull; }
+        pull();
+        if (status == CBC_ST_OK && !(b_flags & CBC_BF_GROUP)) fail(CBC_ST_ASSERT);
+        return b_neq;
+    }
+    /* coder wave: before leaving, take every batch the model wave still sends */
+    CBC_MFN void pull_rest() { while (!seen_last) pull(); }
     /* floor(range * c / n) given f = floor(c * 2^32 / n) (clamped to 2^32 - 1 when c == n):
      * range <= 2^26, so range * f / 2^32 is below the true quotient by less than 2^-6 + 1: the
      * multiply-high is the quotient or one less, and the remainder (< 2n < 2^22, so its low 32 bits are
      * all of it) says which. */
-    static CBC_MFN uint32_t scaled_div(uint32_t range, uint32_t c, uint32_t n, uint32_t f)
+    static CBC_MFN Uv scaled_div(Uv range, uint32_t c, uint32_t n, uint32_t f)
     {
-        uint32_t q = (uint32_t)(((uint64_t)range * f) >> 32);
-        uint32_t r = range * c - q * n;
+        Uv q = W::mulhi(range, f);
+        Uv r = range * c - q * n;
         return q + (r >= n ? 1u : 0u);
     }
-    /* one coder step without its output: the range update and the closed-form E1/E2 and E3 shifts.
-     * k1 bits (`bits`, MSB first) leave through E1/E2; `sc` is the E3 count pending at that moment. */
-    CBC_MFN void code1(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi,
-                       uint32_t &k1, uint32_t &bits, uint32_t &sc)
+    /* one coder step without its output: the range update (Arithmetic_stream.c:274-295) and the E1/E2
+     * and E3 loops (:296-341) in closed form -- within one step all E1/E2 iterations come first (they
+     * strip the common leading bits of l and u), then all E3 iterations (the run of positions below the
+     * MSB where l has 1 and u has 0); E3 leaves msb(l) = 0, msb(u) = 1, so E1/E2 cannot recur.
+     * k1 bits (`bits`, MSB first) leave through E1/E2; `sc` is the E3 count pending at that moment.
+     * The recurrence runs on the VECTOR unit although every lane holds the same value: a CU has one
+     * scalar unit for all its wavefronts and four vector units, and with ten blocks resident per CU the
+     * scalar unit is what the kernel queues on. */
+    CBC_MFN void code1(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi, Uv &k1, Uv &bits, Uv &sc)
     {
 #ifdef CBC_ABLATE_CODER          /* timing experiments only: keeps the operands live, skips the coder */
-        l ^= lo; u ^= hi + n; k1 = 0; bits = 0; sc = 0; return;
+        l ^= lo; u ^= hi + n; k1 = W::uv(0u); bits = k1; sc = k1; return;
 #endif
-#ifdef __HIP_DEVICE_COMPILE__
-        asm volatile("" : "+s"(l), "+s"(u), "+s"(scale3));
-#endif
-        const uint32_t range = u - l + 1u;
-        const uint32_t ql = scaled_div(range, lo, n, flo), qh = scaled_div(range, hi, n, fhi);
-        W::expect_eq(ql, (uint32_t)((uint64_t)range * lo / n), "scaled_div(cum)");
-        W::expect_eq(qh, (uint32_t)((uint64_t)range * hi / n), "scaled_div(cum + count)");
+        const Uv range = u - l + 1u;
+        const Uv ql = scaled_div(range, lo, n, flo), qh = scaled_div(range, hi, n, fhi);
+        W::expect_eq(W::uv_scalar(ql), (uint32_t)((uint64_t)W::uv_scalar(range) * lo / n), "scaled_div(cum)");
+        W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi / n), "scaled_div(cum + count)");
         u = l + qh - 1u;
         l = l + ql;
-        /* branch-free: a taken branch costs the lone wave more than the few operations it would skip.
-         * k1 = 0 makes the E1/E2 shifts the identity; after them bit 25 of l is 0 and of u is 1, so
-         * k3 = 0 makes the E3 update the identity too. */
-        const uint32_t x = l ^ u;
-        k1 = x ? (W::clz32(x) - 6u) : 26u;
-        bits = (uint32_t)(((uint64_t)l << k1) >> 26);            /* the k1 leading bits of l */
+        /* branch-free, and in 32-bit arithmetic only: l, u < 2^26 and k1 <= 26, so the bits a 32-bit
+         * shift drops are bits the 26-bit masks drop anyway.  k1 = 0 makes the E1/E2 shifts the
+         * identity; after them bit 25 of l is 0 and of u is 1, so k3 = 0 makes the E3 update the identity. */
+        const Uv x = l ^ u;
+        k1 = x ? (W::clz_uv(x) - 6u) : 26u;
+        bits = l >> (26u - k1);                                  /* the k1 leading bits of l (k1 = 0: l >> 26 = 0) */
         sc = k1 ? scale3 : 0u;
         scale3 = k1 ? 0u : scale3;
-        l = (uint32_t)(((uint64_t)l << k1) & CBC_M26);
-        u = (uint32_t)((((uint64_t)u << k1) & CBC_M26) | ((1ull << k1) - 1ull));
-        const uint32_t y = ((l & ~u) & CBC_M25) << 7;
-        const uint32_t k3 = W::clz32(~y);                        /* ~y != 0: its low 7 bits are set */
+        l = (l << k1) & CBC_M26;
+        u = ((u << k1) & CBC_M26) | ((1u << k1) - 1u);
+        const Uv y = ((l & ~u) & CBC_M25) << 7;
+        const Uv k3 = W::clz_uv(~y);                             /* ~y != 0: its low 7 bits are set */
         scale3 += k3;
         l = (l << k3) & CBC_M25;
         u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
     }
     CBC_MFN uint32_t finish()                        /* encoder_last_step :348-363 + stream_finish_byte */
     {
-        uint32_t msb = l >> 25;
-        put(msb, 1u); put_run(msb ^ 1u, scale3); scale3 = 0u;
-        put(l & CBC_M25, 25u);
+        const uint32_t lf = W::uv_scalar(l);
+        uint32_t msb = lf >> 25;
+        put(msb, 1u); put_run(msb ^ 1u, W::uv_scalar(scale3)); scale3 = W::uv(0u);
+        put(lf & CBC_M25, 25u);
         const uint32_t nbytes = (bitpos >> 3) + 1u;          /* +1: the partial byte, or the extra 0x00 */
         const uint32_t nw = (nbytes + 3u) >> 2;              /* the ring is zero past the last bit */
         const V32 ln = W::lane();
@@ -842,11 +895,12 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
 
     E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
-    E.l = 0; E.u = CBC_M26; E.scale3 = 0; E.bitpos = 0; E.flushed = 0;
+    E.l = W::uv(0u); E.u = W::uv(CBC_M26); E.scale3 = W::uv(0u); E.bitpos = 0; E.flushed = 0;
     E.ring = lds + CBC_LDS_RING;
-    if (ROLE != CBC_ROLE_MODEL)
-        for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
     E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
+    E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);
+    E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
+    E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
     E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH;
     /* the block's out area: [0, payload_cap) payload, [payload_cap, out_cap) its var-event list */
     const uint32_t payload_cap = bd->reserved;
@@ -859,48 +913,39 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                    cbc_le64(rec_base + n_reads, A.n_recs) && cbc_le64(tok_base + n_tok_blk, A.n_tok) &&
                    (L0 >= 1u && L0 <= 256u) && (name_off < A.names_bytes);
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
+    /* the closed forms of fixed_group() hold while no per-record model can reach its rescale point */
+    if (n_reads > CBC_MAX_BLOCK_READS) E.fail(CBC_ST_UNSUPPORTED);
 
-    if (ROLE == CBC_ROLE_CODER) {
-        /* coder wavefront: nothing but the range coder, fed by the model wavefront's batches */
-#ifdef CBC_STAMP
-        for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
-        CBC_T0();
-#endif
-        E.consume_all();
-        uint32_t nb = 0;
-        if (E.status == CBC_ST_OK) nb = E.finish();
-        if (E.status != CBC_ST_OK) nb = 0;
-#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
-        if (payload_cap >= 128u) for (int i = 0; i < 16; i++) {   /* diagnostic build: over the payload start */
-            W::write_uni(E.out32, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.out32, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
-#endif
-        V32 rv = W::select(ln == 0u, W::splat(nb), W::select(ln == 1u, W::splat(E.status),
-                 W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
-        W::store32((uint32_t *)(A.results + blk), ln, rv, ln < 4u);
-        return;
-    }
-
-    /* ---- model initialisation (alloc_read_models_t sam_models.c:562-586 etc.) ---- */
+    /* ---- model tables.  LDS words [0, 256) rlength, the output ring and the pos arrays belong to the
+     * wavefront that codes the fixed symbols (coder / fused); snps, indels, the name list, the Bloom
+     * filter and the hot var slots to the one that produces the segments (model / fused).
+     * (alloc_read_models_t sam_models.c:562-586 etc.) ---- */
     E.L0 = L0;
     E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
     E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
     E.bloom = lds + CBC_LDS_BLOOM;
     E.pos_val = lds + CBC_LDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = E.pos_occ + A.cap_pos;
     E.cap_pos = A.cap_pos;
-    for (uint32_t b = 0; b < 768u; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
-    for (uint32_t b = 0; b < 768u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* Bloom + 2 slots */
+    if (ROLE != CBC_ROLE_MODEL) {
+        for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
+        for (uint32_t b = 0; b < 256u; b += 64u) W::store32(E.rlen_exc, ln + b, W::splat(0u), W::all());
+        W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 0u); W::write_uni(E.pos_pre, 0u, 0u);
+    }
+    if (ROLE != CBC_ROLE_CODER) {
+        for (uint32_t b = 0; b < 512u; b += 64u) W::store32(E.snps_exc, ln + b, W::splat(0u), W::all());   /* snps + indels */
+        for (uint32_t b = 0; b < 768u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());      /* Bloom + 2 slots */
+    }
     E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
     E.snps_n = L0; E.indels_n = L0;
     E.rn_count = 0;
     E.pos_card = 1u;                                         /* initialize_stream_model_pos :132-162: the escape */
-    W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 0u); W::write_uni(E.pos_pre, 0u, 0u);
     E.nev = 0;
     E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
     E.hkey = W::splat(0u); E.hexc = W::splat(0u);
     E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
     {   /* lane table: match 1,1 (n=2); same_ref 1,1; chars rows (sam_models.c:372-401) */
-        V32 s = W::splat(0u);
-        s = W::select(ln < 10u, W::splat(1u), s);
+        V32 sm = W::splat(0u);
+        sm = W::select(ln < 10u, W::splat(1u), sm);
         V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
         Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
         V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
@@ -908,24 +953,12 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
                     ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
         cv = W::select(bump, cv + 8u, cv);
-        s = W::select(inch, cv, s);
-        E.small = s;
+        sm = W::select(inch, cv, sm);
+        E.small = sm;
     }
     E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0;
     E.win_clear();
 
-    /* ---- stream header: int(L0), 32 x int(WELL), int(LOSSLESS=8)  (sam_file_allocation.c:371,
-     *      392-403; compression.c:139; compress_int qv_codebook.c:14-50) ---- */
-    for (uint32_t k = 0; k < 34u && E.status == CBC_ST_OK; k++) {
-        uint32_t v = (k == 0u) ? L0 : (k == 33u) ? 8u : CBC_WELL_SEED;
-        E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
-        E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
-        E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
-        E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
-        if ((k & 7u) == 7u || k == 33u) E.drain();
-    }
-
-    /* ---- records ---- */
     const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
     const uint8_t *seqb = A.seq + seq_base;
     const uint32_t *tokb = A.tok + tok_base;
@@ -933,117 +966,46 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const uint64_t seq_avail = cbc_le64(seq_base, A.seq_bytes) ? A.seq_bytes - seq_base : 0;
     const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
     const uint32_t seq_lim = cbc_avail32(seq_avail, 0u), ref_lim = cbc_avail32(ref_avail, 0u);
-
 #ifdef CBC_STAMP
     for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
     CBC_T0();
 #endif
-    /* the closed forms of fixed_group() hold while no per-record model can reach its rescale point */
-    if (n_reads > CBC_MAX_BLOCK_READS) E.fail(CBC_ST_UNSUPPORTED);
-    for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
-        V32 r_pos, r_fl, r_seq, r_tok;
-        W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
-        const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
-        {   /* validate the 64 records at once (one lane each) so the per-record loads below need no
-             * clamping: read length 1..252, POS >= 1, bases and reference window inside the buffers */
-            V32 vrl = r_fl >> 16;
-            Mask live = (ln + c0) < n_reads;
-            Mask bad = live & ((vrl == 0u) | (vrl > CBC_MAX_READ_LEN) | (r_pos == 0u) |
-                               ((r_seq + vrl + 4u) > seq_lim) | ((r_pos + vrl + 3u) > ref_lim) | (r_tok >= n_tok_blk));
-            uint64_t bb = W::ballot(bad);
-            if (bb) { E.cur_read = c0 + W::ctz64(bb); E.fail(CBC_ST_ASSERT); break; }
+
+    /* ================================ segment generators ==================================== */
+    /* stream header: int(L0), 32 x int(WELL), int(LOSSLESS=8)  (sam_file_allocation.c:371, 392-403;
+     * compression.c:139; compress_int qv_codebook.c:14-50) */
+    auto gen_header = [&]() {
+        for (uint32_t k = 0; k < 34u && E.status == CBC_ST_OK; k++) {
+            uint32_t v = (k == 0u) ? L0 : (k == 33u) ? 8u : CBC_WELL_SEED;
+            E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
+            E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
+            E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
+            E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
+            if ((k & 7u) == 7u) E.drain();
         }
-
-        /* -- match test of every record of the group (read_compression.c:291-296): lane l compares
-         *    bases 4l..4l+3; the loads of 8 records are in flight together -- */
-        uint64_t neq = 0;
-        for (uint32_t j0 = 0; j0 < cn; j0 += 8u) {
-            V32 sv[8], rv[8]; uint32_t rls[8];
-            const V32 bo = ln * 4u;
-            for (uint32_t q = 0; q < 8u; q++) {                 /* lanes past cn hold zero records: nothing is loaded */
-                const uint32_t jj = (j0 + q) & 63u;
-                const uint32_t pos = W::readlane(r_pos, jj), so = W::readlane(r_seq, jj);
-                rls[q] = (j0 + q < cn) ? W::readlane(r_fl, jj) >> 16 : 0u;
-                sv[q] = W::load32_bytes(seqb + so, bo, bo < rls[q]);
-                rv[q] = W::load32_bytes(refb + (pos - 1u), bo, bo < rls[q]);
-            }
-            for (uint32_t q = 0; q < 8u; q++) {
-                const uint32_t rl = rls[q];
-                V32 bmask = W::select(bo + 4u <= rl, W::splat(0xffffffffu),
-                                      W::select(bo < rl, (W::splat(1u) << ((W::splat(rl) - bo) * 8u)) - 1u, W::splat(0u)));
-                if (W::ballot(((sv[q] ^ rv[q]) & bmask) != 0u)) neq |= 1ull << ((j0 + q) & 63u);
-            }
+    };
+    /* the contig name of record 0, compress_rname (id_compression.c:39-65); a block holds one contig */
+    auto gen_rname = [&]() {
+        for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
+            uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
+            E.rname_code(E.prevChar, ch);
+            if ((q & 31u) == 31u) E.drain();                  /* long contig names: keep the queue short */
+            if (ch == 0u) break;
+            E.prevChar = ch;
         }
-        CBC_TS(0);                                            /* group loads + match test */
-
-        typename CbcEnc<W>::Fixed F;
-        E.fixed_group(F, c0, cn, r_pos, r_fl, neq);
-        CBC_TS(1);                                            /* fixed symbols of the group */
-
-        /* software prefetch: bases, reference window and tokens of the next imperfect record */
-        uint64_t todo = neq;
-        V32 nx_seq = W::splat(0u), nx_tok = W::splat(0u);
-        if (todo) {
-            const uint32_t jn = W::ctz64(todo);
-            const uint32_t so = W::readlane(r_seq, jn), to = W::readlane(r_tok, jn);
-            const uint32_t nrl = W::readlane(r_fl, jn) >> 16;
-            V32 bo = ln * 4u;
-            nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
-            nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
-        }
-        for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
-            const uint32_t r = c0 + j;
-            E.cur_read = r;
-            if ((F.bad >> j) & 1ull) { E.fail(W::readlane(F.st, j)); break; }
-
-            /* -- compress_rname (id_compression.c:39-65); a block holds one contig.  same_ref is
-             *    (1,1) until record 0 codes symbol 1, after which only symbol 0 is coded -- */
-            if (r != 0u) E.encode(0u, 10u * r - 9u, 10u * r + 2u);
-            else {
-                E.encode(1u, 1u, 2u);
-                for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
-                    uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
-                    E.rname_code(E.prevChar, ch);
-                    if ((q & 31u) == 31u) E.drain();          /* long contig names: keep the queue short */
-                    if (ch == 0u) break;
-                    E.prevChar = ch;
-                }
-            }
-            /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1): rlength[0] from the group
-             *    pass; contexts 1..3 only ever code symbol 0, each once per record -- */
-            E.encode(W::readlane(F.rl_lo, j), W::readlane(F.rl_cnt, j), 255u + 10u * r);
-            E.encode(0u, 1u + 10u * r, 255u + 10u * r);
-            E.encode(0u, 1u + 10u * r, 255u + 10u * r);
-            E.encode(0u, 1u + 10u * r, 255u + 10u * r);
-            /* -- compress_pos: hit, or escape + the four bytes of the new delta -- */
-            {
-                const uint32_t card = W::readlane(F.p_card, j);
-                E.encode(W::readlane(F.p_lo, j), W::readlane(F.p_cnt, j), 10u * (card - 1u) + 10u * r + 1u);
-                if ((F.esc >> j) & 1ull) E.pos_alpha(W::read_uni(E.pos_val, card), card);
-            }
-            /* -- compress_flag (read_compression.c:50-70) -- */
-            E.encode(W::readlane(F.fl_lo, j), W::readlane(F.fl_cnt, j), 65536u + 8u * r);
-            /* -- match flag -- */
-            E.encode(W::readlane(F.m_lo, j), W::readlane(F.m_cnt, j), W::readlane(F.m_n, j));
-            CBC_TS(2);                                        /* fixed symbols queued */
-
-            if (((todo >> j) & 1ull) && E.status == CBC_ST_OK) {
-            /* -- compress_edits for an imperfect read (read_compression.c:308-600) --
-             * The packer has already counted the edits (token word 1) and checked that the MD string is
-             * consistent with the read, so every MD token becomes exactly one SNP: numSnps = n_md. */
-            const uint32_t pos = W::readlane(r_pos, j), flw = W::readlane(r_fl, j);
+    };
+    /* end-of-stream sentinel compress_rname("\n") (compression.c:152), after its same_ref symbol */
+    auto gen_sentinel = [&]() {
+        if (E.q_len >= 56u) E.drain();
+        E.cur_read = n_reads;
+        E.rname_code(E.prevChar, (uint32_t)'\n');
+        E.rname_code((uint32_t)'\n', 0u);
+    };
+    /* compress_edits for an imperfect read (read_compression.c:308-600).
+     * The packer has already counted the edits (token word 1) and checked that the MD string is
+     * consistent with the read, so every MD token becomes exactly one SNP: numSnps = n_md. */
+    auto gen_edits = [&](uint32_t pos, uint32_t flw, uint32_t tok_off, const V32 &seqv, const V32 &tokv) {
             const uint32_t rl = flw >> 16, strand = (flw >> 4) & 1u;
-            const uint32_t tok_off = W::readlane(r_tok, j);
-            const V32 seqv = nx_seq, tokv = nx_tok;
-            todo &= ~(1ull << j);
-            if (todo) {
-                const uint32_t jn = W::ctz64(todo);
-                const uint32_t so = W::readlane(r_seq, jn), to = W::readlane(r_tok, jn);
-                const uint32_t nrl = W::readlane(r_fl, jn) >> 16;
-                V32 bo = ln * 4u;
-                nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
-                nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
-            }
             {   /* snpInRef window: slide it to this record's POS (chr_change clears it, compression.c:62-63;
                  * it is empty at the start of the block, so the first slide may be anything) */
                 const uint32_t d = pos - E.win_pos;
@@ -1054,7 +1016,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             const uint32_t n_cig = hdr & 0xffffu, n_md = hdr >> 16;
             const uint32_t nSnp = n_md, nDel = hdr1 & 0xffffu, nIns = hdr1 >> 16;
             if (tok_off + 2u + n_cig + n_md > n_tok_blk || nSnp >= 1024u || nDel >= 1024u || nIns >= 1024u) {
-                E.fail(CBC_ST_ASSERT); break;
+                E.fail(CBC_ST_ASSERT); return;
             }
 #define CBC_TOK(i) ((i) < 64u ? W::readlane(tokv, (i)) : W::read_uni(tokb + tok_off, (i)))
 #define CBC_READ_BYTE(i) ((i) < rl ? ((W::readlane(seqv, (i) >> 2) >> (((i) & 3u) * 8u)) & 0xffu) : 0u)
@@ -1145,32 +1107,185 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
 #undef CBC_SNP
 #undef CBC_TOK
 #undef CBC_READ_BYTE
+    };
+    /* match test of a group's records (read_compression.c:291-296): lane l compares bases 4l..4l+3;
+     * the loads of 8 records are in flight together */
+    auto match_group = [&](uint32_t cn, const V32 &r_pos, const V32 &r_fl, const V32 &r_seq) -> uint64_t {
+        uint64_t neq = 0;
+        for (uint32_t j0 = 0; j0 < cn; j0 += 8u) {
+            V32 sv[8], rv[8]; uint32_t rls[8];
+            const V32 bo = ln * 4u;
+            for (uint32_t q = 0; q < 8u; q++) {                 /* lanes past cn hold zero records: nothing is loaded */
+                const uint32_t jj = (j0 + q) & 63u;
+                const uint32_t pos = W::readlane(r_pos, jj), so = W::readlane(r_seq, jj);
+                rls[q] = (j0 + q < cn) ? W::readlane(r_fl, jj) >> 16 : 0u;
+                sv[q] = W::load32_bytes(seqb + so, bo, bo < rls[q]);
+                rv[q] = W::load32_bytes(refb + (pos - 1u), bo, bo < rls[q]);
             }
-            CBC_TS(5);                                        /* edits */
-            if (E.q_len >= CBC_BATCH_MIN) E.drain();          /* hand over once a few records' symbols are pending */
-            CBC_TS(6);                                        /* coder */
+            for (uint32_t q = 0; q < 8u; q++) {
+                const uint32_t rl = rls[q];
+                V32 bmask = W::select(bo + 4u <= rl, W::splat(0xffffffffu),
+                                      W::select(bo < rl, (W::splat(1u) << ((W::splat(rl) - bo) * 8u)) - 1u, W::splat(0u)));
+                if (W::ballot(((sv[q] ^ rv[q]) & bmask) != 0u)) neq |= 1ull << ((j0 + q) & 63u);
+            }
         }
+        return neq;
+    };
+    /* the 64 records of a group, validated one lane each so that the per-record loads need no clamping:
+     * read length 1..252, POS >= 1, bases and reference window inside the buffers */
+    auto load_group = [&](uint32_t c0, V32 &r_pos, V32 &r_fl, V32 &r_seq, V32 &r_tok, bool check) -> bool {
+        W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
+        if (!check) return true;
+        V32 vrl = r_fl >> 16;
+        Mask live = (ln + c0) < n_reads;
+        Mask bad = live & ((vrl == 0u) | (vrl > CBC_MAX_READ_LEN) | (r_pos == 0u) |
+                           ((r_seq + vrl + 4u) > seq_lim) | ((r_pos + vrl + 3u) > ref_lim) | (r_tok >= n_tok_blk));
+        uint64_t bb = W::ballot(bad);
+        if (bb) { E.cur_read = c0 + W::ctz64(bb); E.fail(CBC_ST_ASSERT); return false; }
+        return true;
+    };
+
+    /* ================================ model wavefront ======================================== */
+    if (ROLE == CBC_ROLE_MODEL) {
+        if (E.status == CBC_ST_OK) { gen_header(); E.seg_end(); }
+        for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
+            V32 r_pos, r_fl, r_seq, r_tok;
+            const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
+            E.cur_read = c0;
+            if (!load_group(c0, r_pos, r_fl, r_seq, r_tok, true)) break;
+            const uint64_t neq = match_group(cn, r_pos, r_fl, r_seq);
+            CBC_TS(0);                                        /* group loads + match test */
+            if (E.q_len) E.publish(0u, 0ull);                 /* a GROUP batch carries no symbols */
+            E.publish(CBC_BF_GROUP, neq);
+            if (c0 == 0u) { gen_rname(); E.seg_end(); }
+            /* software prefetch: bases and tokens of the next imperfect record */
+            uint64_t todo = neq;
+            V32 nx_seq = W::splat(0u), nx_tok = W::splat(0u);
+            if (todo) {
+                const uint32_t jn = W::ctz64(todo);
+                const uint32_t so = W::readlane(r_seq, jn), to = W::readlane(r_tok, jn), nrl = W::readlane(r_fl, jn) >> 16;
+                V32 bo = ln * 4u;
+                nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
+                nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
+            }
+            while (todo && E.status == CBC_ST_OK) {
+                const uint32_t j = W::ctz64(todo);
+                todo &= todo - 1ull;
+                E.cur_read = c0 + j;
+                const V32 seqv = nx_seq, tokv = nx_tok;
+                if (todo) {
+                    const uint32_t jn = W::ctz64(todo);
+                    const uint32_t so = W::readlane(r_seq, jn), to = W::readlane(r_tok, jn), nrl = W::readlane(r_fl, jn) >> 16;
+                    V32 bo = ln * 4u;
+                    nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
+                    nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
+                }
+                gen_edits(W::readlane(r_pos, j), W::readlane(r_fl, j), W::readlane(r_tok, j), seqv, tokv);
+                E.seg_end();
+                CBC_TS(1);                                    /* edits of one record */
+                if (E.q_len >= CBC_BATCH_MIN) E.drain();      /* hand over once a few records' symbols are pending */
+            }
+        }
+        if (E.status == CBC_ST_OK) { gen_sentinel(); E.seg_end(); }
+#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+        if (E.cap_var >= 64u) for (int i = 0; i < 16; i++) {   /* diagnostic build: tail of the event area */
+            W::write_uni(E.var_ev + E.cap_var - 32u, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.var_ev + E.cap_var - 32u, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
+#endif
+        E.publish(CBC_BF_LAST, 0ull);                         /* carries the status if a check failed */
+        return;
     }
 
-    /* ---- end-of-stream sentinel compress_rname("\n") (compression.c:152) + flush ---- */
+    /* ========================== coder wavefront / fused emulation =========================== */
+    const bool fused = ROLE == CBC_ROLE_FUSED;
+    if (E.status == CBC_ST_OK) { if (fused) { gen_header(); E.seg_end(); } else E.seg_consume(); }
+    for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
+        V32 r_pos, r_fl, r_seq, r_tok;
+        const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
+        E.cur_read = c0;
+        uint64_t neq;
+        if (fused) {
+            if (!load_group(c0, r_pos, r_fl, r_seq, r_tok, true)) break;
+            neq = match_group(cn, r_pos, r_fl, r_seq);
+        } else {
+            neq = E.pull_group();                             /* the model wave has validated the group */
+            if (E.status != CBC_ST_OK) break;
+            load_group(c0, r_pos, r_fl, r_seq, r_tok, false);
+        }
+        typename CbcEnc<W>::Fixed F;
+        E.fixed_group(F, c0, cn, r_pos, r_fl, neq);
+        /* totals and the scaled fractions of every fixed symbol of the group, one lane per record */
+        const V32 rdv = ln + c0;
+        const V32 sr_hi = rdv * 10u - 9u, sr_n = rdv * 10u + 2u;          /* same_ref symbol 0 of record r >= 1 */
+        const V32 sr_fh = CBC_FRAC(sr_hi, sr_n);
+        const V32 t_hi = rdv * 10u + 1u, t_n = rdv * 10u + 255u;          /* rlength[1..3] symbol 0; rlength[0]'s total */
+        const V32 t_fh = CBC_FRAC(t_hi, t_n);
+        const V32 rl_hi = F.rl_lo + F.rl_cnt;
+        const V32 rl_fl = CBC_FRAC(F.rl_lo, t_n), rl_fh = CBC_FRAC(rl_hi, t_n);
+        const V32 p_n = (F.p_card - 1u) * 10u + rdv * 10u + 1u, p_hi = F.p_lo + F.p_cnt;
+        const V32 p_fl = CBC_FRAC(F.p_lo, p_n), p_fh = CBC_FRAC(p_hi, p_n);
+        const V32 fl_n = rdv * 8u + 65536u, fl_hi = F.fl_lo + F.fl_cnt;
+        const V32 fl_fl = CBC_FRAC(F.fl_lo, fl_n), fl_fh = CBC_FRAC(fl_hi, fl_n);
+        const V32 m_hi = F.m_lo + F.m_cnt;
+        const V32 m_fl = CBC_FRAC(F.m_lo, F.m_n), m_fh = CBC_FRAC(m_hi, F.m_n);
+
+        for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
+            const uint32_t r = c0 + j;
+            E.cur_read = r;
+            if ((F.bad >> j) & 1ull) { E.fail(W::readlane(F.st, j)); break; }
+            /* -- compress_rname (id_compression.c:39-65): same_ref is (1,1) until record 0 codes symbol 1,
+             *    after which only symbol 0 is coded; the name itself is the model wave's segment -- */
+            if (r != 0u) E.step(0u, W::readlane(sr_hi, j), 10u * r + 2u, 0u, W::readlane(sr_fh, j));
+            else {
+                E.encode(1u, 1u, 2u); E.drain_q();
+                if (fused) { gen_rname(); E.seg_end(); } else E.seg_consume();
+                if (E.status != CBC_ST_OK) break;
+            }
+            /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1): rlength[0] from the group
+             *    pass; contexts 1..3 only ever code symbol 0, each once per record -- */
+            {
+                const uint32_t tn = 255u + 10u * r, th = W::readlane(t_hi, j), tf = W::readlane(t_fh, j);
+                E.step(W::readlane(F.rl_lo, j), W::readlane(rl_hi, j), tn, W::readlane(rl_fl, j), W::readlane(rl_fh, j));
+                E.step(0u, th, tn, 0u, tf);
+                E.step(0u, th, tn, 0u, tf);
+                E.step(0u, th, tn, 0u, tf);
+            }
+            /* -- compress_pos: hit, or escape + the four bytes of the new delta -- */
+            E.step(W::readlane(F.p_lo, j), W::readlane(p_hi, j), W::readlane(p_n, j), W::readlane(p_fl, j), W::readlane(p_fh, j));
+            if ((F.esc >> j) & 1ull) {
+                const uint32_t card = W::readlane(F.p_card, j);
+                E.pos_alpha(W::read_uni(E.pos_val, card), card);
+                E.drain_q();
+            }
+            /* -- compress_flag (read_compression.c:50-70), then the match flag -- */
+            E.step(W::readlane(F.fl_lo, j), W::readlane(fl_hi, j), 65536u + 8u * r, W::readlane(fl_fl, j), W::readlane(fl_fh, j));
+            E.step(W::readlane(F.m_lo, j), W::readlane(m_hi, j), W::readlane(F.m_n, j), W::readlane(m_fl, j), W::readlane(m_fh, j));
+            if ((neq >> j) & 1ull) {
+                if (fused) {
+                    const uint32_t so = W::readlane(r_seq, j), to = W::readlane(r_tok, j), flw = W::readlane(r_fl, j);
+                    const V32 bo = ln * 4u;
+                    const V32 seqv = W::load32_bytes(seqb + so, bo, bo < (flw >> 16));
+                    const V32 tokv = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
+                    gen_edits(W::readlane(r_pos, j), flw, to, seqv, tokv);
+                    E.seg_end();
+                } else E.seg_consume();
+            }
+        }
+    }
+    /* ---- end-of-stream sentinel (compression.c:152): same_ref symbol 1 at counts (1 + 10 (n - 1), 11),
+     *      then the model wave's two name symbols; flush ---- */
     uint32_t nbytes = 0;
     if (E.status == CBC_ST_OK) {
         E.cur_read = n_reads;
-        if (n_reads) E.encode(10u * n_reads - 9u, 11u, 10u * n_reads + 2u);    /* same_ref symbol 1: counts (1 + 10 (n-1), 11) */
+        if (n_reads) E.encode(10u * n_reads - 9u, 11u, 10u * n_reads + 2u);
         else E.encode(1u, 1u, 2u);
-        E.rname_code(E.prevChar, (uint32_t)'\n');
-        E.rname_code((uint32_t)'\n', 0u);
+        E.drain_q();
+        if (fused) { gen_sentinel(); E.seg_end(); } else E.seg_consume();
     }
-#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
-    if (ROLE == CBC_ROLE_MODEL && E.cap_var >= 64u) for (int i = 0; i < 16; i++) {   /* diagnostic build: tail of the event area */
-        W::write_uni(E.var_ev + E.cap_var - 32u, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.var_ev + E.cap_var - 32u, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
-#endif
-    if (ROLE == CBC_ROLE_MODEL) { E.publish(1u); return; }       /* last batch; carries the status if a model check failed */
-    E.drain();
-    if (E.status == CBC_ST_OK) nbytes = E.finish();
+    if (E.status == CBC_ST_OK) { E.flush_recs(); nbytes = E.finish(); }
     if (E.status != CBC_ST_OK) nbytes = 0;
+    if (!fused) E.pull_rest();
 #if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
-    if (out_cap >= 128u) for (int i = 0; i < 16; i++) {
+    if (payload_cap >= 128u) for (int i = 0; i < 16; i++) {   /* diagnostic build: over the payload start */
         W::write_uni(E.out32, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.out32, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
 #endif
     V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),

@@ -98,6 +98,21 @@ struct WaveGPU {
     static CBC_FN void lds_or(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) __hip_atomic_fetch_or(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     static CBC_FN void set_lane(V32 &v, uint32_t k, uint32_t val) { v = lane() == k ? val : v; }
     static CBC_FN V32 bswap_v(V32 x) { return __builtin_bswap32(x); }
+    /* A wave-uniform value deliberately kept in a VECTOR register: every lane computes the same thing.
+     * The coder recurrence uses it so that its ~50 operations per symbol go to the SIMD's vector unit
+     * (four per CU) instead of the CU's single scalar unit, which all resident wavefronts share.  uv()
+     * passes the value through an opaque v_mov so the compiler cannot prove it uniform and move the
+     * arithmetic back to the scalar unit. */
+    typedef uint32_t Uv;
+#ifndef CBC_CODER_SALU
+    static CBC_FN Uv uv(uint32_t x) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#else                             /* experiment: the recurrence on the scalar unit */
+    static CBC_FN Uv uv(uint32_t x) { return x; }
+#endif
+    static CBC_FN uint32_t uv_scalar(Uv x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    static CBC_FN Uv mulhi(Uv a, uint32_t b) { return __umulhi(a, b); }
+    static CBC_FN Uv clz_uv(Uv x) { return (uint32_t)__builtin_clz(x); }                  /* x != 0 */
+    static CBC_FN void set_lane_uv(V32 &v, uint32_t k, Uv val) { v = lane() == k ? val : v; }
     /* emulation-only cross-check hook */
     static CBC_FN void expect_eq(uint32_t, uint32_t, const char *) {}
 

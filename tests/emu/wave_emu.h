@@ -86,6 +86,12 @@ struct WaveEmu {
     static void lds_or(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[idx.v[i]] |= val.v[i]; }
     static void set_lane(V32 &v, uint32_t k, uint32_t val) { if (k >= 64) { emu_oob("set_lane index"); return; } v.v[k] = val; }
     static V32 bswap_v(const V32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = __builtin_bswap32(x.v[i]); return r; }
+    typedef uint32_t Uv;
+    static Uv uv(uint32_t x) { return x; }
+    static uint32_t uv_scalar(Uv x) { return x; }
+    static Uv mulhi(Uv a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+    static Uv clz_uv(Uv x) { return clz32(x); }
+    static void set_lane_uv(V32 &v, uint32_t k, Uv val) { set_lane(v, k, val); }
     static void expect_eq(uint32_t a, uint32_t b, const char *what) { if (a != b) emu_oob(what); }
     static V32 scan_incl_add(const V32 &v) { V32 r; uint32_t s = 0; for (int i = 0; i < 64; i++) { s += v.v[i]; r.v[i] = s; } return r; }
     static V32 load8(const uint8_t *p, const V32 &off, const Mask &m) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? p[off.v[i]] : 0u; return r; }
