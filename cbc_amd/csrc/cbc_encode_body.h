@@ -58,14 +58,16 @@
 #define CBC_LDS_RNEXC   (768u + CBC_CAP_NAME)      /* CBC_CAP_NAME                      */
 #define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* 256 words = 8192-bit Bloom filter on var ctx */
 #define CBC_LDS_VSLOT   (768u + 2u * CBC_CAP_NAME + 256u) /* 2 x 256: dense excess of the two hot var contexts */
-#define CBC_LDS_BATCH   (768u + 2u * CBC_CAP_NAME + 256u + 512u)  /* 2 x 196: symbol batches producer -> coder wave */
+#define CBC_LDS_BATCH   (768u + 2u * CBC_CAP_NAME + 256u + 512u)  /* CBC_BATCH_SLOTS x CBC_BATCH_WORDS: model wave -> coder wave */
 #ifndef CBC_BATCH_MIN
 #define CBC_BATCH_MIN   40u    /* <= 64 - 12 (a record's fixed symbols) - 4 (edit counts) - slack: see the 56 checks */
 #endif
 #define CBC_BATCH_WORDS 200u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record, match mask x2} */
 #define CBC_RING_WORDS  256u                       /* output bit ring of the coder wave (power of two) */
-#define CBC_LDS_RING    (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS)
-#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + 2u * CBC_BATCH_WORDS + CBC_RING_WORDS)
+#define CBC_BATCH_SLOTS 4u                         /* hand-off ring depth (power of two) */
+#define CBC_LDS_CTL     (768u + 2u * CBC_CAP_NAME + 256u + 512u + CBC_BATCH_SLOTS * CBC_BATCH_WORDS)   /* 8: produced, consumed */
+#define CBC_LDS_RING    (768u + 2u * CBC_CAP_NAME + 256u + 512u + CBC_BATCH_SLOTS * CBC_BATCH_WORDS + 8u)
+#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + CBC_BATCH_SLOTS * CBC_BATCH_WORDS + 8u + CBC_RING_WORDS)
 /* then pos_val[cap_pos], pos_occ[cap_pos], pos_pre[cap_pos]; the var-event list lives in global memory (see var_code) */
 
 #ifdef CBC_EMU_TRACE
@@ -114,7 +116,7 @@ struct CbcEnc {
     uint32_t *out32; uint32_t cap_words;
     uint32_t status, nsym, fail_read, cur_read;
     V32 q_lo, q_cnt, q_n; uint32_t q_len;   /* pending symbols: lane k = k-th queued (lo, cnt, n)      */
-    uint32_t role, batch_i; uint32_t *batch;  /* CBC_ROLE_*; hand-off buffers between the two waves     */
+    uint32_t role, batch_i; uint32_t *batch, *ctl;  /* CBC_ROLE_*; hand-off ring and its two counters in LDS */
     /* coder wave: the batch taken from the model wave (lane k = its k-th symbol) and the read cursor */
     V32 b_lo, b_hi, b_n, b_fl, b_fh; uint32_t b_len, b_pos, b_stop, b_flags, seen_last; uint64_t b_neq;
     V32 rec_a, rec_s; uint32_t rec_n;       /* output of the coder steps not packed yet (see pack())   */
@@ -241,12 +243,16 @@ struct CbcEnc {
      * fixed_group()'s lanes; the model wave owns the edit models and produces everything else as
      * SEGMENTS of the symbol stream, each closed by an END entry: the stream header, the contig name of
      * record 0, the edits of one imperfect record, the end-of-stream sentinel.  Segments travel in
-     * batches of <= 64 entries through one of two LDS buffers and a workgroup barrier: batch b goes to
-     * buffer b & 1; after barrier b the coder copies it into registers, so the model wave may refill
-     * that buffer once barrier b + 1 has passed.  Per group of 64 records the model wave also sends one
-     * empty batch flagged GROUP that carries the group's match-test mask.  Both waves execute exactly
-     * one barrier per batch, and the model wave always ends with a batch flagged LAST (which carries
-     * its status): whatever happens, the coder takes batches until it has seen LAST. */
+     * batches of <= 64 entries through a ring of CBC_BATCH_SLOTS LDS buffers guarded by two counters in
+     * LDS, `produced` (written by the model wave only) and `consumed` (written by the coder wave only):
+     * the model wave fills slot produced % SLOTS once produced - consumed < SLOTS and then bumps
+     * `produced` with release order; the coder waits for produced > consumed, copies the slot into
+     * registers and bumps `consumed`.  The ring lets the model wave run several batches ahead, which
+     * absorbs the burstiness of the two sides (a run of perfect records costs the coder time and the
+     * model wave none; an imperfect record the reverse).  Per group of 64 records the model wave also
+     * sends one empty batch flagged GROUP that carries the group's match-test mask.  The model wave
+     * always ends with a batch flagged LAST (which carries its status) and never waits after it;
+     * whatever happens, the coder takes batches until it has seen LAST, so both waves run to their end. */
 #define CBC_FRAC(c, n) W::frac32(c, n)
 #define CBC_BF_LAST  1u
 #define CBC_BF_GROUP 2u
@@ -265,17 +271,18 @@ struct CbcEnc {
     CBC_MFN void publish(uint32_t flags, uint64_t neq)
     {
         V32 ln = W::lane();
-        uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
+        CBC_TSM(5);
+        while (batch_i - W::ctl_load(ctl + 1) >= CBC_BATCH_SLOTS) W::nap();      /* a free slot */
+        CBC_TSM(6);                                          /* model wave: waiting for the coder */
+        uint32_t *buf = batch + (batch_i & (CBC_BATCH_SLOTS - 1u)) * CBC_BATCH_WORDS;
         Mask m = ln < q_len;
         W::store32(buf, ln, q_lo, m); W::store32(buf + 64u, ln, q_cnt, m); W::store32(buf + 128u, ln, q_n, m);
         V32 hdr = W::select(ln == 0u, W::splat(q_len), W::select(ln == 1u, W::splat(flags),
                   W::select(ln == 2u, W::splat(status), W::select(ln == 3u, W::splat(status == CBC_ST_OK ? cur_read : fail_read),
                   W::select(ln == 4u, W::splat((uint32_t)neq), W::splat((uint32_t)(neq >> 32)))))));
         W::store32(buf + 192u, ln, hdr, ln < 6u);
-        CBC_TSM(5);
-        W::barrier();
-        CBC_TSM(6);                                          /* model wave: waiting at the hand-off */
         batch_i++;
+        W::ctl_store(ctl, batch_i);                          /* release: the slot's words are in LDS before the count */
         q_len = 0;
     }
     /* one symbol through the coder; the step's output waits in rec_a / rec_s for pack() */
@@ -312,9 +319,9 @@ struct CbcEnc {
     {
         V32 ln = W::lane();
         CBC_TSM(9);                                           /* coder wave: coding */
-        W::barrier();
+        while (W::ctl_load(ctl) == batch_i) W::nap();         /* acquire: the next batch is in its slot */
         CBC_TSM(10);                                          /* coder wave: waiting for a batch */
-        const uint32_t *buf = batch + (batch_i & 1u) * CBC_BATCH_WORDS;
+        const uint32_t *buf = batch + (batch_i & (CBC_BATCH_SLOTS - 1u)) * CBC_BATCH_WORDS;
         V32 hdr = W::load32(buf + 192u, ln, ln < 6u, 0u);
         const uint32_t len = W::readlane(hdr, 0u);
         const uint32_t pst = W::readlane(hdr, 2u), prec = W::readlane(hdr, 3u);
@@ -329,6 +336,7 @@ struct CbcEnc {
         const uint64_t bad = W::ballot(m & ((cnt == 0u) | (b_n == 0u)));
         b_stop = bad ? W::ctz64(bad) : 64u;
         batch_i++;
+        W::ctl_store(ctl + 1, batch_i);                       /* release: the slot has been copied to registers */
         if (b_flags & CBC_BF_LAST) seen_last = 1u;
         if (pst != CBC_ST_OK && status == CBC_ST_OK) { status = pst; fail_read = prec; }
     }
@@ -901,7 +909,11 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);
     E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
     E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
-    E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH;
+    E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH; E.ctl = lds + CBC_LDS_CTL;
+    if (ROLE != CBC_ROLE_FUSED) {                            /* the only barrier: the counters start at zero for both waves */
+        if (ROLE == CBC_ROLE_MODEL) { W::write_uni(E.ctl, 0u, 0u); W::write_uni(E.ctl, 1u, 0u); }
+        W::barrier();
+    }
     /* the block's out area: [0, payload_cap) payload, [payload_cap, out_cap) its var-event list */
     const uint32_t payload_cap = bd->reserved;
     E.out32 = (uint32_t *)(A.out + out_off);

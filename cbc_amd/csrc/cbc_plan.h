@@ -10,7 +10,7 @@
 #include "../../include/cbc_gpu.h"
 
 /* must match CBC_LDS_FIXED in cbc_encode_body.h */
-#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u + 400u + 256u)
+#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u + 4u * 200u + 8u + 256u)
 
 /* LDS per wavefront: fixed tables + the POS alphabet.  The var-event list is NOT in LDS: it lives in
  * global memory behind the block's payload area (encode) / in the decode scratch, so caps->cap_var

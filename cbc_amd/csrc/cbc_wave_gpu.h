@@ -113,6 +113,18 @@ struct WaveGPU {
     static CBC_FN Uv mulhi(Uv a, uint32_t b) { return __umulhi(a, b); }
     static CBC_FN Uv clz_uv(Uv x) { return (uint32_t)__builtin_clz(x); }                  /* x != 0 */
     static CBC_FN void set_lane_uv(V32 &v, uint32_t k, Uv val) { v = lane() == k ? val : v; }
+    /* the hand-off counters in LDS: a real ds_read per poll (acquire), a store ordered after the wave's
+     * earlier LDS traffic (release), and a short sleep between polls so a waiting wave leaves the issue
+     * slots to the others */
+    static CBC_FN uint32_t ctl_load(const uint32_t *p)
+    {
+        return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    static CBC_FN void ctl_store(uint32_t *p, uint32_t v)
+    {
+        if (lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    static CBC_FN void nap() { __builtin_amdgcn_s_sleep(2); }
     /* emulation-only cross-check hook */
     static CBC_FN void expect_eq(uint32_t, uint32_t, const char *) {}
 
