@@ -220,3 +220,70 @@ def test_soft_clips(enc, built):
     pb = host.pack_sam(sam, fa, block_reads=256)
     _check_blocks(enc, pb, sam)
     _gpu_roundtrip(enc, pb, sam, fa)
+
+
+# ------------------------------------------------------------------ two-wavefront hand-off, edge shapes
+def _gpu_vs_emu(enc, pb):
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)
+    ep, eres = blockref.emu_encode(pb)
+    assert (res["status"] == eres["status"]).all() and (res["fail_read"] == eres["fail_read"]).all()
+    assert payloads == ep
+    assert (res["n_symbols"] == eres["n_symbols"]).all()
+    return payloads, res
+
+
+@pytest.mark.parametrize("n_reads", [2, 63, 64, 65, 128, 129, 1000])
+def test_group_boundaries(enc, built, n_reads):
+    """Record counts around the 64-record group size: the GROUP batches and the last, partial group."""
+    fa, sam, _, _ = synth.dataset(40 + n_reads, [40000], [n_reads], 100, sub_rate=0.01, indel_frac=0.1)
+    pb = host.pack_sam(sam, fa, block_reads=4096)
+    _check_blocks(enc, pb, sam)
+
+
+def test_all_perfect_and_all_imperfect_blocks(enc, built):
+    """Groups with no imperfect record (GROUP batches only, no segments) and groups where every record has
+    many edits (segments spill over several batches while the coder is still on earlier ones)."""
+    fa, sam, _, _ = synth.dataset(71, [200000], [3000], 150, sub_rate=0.0, indel_frac=0.0)
+    pb = host.pack_sam(sam, fa, block_reads=1024)
+    _check_blocks(enc, pb, sam)
+    fa, sam, _, _ = synth.dataset(72, [200000], [3000], 150, sub_rate=0.06, indel_frac=0.9)
+    pb = host.pack_sam(sam, fa, block_reads=1024)
+    _check_blocks(enc, pb, sam)
+
+
+def test_long_contig_name_segment(enc, built):
+    """A 120-character RNAME: the name segment spans several batches before the first record's symbols."""
+    name = "chr_" + "x" * 116
+    fa, sam, _, _ = synth.dataset(73, [50000], [500], 100, names=[name])
+    pb = host.pack_sam(sam, fa, block_reads=256)
+    _check_blocks(enc, pb, sam)
+
+
+def test_many_small_blocks_fill_the_gpu(enc, built):
+    """Thousands of 64..200-record blocks: every CU holds many workgroups, each with its own ring."""
+    pb = host.synth(9, 30_000_000, 400_000, 150, block_reads=128)
+    assert pb.n_blocks > 3000
+    _gpu_vs_emu(enc, pb)
+
+
+def test_failures_on_either_wavefront_end_the_block_cleanly(enc, built):
+    """A model-side abort (MD inconsistent with the read: reference assert) and a coder-side one (POS table
+    cap) in a batch of otherwise good blocks: statuses equal the emulation's, the other blocks are intact."""
+    fa, sam, rbc, _ = synth.dataset(15, [100000], [700], 100, sub_rate=0.0, indel_frac=0.0)
+    r = rbc[0][2][350]
+    seq = bytearray(r["seq"]); seq[10] = ord("A") if seq[10] != ord("A") else ord("C")
+    r["seq"] = bytes(seq); r["md"] = "10%s89" % chr(seq[10])
+    pb = host.pack_sam(synth.sam_text(rbc), fa, block_reads=100)
+    payloads, res = _gpu_vs_emu(enc, pb)
+    assert int(res[3]["status"]) == 2 and int(res[3]["fail_read"]) == 50 and payloads[3] == b""
+    assert all(int(s) == 0 for i, s in enumerate(res["status"]) if i != 3)
+    # coder side: sparse positions with a POS table smaller than the block needs
+    pb = host.synth(4, 200_000_000, 3000, 150, block_reads=1000, max_cap_pos=4096)
+    assert pb.cap_pos > 64
+    pb.cap_pos = 64                                   # both the GPU call and the emulation take the caps from here
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)
+    ep, eres = blockref.emu_encode(pb)
+    assert (res["status"] == eres["status"]).all() and (res["fail_read"] == eres["fail_read"]).all()
+    assert (res["status"] == 3).all() and payloads == ep            # CBC_ST_CAP_POS
