@@ -392,7 +392,21 @@ struct CbcEnc {
         l ^= lo; u ^= hi + n; k1 = W::uv(0u); bits = k1; sc = k1; return;
 #endif
         const Uv range = u - l + 1u;
+#ifndef CBC_DIV_ALWAYS_EXACT
+        /* range * f = q * 2^32 + t: the true quotient is q + (t + range * g / n) / 2^32 with g < n the
+         * remainder of f's own division, and range <= 2^26, so q is final unless t >= 2^32 - 2^26
+         * (one step in 64 for a random t, and always when cum + count = n, where f is the clamped
+         * 2^32 - 1).  Only then is the remainder formed: one 32x32->64 multiply per division on the
+         * usual path instead of three quarter-rate ones. */
+        Uv ql, qh, tl, th;
+        W::mul64(range, flo, ql, tl); W::mul64(range, fhi, qh, th);
+        if (W::uv_scalar(tl | th) >= 0xfc000000u) {
+            ql += (range * lo - ql * n >= n) ? 1u : 0u;
+            qh += (range * hi - qh * n >= n) ? 1u : 0u;
+        }
+#else
         const Uv ql = scaled_div(range, lo, n, flo), qh = scaled_div(range, hi, n, fhi);
+#endif
         W::expect_eq(W::uv_scalar(ql), (uint32_t)((uint64_t)W::uv_scalar(range) * lo / n), "scaled_div(cum)");
         W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi / n), "scaled_div(cum + count)");
         u = l + qh - 1u;
