@@ -27,15 +27,11 @@
 
 /* LDS words of the decoder: the encoder's tables (its batch area is reused here for the scratch read
  * and the deletion list), then the 4 x 256 pos_alpha byte histograms as u16 pairs and the insertion list */
-#define CBC_DLDS_TMP     CBC_LDS_BATCH                 /* 80 words: insertion-free read, bytes      */
-#define CBC_DLDS_DELS    (CBC_LDS_BATCH + 80u)         /* 256: deletion positions (matched coords)  */
-#define CBC_DLDS_HIST    CBC_LDS_FIXED                 /* 512: registered POS deltas per byte value, u16 x 2 per word */
-#define CBC_DLDS_INS     (CBC_LDS_FIXED + 512u)        /* 256: (output index << 8) | base char      */
-#define CBC_DLDS_FIXED   (CBC_LDS_FIXED + 768u)
-/* then pos_val[cap_pos], pos_cnt[cap_pos]; the var-event list is in global scratch (cap_var words per block) */
-#if (80u + 256u) > 2u * CBC_BATCH_WORDS
-#error "decoder scratch does not fit the encoder's batch area"
-#endif
+#define CBC_DLDS_TMP     CBC_PLAN_TABLE_WORDS          /* 80 words: insertion-free read, bytes      */
+#define CBC_DLDS_DELS    (CBC_PLAN_TABLE_WORDS + 80u)  /* 256: deletion positions (matched coords)  */
+#define CBC_DLDS_HIST    (CBC_PLAN_TABLE_WORDS + CBC_PLAN_DLDS_SCRATCH_WORDS)   /* 512: registered POS deltas per byte value, u16 x 2 per word */
+#define CBC_DLDS_INS     (CBC_DLDS_HIST + 512u)        /* 256: (output index << 8) | base char      */
+#define CBC_DLDS_FIXED   CBC_PLAN_DLDS_FIXED_WORDS
 
 struct cbc_dec_args {
     const uint8_t            *in;         /* payload bytes of all blocks                    */
@@ -560,6 +556,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     uint8_t *tmpb = (uint8_t *)(lds + CBC_DLDS_TMP);
     uint32_t *dels = lds + CBC_DLDS_DELS, *insl = lds + CBC_DLDS_INS;
 
+    V32 pend_w = W::splat(0u); uint8_t *pend_dst = seqo; uint32_t pend_rl = 0;
     for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) {
         D.cur_read = r;
         /* -- decompress_rname (id_compression.c:67-94) -- */
@@ -608,8 +605,11 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         uint8_t *dst = seqo + (uint64_t)r * stride;
         V32 bo = ln * 4u;
         if (match) {
-            V32 w = W::load32_bytes(refb + (pos - 1u), bo, bo < rl);
-            W::store32_bytes(dst, bo, w, bo < rl);                 /* stride >= rl rounded to 4 */
+            /* a perfect read is a copy of the reference window: the load is issued now, the store goes out
+             * when the next perfect read comes by (or at the end), so the wave never sits on the load */
+            if (pend_rl) W::store32_bytes(pend_dst, bo, pend_w, bo < pend_rl);
+            pend_w = W::load32_bytes(refb + (pos - 1u), bo, bo < rl);
+            pend_dst = dst; pend_rl = rl;                          /* stride >= rl rounded to 4 */
         } else {
             uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
             if (D.status == CBC_ST_OK && nSnp == 0u) {
@@ -682,6 +682,8 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         V32 rv0 = W::splat(pos), rv1 = W::splat(flag | (rl << 16)), rv2 = W::splat(r * stride), rv3 = W::splat(0u);
         W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
     }
+
+    if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, pend_w, (ln * 4u) < pend_rl);
 
     /* sentinel: same_ref(1), '\n', NUL (compression.c:152; decompress_rname returns -1 on it) */
     if (D.status == CBC_ST_OK) {

@@ -34,6 +34,7 @@
 
 #include <stdint.h>
 #include "../../include/cbc_gpu.h"
+#include "cbc_plan.h"
 
 #define CBC_AWORD     26u
 #define CBC_M26       ((1u << 26) - 1u)
@@ -58,16 +59,13 @@
 #define CBC_LDS_RNEXC   (768u + CBC_CAP_NAME)      /* CBC_CAP_NAME                      */
 #define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* 256 words = 8192-bit Bloom filter on var ctx */
 #define CBC_LDS_VSLOT   (768u + 2u * CBC_CAP_NAME + 256u) /* 2 x 256: dense excess of the two hot var contexts */
-#define CBC_LDS_BATCH   (768u + 2u * CBC_CAP_NAME + 256u + 512u)  /* CBC_BATCH_SLOTS x CBC_BATCH_WORDS: model wave -> coder wave */
+#define CBC_LDS_BATCH   CBC_PLAN_TABLE_WORDS       /* CBC_BATCH_SLOTS x CBC_BATCH_WORDS: model wave -> coder wave */
 #ifndef CBC_BATCH_MIN
 #define CBC_BATCH_MIN   40u    /* <= 64 - 12 (a record's fixed symbols) - 4 (edit counts) - slack: see the 56 checks */
 #endif
-#define CBC_BATCH_WORDS 200u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record, match mask x2} */
-#define CBC_RING_WORDS  256u                       /* output bit ring of the coder wave (power of two) */
-#define CBC_BATCH_SLOTS 4u                         /* hand-off ring depth (power of two) */
-#define CBC_LDS_CTL     (768u + 2u * CBC_CAP_NAME + 256u + 512u + CBC_BATCH_SLOTS * CBC_BATCH_WORDS)   /* 8: produced, consumed */
-#define CBC_LDS_RING    (768u + 2u * CBC_CAP_NAME + 256u + 512u + CBC_BATCH_SLOTS * CBC_BATCH_WORDS + 8u)
-#define CBC_LDS_FIXED   (768u + 2u * CBC_CAP_NAME + 256u + 512u + CBC_BATCH_SLOTS * CBC_BATCH_WORDS + 8u + CBC_RING_WORDS)
+#define CBC_LDS_CTL     (CBC_LDS_BATCH + CBC_BATCH_SLOTS * CBC_BATCH_WORDS)   /* 8: produced, consumed */
+#define CBC_LDS_RING    (CBC_LDS_CTL + 8u)
+#define CBC_LDS_FIXED   CBC_PLAN_LDS_FIXED_WORDS
 /* then pos_val[cap_pos], pos_occ[cap_pos], pos_pre[cap_pos]; the var-event list lives in global memory (see var_code) */
 
 #ifdef CBC_EMU_TRACE

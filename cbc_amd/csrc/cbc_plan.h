@@ -9,8 +9,17 @@
 #include <string.h>
 #include "../../include/cbc_gpu.h"
 
-/* must match CBC_LDS_FIXED in cbc_encode_body.h */
-#define CBC_PLAN_LDS_FIXED_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u + 4u * 200u + 8u + 256u)
+/* LDS layout constants, in 32-bit words (the kernel bodies take them from here).
+ * [0, CBC_PLAN_TABLE_WORDS): model tables shared by encoder and decoder bodies:
+ *   256 rlength, 256 snps, 256 indels, 2 x CBC_CAP_NAME contig-name pairs, 256 Bloom filter, 2 x 256 hot var slots */
+#define CBC_PLAN_TABLE_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u)
+#ifndef CBC_BATCH_SLOTS
+#define CBC_BATCH_SLOTS 4u                         /* encoder hand-off ring depth (power of two) */
+#endif
+#define CBC_BATCH_WORDS 200u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record, match mask x2} */
+#define CBC_RING_WORDS  256u                       /* output bit ring of the coder wave (power of two) */
+/* encoder: tables, hand-off ring, its two counters (8 words), output ring; then 3 x cap_pos */
+#define CBC_PLAN_LDS_FIXED_WORDS (CBC_PLAN_TABLE_WORDS + CBC_BATCH_SLOTS * CBC_BATCH_WORDS + 8u + CBC_RING_WORDS)
 
 /* LDS per wavefront: fixed tables + the POS alphabet.  The var-event list is NOT in LDS: it lives in
  * global memory behind the block's payload area (encode) / in the decode scratch, so caps->cap_var
@@ -20,9 +29,11 @@ static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
     return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 3u * caps->cap_pos);   /* pos_val, pos_occ, pos_pre */
 }
 
-/* decoder: the encoder's fixed tables + pos_alpha histograms + edit lists + scratch read
- * (must match CBC_DLDS_FIXED in cbc_decode_body.h) */
-#define CBC_PLAN_DLDS_FIXED_WORDS (CBC_PLAN_LDS_FIXED_WORDS + 768u)
+/* decoder: tables, 80 words scratch read + 256 deletion positions, 512 pos_alpha histograms, 256 insertions;
+ * then 2 x cap_pos.  It does not carry the encoder's rings: its LDS footprint decides how many blocks
+ * a CU holds, and with one wavefront per block that is the decoder's only latency hiding. */
+#define CBC_PLAN_DLDS_SCRATCH_WORDS 336u
+#define CBC_PLAN_DLDS_FIXED_WORDS (CBC_PLAN_TABLE_WORDS + CBC_PLAN_DLDS_SCRATCH_WORDS + 768u)
 static inline uint32_t cbc_plan_dec_lds_bytes(const cbc_lds_caps *caps)
 {
     return 4u * (CBC_PLAN_DLDS_FIXED_WORDS + 2u * caps->cap_pos);

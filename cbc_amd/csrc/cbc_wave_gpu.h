@@ -104,11 +104,7 @@ struct WaveGPU {
      * passes the value through an opaque v_mov so the compiler cannot prove it uniform and move the
      * arithmetic back to the scalar unit. */
     typedef uint32_t Uv;
-#ifndef CBC_CODER_SALU
     static CBC_FN Uv uv(uint32_t x) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
-#else                             /* experiment: the recurrence on the scalar unit */
-    static CBC_FN Uv uv(uint32_t x) { return x; }
-#endif
     static CBC_FN uint32_t uv_scalar(Uv x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
     static CBC_FN Uv mulhi(Uv a, uint32_t b) { return __umulhi(a, b); }
     static CBC_FN void mul64(Uv a, uint32_t b, Uv &hi, Uv &lo) { uint64_t p = (uint64_t)a * b; hi = (uint32_t)(p >> 32); lo = (uint32_t)p; }
@@ -213,6 +209,14 @@ struct WaveGPU {
     static CBC_FN uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }     /* x != 0 */
     static CBC_FN uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
     static CBC_FN uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+};
+
+/* The same policy with the coder recurrence left on the scalar unit (uv() is the identity, so the
+ * compiler sees a uniform value).  The kernel gives it to a fraction of the blocks: at saturation a
+ * vector instruction costs a CU about as much as a scalar one (4 cycles on one of 4 SIMDs vs 1 cycle on
+ * the one scalar unit), so the best split of the coder waves is the one that levels the two queues. */
+struct WaveGPUS : WaveGPU {
+    static CBC_FN Uv uv(uint32_t x) { return x; }
 };
 
 #endif

@@ -287,3 +287,32 @@ def test_failures_on_either_wavefront_end_the_block_cleanly(enc, built):
     ep, eres = blockref.emu_encode(pb)
     assert (res["status"] == eres["status"]).all() and (res["fail_read"] == eres["fail_read"]).all()
     assert (res["status"] == 3).all() and payloads == ep            # CBC_ST_CAP_POS
+
+
+def test_piece_by_piece_bit_packing_on_the_gpu(built):
+    """pack() places strings longer than 32 bits (long E3 runs) piece by piece; that path is rare.  A test
+    build of the same kernels takes it for every string longer than 9 bits: its payloads must equal the
+    oracle's too.  Runs in a child process because the library is chosen at import time."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "cbc_amd", "csrc", "libcbc_gpu_serialpack.so")
+    assert os.path.exists(lib)
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import synth, blockref
+        from cbc_amd import gpu, host
+        from oracle import oracle
+        fa, sam, _, _ = synth.dataset(91, [300000], [6000], 150, sub_rate=0.01, indel_frac=0.2)
+        pb = host.pack_sam(sam, fa, block_reads=1500)
+        enc = gpu.Encoder(0); enc.upload_reference(pb.ref)
+        payloads, res, offs, flat = enc.encode_blocks(pb)
+        assert (res["status"] == 0).all()
+        lines = blockref.mapped_sam_lines(sam)
+        for b in range(pb.n_blocks):
+            bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
+            assert payloads[b] == oracle.encode(bsam, bfa), b
+        print("SERIALPACK_OK", pb.n_blocks)
+    """ % (root, os.path.join(root, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CBC_GPU_LIB=lib), capture_output=True, text=True)
+    assert "SERIALPACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
