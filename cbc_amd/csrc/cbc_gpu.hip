@@ -40,14 +40,7 @@ cbc_encode_blocks_kernel(cbc_enc_args A)
     if (blk >= A.n_blocks) return;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wid == 0u) cbc_encode_stream<WaveGPU, CBC_ROLE_MODEL>(A, blk, cbc_lds);
-    else {
-#ifndef CBC_SCALAR_CODER_EVERY
-#define CBC_SCALAR_CODER_EVERY 0u          /* every n-th block's coder runs on the scalar unit (0 = none) */
-#endif
-        if (CBC_SCALAR_CODER_EVERY != 0u && A.n_blocks >= 2048u && blk % (CBC_SCALAR_CODER_EVERY ? CBC_SCALAR_CODER_EVERY : 1u) == 0u)
-            cbc_encode_stream<WaveGPUS, CBC_ROLE_CODER>(A, blk, cbc_lds);
-        else cbc_encode_stream<WaveGPU, CBC_ROLE_CODER>(A, blk, cbc_lds);
-    }
+    else cbc_encode_stream<WaveGPU, CBC_ROLE_CODER>(A, blk, cbc_lds);
 }
 
 __global__ void __launch_bounds__(64)

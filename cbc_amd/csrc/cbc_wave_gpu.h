@@ -211,12 +211,4 @@ struct WaveGPU {
     static CBC_FN uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 };
 
-/* The same policy with the coder recurrence left on the scalar unit (uv() is the identity, so the
- * compiler sees a uniform value).  The kernel gives it to a fraction of the blocks: at saturation a
- * vector instruction costs a CU about as much as a scalar one (4 cycles on one of 4 SIMDs vs 1 cycle on
- * the one scalar unit), so the best split of the coder waves is the one that levels the two queues. */
-struct WaveGPUS : WaveGPU {
-    static CBC_FN Uv uv(uint32_t x) { return x; }
-};
-
 #endif
