@@ -30,9 +30,10 @@ extern __shared__ uint32_t cbc_lds[];
 __global__ void __launch_bounds__(128)
 cbc_encode_blocks_kernel(cbc_enc_args A)
 {
-    /* One workgroup = one block = one arithmetic stream, coded by TWO wavefronts in a pipeline:
-     * wavefront 0 runs the context models and produces (lo, cnt, n) batches in LDS, wavefront 1 runs
-     * the range coder on them (cbc_encode_body.h, CbcEnc::publish / consume_all).
+    /* One workgroup = one block = one arithmetic stream, coded by TWO wavefronts: wavefront 0 (model)
+     * runs the match test and the edit models and sends END-terminated segments of the symbol stream
+     * through an LDS ring; wavefront 1 (coder) owns the per-record models, computes their symbols one
+     * lane per record and runs the range coder (cbc_encode_body.h, CbcEnc::publish / pull).
      * Workgroups are dealt round-robin to the 8 XCDs; blocks of one contig are neighbours in the
      * batch and share nothing but read-only reference lines, so the identity map is kept and the
      * per-XCD L2s each see a strided slice of the record stream. */
