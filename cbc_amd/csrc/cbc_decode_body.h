@@ -33,6 +33,16 @@
 #define CBC_DLDS_INS     (CBC_DLDS_HIST + 512u)        /* 256: (output index << 8) | base char      */
 #define CBC_DLDS_FIXED   CBC_PLAN_DLDS_FIXED_WORDS
 
+/* CBC_DSTAMP: diagnostic build only (cf. CBC_STAMP in cbc_encode_body.h): per-section s_memtime sums of the decode loop,
+ * written over the start of the block's SEQ output -- outputs of such a build are garbage by design. */
+#if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
+#define CBC_DT0() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dt_last) :: "memory"); } while (0)
+#define CBC_DT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dt_sum[k] += t_ - dt_last; dt_last = t_; } while (0)
+#else
+#define CBC_DT0() do {} while (0)
+#define CBC_DT(k) do {} while (0)
+#endif
+
 struct cbc_dec_args {
     const uint8_t            *in;         /* payload bytes of all blocks                    */
     const cbc_dec_block_desc *blocks;
@@ -102,16 +112,9 @@ struct CbcDec {
         uint64_t p = (uint64_t)gap * n - 1u;
         return W::divq(p, range);
     }
-    /* arithmetic_decoder_step, Arithmetic_stream.c:389-454, loops in closed form (cf. CbcEnc::code1) */
-    CBC_MFN void step(uint32_t lo, uint32_t cnt, uint32_t n)
+    /* the E1/E2 and E3 shifts of arithmetic_decoder_step (Arithmetic_stream.c:401-454) in closed form */
+    CBC_MFN void renorm()
     {
-        if (cnt == 0u || n == 0u || lo + cnt > n) { fail(CBC_ST_ASSERT); return; }
-        nsym++;
-        uint32_t range = u - l + 1u, qh, ql;
-        float inv = W::lane_float(W::recip_v(W::splat(n)), 0u);
-        W::muldiv2(range, lo, lo + cnt, n, inv, ql, qh);
-        u = l + qh - 1u;
-        l = l + ql;
         uint32_t x = l ^ u;
         uint32_t k1 = x ? (W::clz32(x) - 6u) : 26u;
         if (k1) {
@@ -128,6 +131,35 @@ struct CbcDec {
             u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
             t = (uint32_t)(((((uint64_t)t << k3) & CBC_M26) ^ (1u << 25)) | bits);
         }
+    }
+    /* A symbol that can only be symbol 0 of its model (same_ref after record 0, rlength[1..3]; their
+     * counts are closed forms of the record index because no rescale can happen below
+     * CBC_MAX_BLOCK_READS): no target division and no search -- the symbol is 0 exactly when the tag lies
+     * below the new upper bound l + floor(range * count0 / n) - 1, and `f` = floor(count0 * 2^32 / n) was
+     * computed for 64 records at once (cf. CbcEnc::code1 / scaled_div). */
+    CBC_MFN void step_known0(uint32_t cnt0, uint32_t n, uint32_t f)
+    {
+        nsym++;
+        const uint32_t range = u - l + 1u;
+        const uint64_t p = (uint64_t)range * f;
+        uint32_t q = (uint32_t)(p >> 32);
+        if ((uint32_t)p >= 0xfc000000u) q += (range * cnt0 - q * n >= n) ? 1u : 0u;
+        W::expect_eq(q, (uint32_t)((uint64_t)range * cnt0 / n), "step_known0 quotient");
+        if (q == 0u || t - l >= q) { fail(CBC_ST_ASSERT); return; }        /* another symbol was coded here */
+        u = l + q - 1u;
+        renorm();
+    }
+    /* arithmetic_decoder_step, Arithmetic_stream.c:389-454, loops in closed form (cf. CbcEnc::code1) */
+    CBC_MFN void step(uint32_t lo, uint32_t cnt, uint32_t n)
+    {
+        if (cnt == 0u || n == 0u || lo + cnt > n) { fail(CBC_ST_ASSERT); return; }
+        nsym++;
+        uint32_t range = u - l + 1u, qh, ql;
+        float inv = W::lane_float(W::recip_v(W::splat(n)), 0u);
+        W::muldiv2(range, lo, lo + cnt, n, inv, ql, qh);
+        u = l + qh - 1u;
+        l = l + ql;
+        renorm();
     }
 
     /* ---- lane-table literal models (match, same_ref, chars) ---- */
@@ -513,6 +545,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     D.nwords_in = (in_bytes + 3u) >> 2;
     D.tail_valid = in_bytes & 3u;
     if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
+    if (n_reads > CBC_MAX_BLOCK_READS) D.fail(CBC_ST_UNSUPPORTED);   /* the closed forms below assume no rescale */
 
     for (uint32_t b = 0; b < CBC_DLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_DLDS_FIXED);
     D.rlen_n = 255u; D.rl123_c0 = 1u; D.rl123_n = 255u; D.snps_n = L0; D.indels_n = L0; D.rn_count = 0;
@@ -557,12 +590,25 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     uint32_t *dels = lds + CBC_DLDS_DELS, *insl = lds + CBC_DLDS_INS;
 
     V32 pend_w = W::splat(0u); uint8_t *pend_dst = seqo; uint32_t pend_rl = 0;
+    V32 sr_fh = W::splat(0u), t_fh = W::splat(0u);
+#if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long dt_last = 0, dt_sum[16];
+    for (int i = 0; i < 16; i++) dt_sum[i] = 0;
+    CBC_DT0();
+#endif
     for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) {
         D.cur_read = r;
-        /* -- decompress_rname (id_compression.c:67-94) -- */
-        uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
-        if (D.status != CBC_ST_OK) break;
-        if (r == 0u) {
+        if ((r & 63u) == 0u) {                               /* scaled fractions of the closed-form symbols of 64 records */
+            const V32 rdv = ln + r;
+            sr_fh = W::frac32(rdv * 10u - 9u, rdv * 10u + 2u);     /* same_ref symbol 0 of record r >= 1 */
+            t_fh = W::frac32(rdv * 10u + 1u, rdv * 10u + 255u);    /* rlength[1..3] symbol 0 */
+        }
+        /* -- decompress_rname (id_compression.c:67-94): same_ref is (1,1) until record 0 takes symbol 1,
+         *    after which every record of the block must take symbol 0 (one contig per block) -- */
+        if (r != 0u) D.step_known0(10u * r - 9u, 10u * r + 2u, W::readlane(sr_fh, r & 63u));
+        else {
+            uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
+            if (D.status != CBC_ST_OK) break;
             if (sr != 1u) { D.fail(CBC_ST_ASSERT); break; }
             for (uint32_t q = 0; q < CBC_CAP_NAME && D.status == CBC_ST_OK; q++) {
                 uint32_t ch = D.rname_dec(D.prevChar);
@@ -571,21 +617,20 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
                 D.prevChar = ch;
             }
             D.prevPos = 0; D.win_clear();
-        } else if (sr != 0u) { D.fail(CBC_ST_ASSERT); break; }     /* one contig per block */
+        }
         if (D.status != CBC_ST_OK) break;
 
+        CBC_DT(0);                                            /* same_ref (+ name) */
         /* -- read length (read_decompression.c:68-74): only the low byte carries information (Q1) -- */
         uint32_t rl = D.dense_dec(D.tab(CBC_LDS_RLEN), 255u, 10u, D.rlen_n);
-        for (int k = 1; k < 4 && D.status == CBC_ST_OK; k++) {
-            uint32_t tg = D.target(D.rl123_n);
-            if (tg >= D.rl123_c0) { D.fail(CBC_ST_ASSERT); break; }
-            D.step(0u, D.rl123_c0, D.rl123_n);
+        {   /* contexts 1..3 only ever hold symbol 0 (quirk Q1), each coded once per record */
+            const uint32_t tf = W::readlane(t_fh, r & 63u);
+            for (int k = 1; k < 4 && D.status == CBC_ST_OK; k++) D.step_known0(10u * r + 1u, 10u * r + 255u, tf);
         }
-        D.rl123_c0 += 10u; D.rl123_n += 10u;
-        if (D.rl123_n >= CBC_RESCALE) { D.rl123_c0 = (D.rl123_c0 >> 1) + 1u; D.rl123_n = 254u + D.rl123_c0; }
         if (D.status != CBC_ST_OK) break;
         if (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride) { D.fail(CBC_ST_ASSERT); break; }
 
+        CBC_DT(1);                                            /* rlength x 4 */
         /* -- pos, flag -- */
         uint32_t x = D.pos_dec();
         if (D.status != CBC_ST_OK) break;
@@ -593,22 +638,28 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         uint32_t pos = D.prevPos + x - 1u;
         D.win_shift(r == 0u ? 256u : x - 1u);
         D.prevPos = pos;
+        CBC_DT(2);                                            /* pos */
         uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
         if (D.status != CBC_ST_OK) break;
         const uint32_t strand = (flag >> 4) & 1u;
         if (pos == 0u || pos + rl + 3u + 256u > ref_lim) { D.fail(CBC_ST_ASSERT); break; }
+        /* the reference window of the read, 4 bases per lane: issued now, needed after the match flag
+         * (perfect read: it IS the read) or after the edits (SNP-only read: patched in place) */
+        const V32 refw = W::load32_bytes(refb + (pos - 1u), ln * 4u, (ln * 4u) < rl);
 
+        CBC_DT(3);                                            /* flag */
         /* -- match -- */
         uint32_t match = D.small_dec(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | D.prevM) * 2u, 2u, 1u);
         if (D.status != CBC_ST_OK) break;
         D.prevM = match;
         uint8_t *dst = seqo + (uint64_t)r * stride;
         V32 bo = ln * 4u;
+        CBC_DT(4);                                            /* match */
         if (match) {
-            /* a perfect read is a copy of the reference window: the load is issued now, the store goes out
-             * when the next perfect read comes by (or at the end), so the wave never sits on the load */
+            /* a perfect read is a copy of the reference window (loaded above): the store goes out when the
+             * next such read comes by (or at the end), so the wave never sits on the load */
             if (pend_rl) W::store32_bytes(pend_dst, bo, pend_w, bo < pend_rl);
-            pend_w = W::load32_bytes(refb + (pos - 1u), bo, bo < rl);
+            pend_w = refw;
             pend_dst = dst; pend_rl = rl;                          /* stride >= rl rounded to 4 */
         } else {
             uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
@@ -619,6 +670,27 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             }
             if (D.status != CBC_ST_OK) break;
             if (nIns > rl) { D.fail(CBC_ST_ASSERT); break; }
+            if ((nDel | nIns) == 0u) {
+                /* SNPs only (read_decompression.c:440-458): the read is the reference window with a few
+                 * bytes replaced -- patched in the register that holds 4 bases per lane, no LDS scratch read */
+                V32 w = refw;
+                uint32_t p = 0;
+                for (uint32_t sidx = 0; sidx < nSnp && D.status == CBC_ST_OK; sidx++) {
+                    uint32_t dl = D.win_first(p, rl);
+                    uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
+                    if (D.status != CBC_ST_OK) break;
+                    uint32_t at = p + g;
+                    p += g + 1u;
+                    D.win_set(p - 1u);
+                    const uint32_t shf = (at & 3u) * 8u;
+                    uint32_t refch = at < rl ? ((W::readlane(w, (at >> 2) & 63u) >> shf) & 0xffu) : 0u;
+                    uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
+                    if (at < rl)
+                        w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w);
+                }
+                if (D.status != CBC_ST_OK) break;
+                W::store32_bytes(dst, bo, w, bo < rl);
+            } else {
             const uint32_t T = rl - nIns;                          /* insertion-free length */
             /* deletions: cumulative matched coordinate of each deleted base */
             uint32_t p = 0;
@@ -677,10 +749,13 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
                 ch = W::select(isins != 0u, ich, ch);
                 W::store8(dst, q, ch, q < rl);
             }
+            }
         }
+        CBC_DT(5);                                            /* copy / edits + reconstruction */
         /* record */
         V32 rv0 = W::splat(pos), rv1 = W::splat(flag | (rl << 16)), rv2 = W::splat(r * stride), rv3 = W::splat(0u);
         W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
+        CBC_DT(6);                                            /* record store */
     }
 
     if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, pend_w, (ln * 4u) < pend_rl);
@@ -688,6 +763,8 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     /* sentinel: same_ref(1), '\n', NUL (compression.c:152; decompress_rname returns -1 on it) */
     if (D.status == CBC_ST_OK) {
         D.cur_read = n_reads;
+        if (n_reads > 1u)                                    /* same_ref counts after n records: (1 + 10 (n - 1), 11) */
+            D.small = W::select(ln == CBC_LT_SAMEREF, W::splat(10u * n_reads - 9u), D.small);
         uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
         if (D.status == CBC_ST_OK && sr != 1u) D.fail(CBC_ST_ASSERT);
         if (D.status == CBC_ST_OK) {
@@ -696,6 +773,9 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             if (D.status == CBC_ST_OK && D.rname_dec((uint32_t)'\n') != 0u) D.fail(CBC_ST_ASSERT);
         }
     }
+#if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < 16; i++) { W::write_uni((uint32_t *)seqo, 2 * i, (uint32_t)dt_sum[i]); W::write_uni((uint32_t *)seqo, 2 * i + 1, (uint32_t)(dt_sum[i] >> 32)); }
+#endif
     V32 resv = W::select(ln == 0u, W::splat(D.status == CBC_ST_OK ? n_reads : D.cur_read), W::select(ln == 1u, W::splat(D.status),
                W::select(ln == 2u, W::splat(D.nsym), W::splat(D.fail_read))));
     W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);
