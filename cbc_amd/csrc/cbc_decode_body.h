@@ -72,6 +72,7 @@ struct CbcDec {
     uint32_t *lds, *evp;
     uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, cap_var, L0;
     uint32_t prevPos, prevM, prevChar;
+    uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
     uint32_t vtag0, vtag1, vsum0, vsum1;
     uint64_t w0, w1, w2, w3;
 
@@ -163,8 +164,33 @@ struct CbcDec {
     }
 
     /* ---- lane-table literal models (match, same_ref, chars) ---- */
+    /* a two-symbol literal-count model (match, same_ref): no target division and no search.  The tag lies in
+     * symbol 0's interval exactly when t - l < floor(range * count0 / n)  (the same test the target of
+     * Arithmetic_stream.c:373-381 would give: floor(((t-l+1) n - 1) / range) < count0), and symbol 1's
+     * upper bound is the old one, so one division decides and performs the step. */
+    CBC_MFN uint32_t bin_dec(uint32_t base, uint32_t stp)
+    {
+        const uint32_t c0 = W::readlane(small, base), c1 = W::readlane(small, base + 1u), n = c0 + c1;
+        if (c0 == 0u || c1 == 0u) { fail(CBC_ST_ASSERT); return 0u; }
+        nsym++;
+        const uint32_t range = u - l + 1u;
+        uint32_t q0, qn;
+        float inv = W::lane_float(W::recip_v(W::splat(n)), 0u);
+        W::muldiv2(range, c0, n, n, inv, q0, qn);
+        const uint32_t x = (t - l >= q0) ? 1u : 0u;
+        if (x == 0u) u = l + q0 - 1u; else l = l + q0;
+        renorm();
+        V32 ln = W::lane();
+        small = W::select(ln == base + x, small + stp, small);
+        if (n + stp >= CBC_RESCALE) {
+            Mask m = (ln >= base) & (ln < base + 2u);
+            small = W::select(m, (small >> 1) + 1u, small);
+        }
+        return x;
+    }
     CBC_MFN uint32_t small_dec(uint32_t base, uint32_t card, uint32_t stp)
     {
+        if (card == 2u) return bin_dec(base, stp);
         uint32_t n = 0;
         for (uint32_t j = 0; j < card; j++) n += W::readlane(small, base + j);
         uint32_t tg = target(n), lo = 0, cnt = 0, x = 0, found = 0;
@@ -272,6 +298,43 @@ struct CbcDec {
             a = a + W::select(m, e, W::splat(0u));
         }
         n = card + W::reduce_add(a);
+    }
+    /* rlength[0]: the same length nearly always repeats.  The previous symbol's (cum, count) are kept in
+     * scalars; the guess is verified with the two divisions the step needs anyway (the tag must lie in
+     * [l + floor(range cum / n), l + floor(range (cum + count) / n))), which replaces the target division
+     * and the table search.  On a miss the count is written back and the generic decode runs. */
+    CBC_MFN uint32_t rlen_dec()
+    {
+        uint32_t *exc = tab(CBC_LDS_RLEN);
+        if (rl_memo_x != CBC_NOMEMO) {
+            const uint32_t range = u - l + 1u;
+            uint32_t ql, qh;
+            float inv = W::lane_float(W::recip_v(W::splat(rlen_n)), 0u);
+            W::muldiv2(range, rl_memo_lo, rl_memo_lo + rl_memo_cnt, rlen_n, inv, ql, qh);
+            if (t - l >= ql && t - l < qh) {
+                nsym++;
+                u = l + qh - 1u; l = l + ql;
+                renorm();
+                rl_memo_cnt += 10u; rlen_n += 10u;
+                if (rlen_n >= CBC_RESCALE) {                   /* through the table: unreachable below CBC_MAX_BLOCK_READS */
+                    W::write_uni(exc, rl_memo_x, rl_memo_cnt - 1u);
+                    dense_rescale(exc, 255u, rlen_n);
+                    rl_memo_x = CBC_NOMEMO;
+                }
+                return rl_memo_x != CBC_NOMEMO ? rl_memo_x : rl_last_x;
+            }
+            W::write_uni(exc, rl_memo_x, rl_memo_cnt - 1u);
+            rl_memo_x = CBC_NOMEMO;
+        }
+        uint32_t tg = target(rlen_n), lo, cnt;
+        uint32_t x = dense_search(exc, 255u, 1u, tg, lo, cnt);
+        if (status != CBC_ST_OK) return 0u;
+        step(lo, cnt, rlen_n);
+        rlen_n += 10u;
+        if (rlen_n >= CBC_RESCALE) { W::write_uni(exc, x, cnt - 1u + 10u); dense_rescale(exc, 255u, rlen_n); }
+        else { rl_memo_x = x; rl_memo_lo = lo; rl_memo_cnt = cnt + 10u; }
+        rl_last_x = x;
+        return x;
     }
     CBC_MFN uint32_t dense_dec(uint32_t *exc, uint32_t card, uint32_t stp, uint32_t &n)
     {
@@ -565,6 +628,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         D.small = W::select(inch, cv, s);
     }
     D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
+    D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
     D.vtag0 = D.vtag1 = CBC_NOMEMO; D.vsum0 = D.vsum1 = 0;
 
     /* the tag: first 26 bits (alloc_arithmetic_stream, Arithmetic_stream.c:260-263) */
@@ -622,7 +686,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
 
         CBC_DT(0);                                            /* same_ref (+ name) */
         /* -- read length (read_decompression.c:68-74): only the low byte carries information (Q1) -- */
-        uint32_t rl = D.dense_dec(D.tab(CBC_LDS_RLEN), 255u, 10u, D.rlen_n);
+        uint32_t rl = D.rlen_dec();
         {   /* contexts 1..3 only ever hold symbol 0 (quirk Q1), each coded once per record */
             const uint32_t tf = W::readlane(t_fh, r & 63u);
             for (int k = 1; k < 4 && D.status == CBC_ST_OK; k++) D.step_known0(10u * r + 1u, 10u * r + 255u, tf);
@@ -663,6 +727,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             pend_dst = dst; pend_rl = rl;                          /* stride >= rl rounded to 4 */
         } else {
             uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
+            CBC_DT(7);                                        /* snps count */
             if (D.status == CBC_ST_OK && nSnp == 0u) {
                 nSnp = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
                 nDel = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
@@ -677,7 +742,9 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
                 uint32_t p = 0;
                 for (uint32_t sidx = 0; sidx < nSnp && D.status == CBC_ST_OK; sidx++) {
                     uint32_t dl = D.win_first(p, rl);
+                    CBC_DT(8);                                /* win_first */
                     uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
+                    CBC_DT(9);                                /* var_dec */
                     if (D.status != CBC_ST_OK) break;
                     uint32_t at = p + g;
                     p += g + 1u;
@@ -687,6 +754,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
                     uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
                     if (at < rl)
                         w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w);
+                    CBC_DT(10);                               /* chars + patch */
                 }
                 if (D.status != CBC_ST_OK) break;
                 W::store32_bytes(dst, bo, w, bo < rl);
