@@ -496,31 +496,40 @@ struct CbcDec {
         }
         V32 ln = W::lane();
         uint32_t *bloom = tab(CBC_LDS_BLOOM), *ev = var_ev_p();
-        const uint32_t h = (ctx * 0x9E3779B1u) >> 19;
-        const uint32_t bw = W::read_uni(bloom, h >> 5), bbit = 1u << (h & 31u);
+        /* the encoder's filter: two hash functions, both words fetched by one LDS instruction */
+        const uint32_t h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2), h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
+        const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
+        const uint32_t bw1 = W::readlane(bwv, 0u), bw2 = W::readlane(bwv, 1u);
+        const uint32_t bb1 = 1u << (h1 & 31u), bb2 = 1u << (h2 & 31u);
         /* per-symbol excess of this context, 4 symbols per lane, built from the event list */
         V32 e0 = W::splat(0u), e1 = W::splat(0u), e2 = W::splat(0u), e3 = W::splat(0u);
         uint32_t m = 0;
-        if (bw & bbit) {
+        if ((bw1 & bb1) && (bw2 & bb2)) {
             W::list_fence();
             const uint32_t nb = W::uni(nev);
-            for (uint32_t b = 0; b < nb; b += 64u) {
-                V32 i = ln + b; Mask mm = i < nev;
-                V32 e = W::load32_list(ev, i, mm, 0xffffffffu);
-                uint64_t bb = W::ballot(mm & ((e >> 8) == ctx));
-                while (bb) {
-                    uint32_t src = W::ctz64(bb); bb &= bb - 1u;
-                    uint32_t kk = W::readlane(e, src) & 0xffu;
-                    Mask hitl = ln == (kk >> 2);
-                    uint32_t sub = kk & 3u;
-                    e0 = W::select(hitl & (sub == 0u), e0 + 10u, e0);
-                    e1 = W::select(hitl & (sub == 1u), e1 + 10u, e1);
-                    e2 = W::select(hitl & (sub == 2u), e2 + 10u, e2);
-                    e3 = W::select(hitl & (sub == 3u), e3 + 10u, e3);
-                    m++;
+            for (uint32_t b = 0; b < nb; b += 256u) {             /* four loads in flight per trip */
+                V32 ev4[4];
+                for (uint32_t q = 0; q < 4u; q++) { V32 i = ln + (b + 64u * q); ev4[q] = W::load32_list(ev, i, i < nev, 0xffffffffu); }
+                for (uint32_t q = 0; q < 4u; q++) {
+                    const V32 e = ev4[q];
+                    uint64_t bb = W::ballot((e >> 8) == ctx);     /* lanes past nev hold 0xffffffff: ctx 0xffffff never matches */
+                    while (bb) {
+                        uint32_t src = W::ctz64(bb); bb &= bb - 1u;
+                        uint32_t kk = W::readlane(e, src) & 0xffu;
+                        Mask hitl = ln == (kk >> 2);
+                        uint32_t sub = kk & 3u;
+                        e0 = W::select(hitl & (sub == 0u), e0 + 10u, e0);
+                        e1 = W::select(hitl & (sub == 1u), e1 + 10u, e1);
+                        e2 = W::select(hitl & (sub == 2u), e2 + 10u, e2);
+                        e3 = W::select(hitl & (sub == 3u), e3 + 10u, e3);
+                        m++;
+                    }
                 }
             }
-        } else W::write_uni(bloom, h >> 5, bw | bbit);
+        } else {
+            if ((h1 >> 5) == (h2 >> 5)) W::write_uni(bloom, h1 >> 5, bw1 | bb1 | bb2);
+            else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
+        }
         uint32_t n = L0 + 10u * m;
         uint32_t tg = target(n), x, lo, cnt;
         if (m == 0u) { x = tg; lo = tg; cnt = 1u; }

@@ -42,6 +42,7 @@
 #define CBC_RESCALE   (1u << 20)
 #define CBC_NVARCTX   0xffffu
 #define CBC_NOMEMO    0xffffffffu
+#define CBC_BLOOM_LOG2 14u       /* log2(32 * CBC_BLOOM_WORDS) */
 #define CBC_ROLE_FUSED 0u      /* one wavefront does models and coder (CPU emulation)        */
 #define CBC_ROLE_MODEL 1u      /* wavefront 0 of the workgroup: models, produces symbol batches */
 #define CBC_ROLE_CODER 2u      /* wavefront 1: range coder, consumes them                        */
@@ -57,8 +58,8 @@
 #define CBC_LDS_INDELS  512u                       /* 256: indels excess                */
 #define CBC_LDS_RNKEY   768u                       /* CBC_CAP_NAME: (ctx<<8)|char       */
 #define CBC_LDS_RNEXC   (768u + CBC_CAP_NAME)      /* CBC_CAP_NAME                      */
-#define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* 256 words = 8192-bit Bloom filter on var ctx */
-#define CBC_LDS_VSLOT   (768u + 2u * CBC_CAP_NAME + 256u) /* 2 x 256: dense excess of the two hot var contexts */
+#define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* CBC_BLOOM_WORDS: Bloom filter on var ctx (two hashes) */
+#define CBC_LDS_VSLOT   (768u + 2u * CBC_CAP_NAME + CBC_BLOOM_WORDS) /* 2 x 256: dense excess of the two hot var contexts */
 #define CBC_LDS_BATCH   CBC_PLAN_TABLE_WORDS       /* CBC_BATCH_SLOTS x CBC_BATCH_WORDS: model wave -> coder wave */
 #ifndef CBC_BATCH_MIN
 #define CBC_BATCH_MIN   40u    /* <= 64 - 12 (a record's fixed symbols) - 4 (edit counts) - slack: see the 56 checks */
@@ -785,7 +786,7 @@ struct CbcEnc {
             uint32_t tag = slot ? vtag1 : vtag0;
             if (tag == CBC_NOMEMO) { tag = ctx; if (slot) vtag1 = ctx; else vtag0 = ctx; }
             if (tag == ctx) {
-                uint32_t *exc = bloom + 256u + 256u * slot;        /* CBC_LDS_VSLOT follows the Bloom filter */
+                uint32_t *exc = bloom + CBC_BLOOM_WORDS + 256u * slot;   /* CBC_LDS_VSLOT follows the Bloom filter */
                 uint32_t lo, cnt, sum = slot ? vsum1 : vsum0;
                 dense_lookup(exc, sym, lo, cnt);
                 encode(lo, cnt, L0 + sum);
@@ -797,9 +798,12 @@ struct CbcEnc {
         }
         V32 ln = W::lane();
         uint32_t cn = 0, clo = 0, ceq = 0, key = (ctx << 8) | sym;
-        const uint32_t h = (ctx * 0x9E3779B1u) >> 19;
-        const uint32_t bw = W::read_uni(bloom, h >> 5), bbit = 1u << (h & 31u);
-        if (bw & bbit) {
+        /* two hash functions, both words fetched by one LDS instruction (lanes 0 and 1) */
+        const uint32_t h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2), h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
+        const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
+        const uint32_t bw1 = W::readlane(bwv, 0u), bw2 = W::readlane(bwv, 1u);
+        const uint32_t bb1 = 1u << (h1 & 31u), bb2 = 1u << (h2 & 31u);
+        if ((bw1 & bb1) && (bw2 & bb2)) {
             W::list_fence();
             const uint32_t nb = W::uni(nev);
             for (uint32_t b = 0; b < nb; b += 256u) {
@@ -820,7 +824,10 @@ struct CbcEnc {
                            W::popc64(W::ballot(e2 == key)) + W::popc64(W::ballot(e3 == key));
                 }
             }
-        } else W::write_uni(bloom, h >> 5, bw | bbit);
+        } else {
+            if ((h1 >> 5) == (h2 >> 5)) W::write_uni(bloom, h1 >> 5, bw1 | bb1 | bb2);
+            else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
+        }
         encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
         if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
         W::append_list(var_ev, nev, key);
@@ -957,7 +964,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     }
     if (ROLE != CBC_ROLE_CODER) {
         for (uint32_t b = 0; b < 512u; b += 64u) W::store32(E.snps_exc, ln + b, W::splat(0u), W::all());   /* snps + indels */
-        for (uint32_t b = 0; b < 768u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());      /* Bloom + 2 slots */
+        for (uint32_t b = 0; b < CBC_BLOOM_WORDS + 512u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* Bloom + 2 slots */
     }
     E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
     E.snps_n = L0; E.indels_n = L0;

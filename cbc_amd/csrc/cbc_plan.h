@@ -11,10 +11,11 @@
 
 /* LDS layout constants, in 32-bit words (the kernel bodies take them from here).
  * [0, CBC_PLAN_TABLE_WORDS): model tables shared by encoder and decoder bodies:
- *   256 rlength, 256 snps, 256 indels, 2 x CBC_CAP_NAME contig-name pairs, 256 Bloom filter, 2 x 256 hot var slots */
-#define CBC_PLAN_TABLE_WORDS (768u + 2u * CBC_CAP_NAME + 256u + 512u)
+ *   256 rlength, 256 snps, 256 indels, 2 x CBC_CAP_NAME contig-name pairs, CBC_BLOOM_WORDS Bloom filter, 2 x 256 hot var slots */
+#define CBC_BLOOM_WORDS 512u                        /* 16384 bits, two hash functions (power of two) */
+#define CBC_PLAN_TABLE_WORDS (768u + 2u * CBC_CAP_NAME + CBC_BLOOM_WORDS + 512u)
 #ifndef CBC_BATCH_SLOTS
-#define CBC_BATCH_SLOTS 4u                         /* encoder hand-off ring depth (power of two) */
+#define CBC_BATCH_SLOTS 2u                         /* encoder hand-off ring depth (power of two; 2 measured as good as 4) */
 #endif
 #define CBC_BATCH_WORDS 200u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record, match mask x2} */
 #define CBC_RING_WORDS  256u                       /* output bit ring of the coder wave (power of two) */
