@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--contig-len", type=int, default=CHR1_LEN)
     ap.add_argument("--block-reads", type=int, default=4096)
-    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000,
+                    help="records of the same workload timed on one host core by the oracle (10 M ~ 11 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="encode", choices=["encode", "decode"],
                     help="encode = BASELINE.json's metric (default); decode = the mirror kernel on the same workload "
@@ -251,7 +252,7 @@ def main():
                                        {10_000_000: "cfg2", 49_791_284: "cfg3 (30x)"}.get(args.reads, "custom"),
                                        args.read_len, args.reads, args.contig_len, args.mode),
                        "reads_per_gpu": n_recs, "blocks_per_gpu": n_blocks, "block_reads": args.block_reads,
-                       "lds_bytes_per_wave": lds_bytes, "payload_bytes_per_gpu": payload_bytes,
+                       "lds_bytes_per_block": lds_bytes, "payload_bytes_per_gpu": payload_bytes,
                        "bits_per_read": round(payload_bytes * 8.0 / n_recs, 3),
                        "symbols_per_read": round(n_symbols / n_recs, 3),
                        "parallelism": "blocks sharded over %d GPU(s), gather of bitstreams to rank 0 (%s)" % (world, args.backend),
