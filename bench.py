@@ -235,8 +235,9 @@ def main():
         data, st = oracle.encode(sam, fa, return_stats=True)
         t_cpu = time.perf_counter() - t1
         cpu = {"value": round(st.n_bases / t_cpu / 1e6, 2), "unit": "Mbases/s", "cores": 1, "kind": "port",
-               "sample": "%d reads x %d bp of the same synthetic workload, one whole-file stream, SAM text "
-                         "parsing and FASTA load included, %.1f s of CPU" % (sample, args.read_len, t_cpu),
+               "sample": "%d reads x %d bp of the same synthetic workload%s, one whole-file stream, SAM text "
+                         "parsing and FASTA load included, %.1f s of CPU" % (
+                             sample, args.read_len, " (all of it)" if sample == args.reads else "", t_cpu),
                "host_cpus": os.cpu_count()}
         spb.close()
 

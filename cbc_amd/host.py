@@ -267,8 +267,9 @@ def synth(seed, contig_len, n_reads, read_len=150, sub_rate=0.003, indel_frac=0.
     pb = PackedBatch(out)
     if not want_text:
         return pb
-    sam = ctypes.string_at(sam_p, sam_n.value)
-    fa = ctypes.string_at(fa_p, fa_n.value)
+    # ctypes.string_at takes a C int: texts of 2 GiB and more (10 M reads) go through a buffer view
+    sam = bytes((ctypes.c_char * sam_n.value).from_address(sam_p.value)) if sam_n.value else b""
+    fa = bytes((ctypes.c_char * fa_n.value).from_address(fa_p.value)) if fa_n.value else b""
     lib().cbc_free(sam_p)
     lib().cbc_free(fa_p)
     return pb, sam, fa

@@ -60,7 +60,7 @@ _ERR = {-2: "reference assert would fire", -3: "output capacity", -4: "malformed
 def encode(sam: bytes, fasta: bytes, var_length: bool = False, return_stats: bool = False):
     """Whole-file encode: the bytes `program -c 1 in.sam out ref.fa` (-DDEBUG build) writes."""
     L = lib()
-    cap = 4096 + len(sam)  # the stream is far smaller than the SAM text
+    cap = 4096 + min(len(sam), (64 << 20) + len(sam) // 16)  # the stream is far smaller than the SAM text
     out = ctypes.create_string_buffer(cap)
     st = OracleStats()
     n = L.cbc_oracle_encode(sam, len(sam), fasta, len(fasta), out, cap, int(var_length), ctypes.byref(st))
