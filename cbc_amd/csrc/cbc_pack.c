@@ -123,6 +123,124 @@ static int load_fasta(packer_t *S, const char *fa, size_t len)
     return 0;
 }
 
+/* ---- the same loader on several threads: the text is cut at line starts; pass 1 counts,
+ * per chunk, the header lines and the sequence bytes before / after each of them; a serial prefix turns the
+ * counts into contig records and output offsets; pass 2 copies and upper-cases.  Byte-identical to
+ * load_fasta() (tests).  Used for texts of 8 MiB and more. */
+typedef struct {
+    const char *fa; size_t beg, end, len;
+    int first_chunk;
+    /* pass 1 */
+    uint64_t n_hdr, seq_before_first_hdr, seq_total; int too_long; size_t bad_off;
+    uint64_t *seg; uint64_t cap_seg;             /* sequence bytes after each header line of the chunk */
+    /* pass 2 */
+    uint8_t *out; uint64_t out_pos;              /* where this chunk's first sequence byte goes */
+    int phase;
+} fa_chunk_t;
+
+static inline int fa_is_hdr(const fa_chunk_t *c, size_t off, size_t ll) { return (ll > 0 && c->fa[off] == '>') || off == 0; }
+
+static void *fa_run(void *arg)
+{
+    fa_chunk_t *c = (fa_chunk_t *)arg;
+    const char *fa = c->fa;
+    size_t off = c->beg;
+    uint64_t cur = 0; int seen_hdr = 0;
+    uint8_t *d = c->out ? c->out + c->out_pos : NULL;
+    while (off < c->end) {
+        const char *nl = (const char *)memchr(fa + off, '\n', c->len - off);
+        size_t e = nl ? (size_t)(nl - fa) : c->len;
+        size_t ll = e - off;
+        if (c->phase == 1 && ll >= LINE_BUF - 1 && !c->too_long) { c->too_long = 1; c->bad_off = off; }
+        if (fa_is_hdr(c, off, ll)) {
+            if (c->phase == 1) {
+                if (!seen_hdr) c->seq_before_first_hdr = cur; else c->seg[c->n_hdr - 1] = cur;
+                if (grow((void **)&c->seg, &c->cap_seg, c->n_hdr + 1, sizeof(uint64_t))) { c->too_long = 2; return NULL; }
+                c->n_hdr++; seen_hdr = 1; cur = 0;
+            } else if (off != 0) {                 /* a header line closes the contig before it: its pad */
+                memset(d, 0, CBC_REF_PAD); d += CBC_REF_PAD;
+            }
+        } else if (c->phase == 1) { cur += ll; c->seq_total += ll; }
+        else {
+            const uint8_t *q = (const uint8_t *)fa + off;
+            for (size_t i = 0; i < ll; i++) { uint8_t ch = q[i]; d[i] = (uint8_t)(ch - (((uint8_t)(ch - 'a') < 26u) << 5)); }
+            d += ll;
+        }
+        off = e + 1;
+    }
+    if (c->phase == 1) { if (!seen_hdr) c->seq_before_first_hdr = cur; else c->seg[c->n_hdr - 1] = cur; }
+    return NULL;
+}
+
+static int load_fasta_mt(packer_t *S, const char *fa, size_t len, int nthreads)
+{
+    cbc_packed *P = S->P;
+    fa_chunk_t *ch = (fa_chunk_t *)calloc((size_t)nthreads, sizeof(fa_chunk_t));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    int rc = 0;
+    if (!ch || !th) { free(ch); free(th); return CBC_E_NOMEM; }
+    size_t b = 0;
+    for (int t = 0; t < nthreads; t++) {
+        size_t e = (t == nthreads - 1) ? len : len / (size_t)nthreads * (size_t)(t + 1);
+        if (e < b) e = b;
+        if (e < len && t != nthreads - 1) { const char *nl = (const char *)memchr(fa + e, '\n', len - e); e = nl ? (size_t)(nl - fa) + 1 : len; }
+        ch[t].fa = fa; ch[t].beg = b; ch[t].end = e; ch[t].len = len; ch[t].phase = 1; b = e;
+    }
+    for (int pass = 1; pass <= 2 && !rc; pass++) {
+        int started = 0;
+        for (int t = 0; t < nthreads; t++) { ch[t].phase = pass; if (pthread_create(&th[t], NULL, fa_run, &ch[t]) != 0) break; started++; }
+        for (int t = started; t < nthreads; t++) fa_run(&ch[t]);
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+        if (pass == 2) break;
+        /* serial prefix: contig records and output offsets */
+        for (int t = 0; t < nthreads && !rc; t++) {
+            if (ch[t].too_long == 2) rc = CBC_E_NOMEM;
+            else if (ch[t].too_long) rc = fail(S, CBC_E_INPUT, "FASTA line longer than %s1022 bytes at offset %lld (reference loader limit)", "", (long long)ch[t].bad_off);
+        }
+        if (rc) break;
+        uint64_t n_hdr = 0, seq = 0;
+        for (int t = 0; t < nthreads; t++) { n_hdr += ch[t].n_hdr; seq += ch[t].seq_total; }
+        S->n_fasta = 0;
+        if (n_hdr == 0) break;                                    /* empty text: no contig (len == 0) */
+        uint64_t total = seq + n_hdr * CBC_REF_PAD;               /* one pad after every contig */
+        if (grow((void **)&P->ref, &P->cap_ref, total, 1) ||
+            grow32((void **)&P->contigs, &P->cap_contigs, n_hdr, sizeof(cbc_contig_info))) { rc = CBC_E_NOMEM; break; }
+        uint64_t pos = 0; uint64_t cur_start = 0, cur_len = 0; int open = 0; uint32_t nc = 0;
+        for (int t = 0; t < nthreads; t++) {
+            ch[t].out = P->ref; ch[t].out_pos = pos;
+            cur_len += ch[t].seq_before_first_hdr; pos += ch[t].seq_before_first_hdr;
+            for (uint64_t k = 0; k < ch[t].n_hdr; k++) {
+                if (open) {                                       /* this header closes the contig before it */
+                    P->contigs[nc].ref_off = cur_start; P->contigs[nc].length = cur_len; P->contigs[nc].name_off = 0; P->contigs[nc].reserved = 0;
+                    nc++; pos += CBC_REF_PAD;
+                }
+                open = 1; cur_start = pos; cur_len = ch[t].seg[k]; pos += ch[t].seg[k];
+            }
+        }
+        P->contigs[nc].ref_off = cur_start; P->contigs[nc].length = cur_len; P->contigs[nc].name_off = 0; P->contigs[nc].reserved = 0;
+        nc++;
+        memset(P->ref + pos, 0, CBC_REF_PAD); pos += CBC_REF_PAD;
+        P->ref_bytes = pos; S->n_fasta = nc;
+    }
+    for (int t = 0; t < nthreads; t++) free(ch[t].seg);
+    free(ch); free(th);
+    return rc;
+}
+
+static int online_cpus(void)
+{
+    long nc = sysconf(_SC_NPROCESSORS_ONLN);
+    return nc < 1 ? 1 : nc > 64 ? 64 : (int)nc;
+}
+/* the FASTA loader behind both the packer and the unpack plan: threaded for big texts */
+static int load_reference(packer_t *S, const char *fa, size_t len, uint32_t n_threads)
+{
+    int nt = n_threads ? (int)n_threads : online_cpus();
+    if (nt > 64) nt = 64;
+    if (nt > 1 && (n_threads > 1 || len >= ((size_t)8 << 20))) return load_fasta_mt(S, fa, len, nt);
+    return load_fasta(S, fa, len);
+}
+
 static void close_block(packer_t *S)
 {
     cbc_packed *P = S->P;
@@ -783,7 +901,7 @@ API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t 
     if (!S) return CBC_E_NOMEM;
     int rc = packer_init(S, opts, errbuf, errlen);
     if (rc) goto done;
-    rc = load_fasta(S, fasta, fasta_len);
+    rc = load_reference(S, fasta, fasta_len, S->o.n_threads);
     if (rc) goto done;
     size_t off = 0;
     S->P->read_length = header_read_length(sam, sam_len, &off, (int)S->o.var_length);
@@ -1042,7 +1160,7 @@ API int cbc_unpack_plan_create(const uint8_t *blob, uint64_t len, const char *fa
             cap_var < 1 || cap_var > 32768) { rc = fail(S, CBC_E_INPUT, "corrupt container header%s%lld", "", 0); goto fail; }
         const uint8_t *ctab = blob + CBC_CONTAINER_HDR + names_pad, *btab = ctab + 16ull * nc, *pay = btab + 32ull * nb;
         uint64_t pay_bytes = len - hdr;
-        rc = load_fasta(S, fasta, fasta_len);
+        rc = load_reference(S, fasta, fasta_len, 0u);
         if (rc) goto fail;
         if (S->n_fasta < nc) { rc = fail(S, CBC_E_INPUT, "the FASTA has fewer records than the container has contigs%s%lld", "", 0); goto fail; }
         for (uint32_t i = 0; i < nc; i++)

@@ -362,3 +362,30 @@ def test_threaded_packer_tiny_inputs(built):
             except host.CbcInputError as e:
                 res.append(str(e))
         assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("threads", [2, 5, 16])
+def test_threaded_fasta_loader_equals_the_serial_one(built, threads):
+    """Four contigs with lower-case bases, an empty line, lines of different widths, a header that is the
+    last line, no trailing newline: reference bytes and the contig table are the serial loader's."""
+    rng = np.random.default_rng(3)
+    c = [synth.make_contig(rng, n) for n in (5000, 37, 12000, 800)]
+    parts = [b">one extra words\n"]
+    parts += [c[0][i:i + 70].tobytes().lower() + b"\n" for i in range(0, 5000, 70)]
+    parts += [b">two\n", c[1].tobytes() + b"\n", b"\n", b">three\n"]
+    parts += [c[2][i:i + 50].tobytes() + b"\n" for i in range(0, 12000, 50)]
+    parts += [b">four\n", c[3].tobytes()[:400] + b"\n", c[3].tobytes()[400:]]
+    fa = b"".join(parts)
+    seq = c[0][:40].tobytes()
+    row = ["r0", 0, "one", 1, 60, "40M", "*", 0, 0, seq.decode(), "I" * 40, "MD:Z:40"]
+    sam = ("\t".join(str(x) for x in row) + "\n").encode() * 2
+    a = host.pack_sam(sam, fa, threads=1)
+    b = host.pack_sam(sam, fa, threads=threads)
+    assert np.array_equal(np.asarray(a.ref), np.asarray(b.ref))
+    lens = lambda pb, n: [(int(pb.c_ptr.contents.contigs[i].ref_off), int(pb.c_ptr.contents.contigs[i].length)) for i in range(n)]
+    assert lens(a, 4) == lens(b, 4) and [l for _, l in lens(a, 4)] == [5000, 37, 12000, 800]
+    # a FASTA whose first line is not a '>' line: the reference still treats it as the header
+    fa2 = b"not a header\n" + c[1].tobytes() + b"\n>x\n" + c[3].tobytes() + b"\n"
+    r1 = host.pack_sam(sam, fa2.replace(c[1].tobytes(), c[0][:100].tobytes()), threads=1)
+    r2 = host.pack_sam(sam, fa2.replace(c[1].tobytes(), c[0][:100].tobytes()), threads=threads)
+    assert np.array_equal(np.asarray(r1.ref), np.asarray(r2.ref))
