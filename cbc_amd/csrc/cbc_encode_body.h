@@ -1,22 +1,24 @@
 /*
  * cbc_encode_body.h -- one arithmetic stream per workgroup: the per-read encode loop of the
- * reference (compress_line .. encoder_last_step) as wave-cooperative code, split over a model
- * wavefront and a coder wavefront (CbcEnc::publish / consume_all); the CPU emulation runs it fused.
+ * reference (compress_line .. encoder_last_step), split over two wavefronts by model ownership
+ * (see "hand-off" below; CbcEnc::publish / pull); the CPU emulation runs it fused in one.
  *
  * Template parameter W supplies the 64-lane primitives (cbc_wave_gpu.h on the GPU).  Every
  * branch below is wave-uniform; per-lane data only flows through W::select / ballot / reduce_add /
  * readlane and masked loads and stores.
  *
- * What is serial (wave-uniform scalars): the range-coder recurrence (l, u, scale3), the bit
- * accumulator, all model totals.  What the 64 lanes share inside ONE symbol:
+ * Where the 64 lanes are used:
+ *   - one lane per RECORD for the per-record models (rlength, pos, flag, match): inside a block
+ *     they are counting models, so (cum, count) of 64 records come from ballots / v_mbcnt
+ *     (fixed_group); one lane per SYMBOL for the scaled fractions the coder step divides by
+ *     (frac32) and for placing the output bits (pack)
  *   - read-vs-reference compare: 4 bases per lane, one ballot            (read_compression.c:291-296)
- *   - cumulative-frequency lookup: masked gather of the sparse/dense table + wave sum
- *                                                                         (stream_model.c:64-69)
- *   - POS-delta alphabet search: 64 candidates per compare + ballot       (read_compression.c:130)
+ *   - cumulative-frequency lookup of the edit models: masked gather of the sparse/dense table +
+ *     wave sum                                                           (stream_model.c:64-69)
  *   - var-context statistics: ballot + popcount over the block's var events
  *   - snpInRef window: a 256-bit sliding bitmap, first-set search         (read_compression.c:703-718)
- *   - output: the bits of a batch of steps are placed in an LDS word ring by a prefix sum of their
- *     lengths, one coalesced 256-byte store per 2048 bits
+ * What is serial: the range-coder recurrence (l, u, pending E3 count) -- kept in VECTOR registers on
+ * purpose (W::Uv) -- and the edit models' totals (wave-uniform scalars).
  *
  * Model tables are kept SPARSE and exact (SURVEY.md section 7 hard part 2): every symbol of the
  * big models starts at count 1 and rescaling maps 1 -> (1>>1)+1 = 1, so with e[s] = count[s]-1:
@@ -25,9 +27,8 @@
  * CBC_LOOP note (uniformity).  A chunk loop `for (b = 0; b < N; b += 64) { m = lane + b < N; ... }`
  * must take its bound from W::uni(N), an opaque copy: hipcc otherwise proves "m false => loop done"
  * (lane id < 64), threads the per-lane mask into the loop exit, the exit becomes divergent, and
- * everything live across the loop -- the whole coder state -- is classified divergent and moved
- * from the scalar unit to VGPRs + exec-mask branches.  encode() carries an asm("+s") guard that turns
- * any such regression into a compile error ("illegal VGPR to SGPR copy").
+ * everything live across the loop is classified divergent and moved from the scalar unit to VGPRs +
+ * exec-mask branches.
  */
 #ifndef CBC_ENCODE_BODY_H
 #define CBC_ENCODE_BODY_H
@@ -367,16 +368,6 @@ struct CbcEnc {
     }
     /* coder wave: before leaving, take every batch the model wave still sends */
     CBC_MFN void pull_rest() { while (!seen_last) pull(); }
-    /* floor(range * c / n) given f = floor(c * 2^32 / n) (clamped to 2^32 - 1 when c == n):
-     * range <= 2^26, so range * f / 2^32 is below the true quotient by less than 2^-6 + 1: the
-     * multiply-high is the quotient or one less, and the remainder (< 2n < 2^22, so its low 32 bits are
-     * all of it) says which. */
-    static CBC_MFN Uv scaled_div(Uv range, uint32_t c, uint32_t n, uint32_t f)
-    {
-        Uv q = W::mulhi(range, f);
-        Uv r = range * c - q * n;
-        return q + (r >= n ? 1u : 0u);
-    }
     /* one coder step without its output: the range update (Arithmetic_stream.c:274-295) and the E1/E2
      * and E3 loops (:296-341) in closed form -- within one step all E1/E2 iterations come first (they
      * strip the common leading bits of l and u), then all E3 iterations (the run of positions below the
@@ -391,21 +382,18 @@ struct CbcEnc {
         l ^= lo; u ^= hi + n; k1 = W::uv(0u); bits = k1; sc = k1; return;
 #endif
         const Uv range = u - l + 1u;
-#ifndef CBC_DIV_ALWAYS_EXACT
-        /* range * f = q * 2^32 + t: the true quotient is q + (t + range * g / n) / 2^32 with g < n the
-         * remainder of f's own division, and range <= 2^26, so q is final unless t >= 2^32 - 2^26
-         * (one step in 64 for a random t, and always when cum + count = n, where f is the clamped
-         * 2^32 - 1).  Only then is the remainder formed: one 32x32->64 multiply per division on the
-         * usual path instead of three quarter-rate ones. */
+        /* floor(range * c / n) for c = lo and c = hi, given f = floor(c * 2^32 / n) (clamped to 2^32 - 1
+         * when c == n).  range * f = q * 2^32 + t: the true quotient is q + (t + range * g / n) / 2^32
+         * with g < n the remainder of f's own division, and range <= 2^26, so q is final unless
+         * t >= 2^32 - 2^26 (one step in 64 for a random t, and always when cum + count = n).  Only then
+         * is the remainder formed (it is < 2n < 2^22, so its low 32 bits are all of it): one 32x32->64
+         * multiply per division on the usual path instead of three quarter-rate ones. */
         Uv ql, qh, tl, th;
         W::mul64(range, flo, ql, tl); W::mul64(range, fhi, qh, th);
         if (W::uv_scalar(tl | th) >= 0xfc000000u) {
             ql += (range * lo - ql * n >= n) ? 1u : 0u;
             qh += (range * hi - qh * n >= n) ? 1u : 0u;
         }
-#else
-        const Uv ql = scaled_div(range, lo, n, flo), qh = scaled_div(range, hi, n, fhi);
-#endif
         W::expect_eq(W::uv_scalar(ql), (uint32_t)((uint64_t)W::uv_scalar(range) * lo / n), "scaled_div(cum)");
         W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi / n), "scaled_div(cum + count)");
         u = l + qh - 1u;

@@ -106,7 +106,6 @@ struct WaveGPU {
     typedef uint32_t Uv;
     static CBC_FN Uv uv(uint32_t x) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
     static CBC_FN uint32_t uv_scalar(Uv x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-    static CBC_FN Uv mulhi(Uv a, uint32_t b) { return __umulhi(a, b); }
     static CBC_FN void mul64(Uv a, uint32_t b, Uv &hi, Uv &lo) { uint64_t p = (uint64_t)a * b; hi = (uint32_t)(p >> 32); lo = (uint32_t)p; }
     static CBC_FN Uv clz_uv(Uv x) { return (uint32_t)__builtin_clz(x); }                  /* x != 0 */
     static CBC_FN void set_lane_uv(V32 &v, uint32_t k, Uv val) { v = lane() == k ? val : v; }
