@@ -398,21 +398,25 @@ struct CbcEnc {
         W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi / n), "scaled_div(cum + count)");
         u = l + qh - 1u;
         l = l + ql;
-        /* branch-free, and in 32-bit arithmetic only: l, u < 2^26 and k1 <= 26, so the bits a 32-bit
-         * shift drops are bits the 26-bit masks drop anyway.  k1 = 0 makes the E1/E2 shifts the
-         * identity; after them bit 25 of l is 0 and of u is 1, so k3 = 0 makes the E3 update the identity. */
+        /* Branch-free, in 32-bit arithmetic, and with the two shifts merged.  E1/E2 shift k1 = number of
+         * common leading bits (of 26); E3 then shifts out the run, below the new MSB, where l has 1 and u
+         * has 0.  After E1/E2 the low k1 bits of l are 0 and of u are 1, so that run can be read from the
+         * unshifted values, y = (l & ~u) << (k1 + 7) (the 32-bit shift drops exactly the bits the masks
+         * would; for k1 >= 25, l & ~u is 0 and the shift count does not matter), k1 + k3 <= 26, and
+         *     l' = (l << (k1 + k3)) & M25,   u' = ((u << (k1 + k3)) & M25) | 2^25 | (2^(k1 + k3) - 1)
+         * equal the two updates of Arithmetic_stream.c:296-341 applied one after the other (k1 = 0 or
+         * k3 = 0 make the respective part the identity: bit 25 of l is then 0 and of u is 1).
+         * `sc` is the E3 count pending before this step; pack() ignores it when k1 = 0. */
         const Uv x = l ^ u;
-        k1 = x ? (W::clz_uv(x) - 6u) : 26u;
+        k1 = W::clz_uv((x << 6) | 32u);                          /* leading zeros of the 26-bit x; 26 when x = 0 */
         bits = l >> (26u - k1);                                  /* the k1 leading bits of l (k1 = 0: l >> 26 = 0) */
-        sc = k1 ? scale3 : 0u;
-        scale3 = k1 ? 0u : scale3;
-        l = (l << k1) & CBC_M26;
-        u = ((u << k1) & CBC_M26) | ((1u << k1) - 1u);
-        const Uv y = ((l & ~u) & CBC_M25) << 7;
+        sc = scale3;
+        const Uv y = (l & ~u) << ((k1 + 7u) & 31u);
         const Uv k3 = W::clz_uv(~y);                             /* ~y != 0: its low 7 bits are set */
-        scale3 += k3;
-        l = (l << k3) & CBC_M25;
-        u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
+        scale3 = (k1 ? 0u : scale3) + k3;
+        const Uv sh = k1 + k3;
+        l = (l << sh) & CBC_M25;
+        u = ((u << sh) & CBC_M25) | (1u << 25) | ((1u << sh) - 1u);
     }
     CBC_MFN uint32_t finish()                        /* encoder_last_step :348-363 + stream_finish_byte */
     {
