@@ -113,7 +113,6 @@ struct CbcDec {
         uint64_t p = (uint64_t)gap * n - 1u;
         return W::divq(p, range);
     }
-    /* the E1/E2 and E3 shifts of arithmetic_decoder_step (Arithmetic_stream.c:401-454) in closed form */
     /* the E1/E2 and E3 shifts of arithmetic_decoder_step (Arithmetic_stream.c:401-454) in closed form.
      * (The merged single shift of CbcEnc::code1 was tried here and is slower on the scalar unit: the two
      * branches below skip more work than the merge saves.) */
