@@ -110,7 +110,7 @@ struct CbcEnc {
 
     /* ---- range coder + bit writer (Arithmetic_stream.c:155-194, 274-371) ---- */
     typedef typename W::Uv Uv;               /* a wave-uniform value kept in a VECTOR register (see cbc_wave_gpu.h) */
-    Uv l, u, scale3;
+    Uv l, rng, scale3;                       /* lower bound, range = u - l + 1, pending E3 count */
     uint32_t bitpos, flushed;               /* bits produced; words already stored (multiple of 64)  */
     uint32_t *ring;                         /* CBC_RING_WORDS of LDS, zero except for the pending bits */
     uint32_t *out32; uint32_t cap_words;
@@ -379,9 +379,9 @@ struct CbcEnc {
     CBC_MFN void code1(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi, Uv &k1, Uv &bits, Uv &sc)
     {
 #ifdef CBC_ABLATE_CODER          /* timing experiments only: keeps the operands live, skips the coder */
-        l ^= lo; u ^= hi + n; k1 = W::uv(0u); bits = k1; sc = k1; return;
+        l ^= lo; rng ^= hi + n; k1 = W::uv(0u); bits = k1; sc = k1; return;
 #endif
-        const Uv range = u - l + 1u;
+        const Uv range = rng;
         /* floor(range * c / n) for c = lo and c = hi, given f = floor(c * 2^32 / n) (clamped to 2^32 - 1
          * when c == n).  range * f = q * 2^32 + t: the true quotient is q + (t + range * g / n) / 2^32
          * with g < n the remainder of f's own division, and range <= 2^26, so q is final unless
@@ -394,9 +394,11 @@ struct CbcEnc {
             ql += (range * lo - ql * n >= n) ? 1u : 0u;
             qh += (range * hi - qh * n >= n) ? 1u : 0u;
         }
+#ifndef __HIP_DEVICE_COMPILE__     /* emulation: every quotient against integer division */
         W::expect_eq(W::uv_scalar(ql), (uint32_t)((uint64_t)W::uv_scalar(range) * lo / n), "scaled_div(cum)");
         W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi / n), "scaled_div(cum + count)");
-        u = l + qh - 1u;
+#endif
+        const Uv u = l + qh - 1u;                                /* the state is (l, range): every E1/E2/E3 shift doubles the range */
         l = l + ql;
         /* Branch-free, in 32-bit arithmetic, and with the two shifts merged.  E1/E2 shift k1 = number of
          * common leading bits (of 26); E3 then shifts out the run, below the new MSB, where l has 1 and u
@@ -405,7 +407,9 @@ struct CbcEnc {
          * would; for k1 >= 25, l & ~u is 0 and the shift count does not matter), k1 + k3 <= 26, and
          *     l' = (l << (k1 + k3)) & M25,   u' = ((u << (k1 + k3)) & M25) | 2^25 | (2^(k1 + k3) - 1)
          * equal the two updates of Arithmetic_stream.c:296-341 applied one after the other (k1 = 0 or
-         * k3 = 0 make the respective part the identity: bit 25 of l is then 0 and of u is 1).
+         * k3 = 0 make the respective part the identity: bit 25 of l is then 0 and of u is 1).  Each of
+         * those shifts maps [l, u] with slope 2 (u' - l' + 1 = 2 (u - l + 1)), so instead of u' the
+         * state keeps range' = (qh - ql) << (k1 + k3), which is also what the next step starts from.
          * `sc` is the E3 count pending before this step; pack() ignores it when k1 = 0. */
         const Uv x = l ^ u;
         k1 = W::clz_uv((x << 6) | 32u);                          /* leading zeros of the 26-bit x; 26 when x = 0 */
@@ -416,7 +420,10 @@ struct CbcEnc {
         scale3 = (k1 ? 0u : scale3) + k3;
         const Uv sh = k1 + k3;
         l = (l << sh) & CBC_M25;
-        u = ((u << sh) & CBC_M25) | (1u << 25) | ((1u << sh) - 1u);
+        rng = (qh - ql) << sh;
+#ifndef __HIP_DEVICE_COMPILE__     /* emulation: the explicit upper bound against the range form */
+        W::expect_eq(W::uv_scalar(l + rng - 1u), W::uv_scalar(((u << sh) & CBC_M25) | (1u << 25) | ((1u << sh) - 1u)), "range form of the upper bound");
+#endif
     }
     CBC_MFN uint32_t finish()                        /* encoder_last_step :348-363 + stream_finish_byte */
     {
@@ -914,7 +921,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
 
     E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
-    E.l = W::uv(0u); E.u = W::uv(CBC_M26); E.scale3 = W::uv(0u); E.bitpos = 0; E.flushed = 0;
+    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = W::uv(0u); E.bitpos = 0; E.flushed = 0;
     E.ring = lds + CBC_LDS_RING;
     E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
     E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);
