@@ -110,7 +110,8 @@ struct CbcEnc {
 
     /* ---- range coder + bit writer (Arithmetic_stream.c:155-194, 274-371) ---- */
     typedef typename W::Uv Uv;               /* a wave-uniform value kept in a VECTOR register (see cbc_wave_gpu.h) */
-    Uv l, rng, scale3;                       /* lower bound, range = u - l + 1, pending E3 count */
+    Uv l, rng;                               /* lower bound, range = u - l + 1 (vector registers)   */
+    uint32_t scale3;                         /* E3 count pending after the steps packed so far      */
     uint32_t bitpos, flushed;               /* bits produced; words already stored (multiple of 64)  */
     uint32_t *ring;                         /* CBC_RING_WORDS of LDS, zero except for the pending bits */
     uint32_t *out32; uint32_t cap_words;
@@ -180,22 +181,36 @@ struct CbcEnc {
         while (n >= 32u) { put(pat, 32u); n -= 32u; }
         if (n) put(pat >> (32u - n), n);
     }
-    /* the output of up to 64 coder steps: lane k holds step k's E1/E2 bits (k1 | bits << 5) and the E3
-     * count that was pending when they were shifted out (Arithmetic_stream.c:296-341: the first bit,
-     * then that many inverted copies, then the other k1 - 1 bits) */
-    CBC_MFN void pack(const V32 &rec_a, const V32 &rec_s, uint32_t m)
+    /* the output of up to 64 coder steps: lane k holds step k's lower bound before its shifts with k1 on top
+     * (l | k1 << 26) and its E3 count k3.  The k1 leading bits of l leave through E1/E2 as: the first
+     * bit, then as many inverted copies as E3 shifts were pending, then the other k1 - 1 bits
+     * (Arithmetic_stream.c:296-341).  "Pending" for step i = the k3 of all steps since the last one that
+     * emitted (that one included): a segmented sum, here S_ex(i) - S_ex(last emitter before i) with the
+     * last emitter found by a prefix maximum (S_ex is non-decreasing), plus the count carried in from
+     * the previous batch when no step of this batch has emitted yet. */
+    CBC_MFN void pack(const V32 &rec_a, const V32 &rec_k3, uint32_t m)
     {
         const V32 ln = W::lane();
-        const V32 k1 = rec_a & 31u, bits = rec_a >> 5;
-        const Mask act = (ln < m) & (k1 != 0u);
+        const Mask in = ln < m;
+        const V32 k1 = rec_a >> 26, bits = (rec_a & CBC_M26) >> ((W::splat(26u) - k1) & 31u);   /* k1 = 0: l >> 26 = 0 */
+        const Mask act = in & (k1 != 0u);
+        const V32 k3 = W::select(in, rec_k3, W::splat(0u));
+        const V32 s_in = W::scan_incl_add(k3), s_ex = s_in - k3;
+        const V32 mark = W::select(act, s_ex + 1u, W::splat(0u));           /* emitters carry S_ex + 1, others 0 */
+        const V32 m_in = W::scan_incl_max(mark);
+        const V32 m_ex = W::shift_up1(m_in, 0u);                             /* last emitter strictly before this lane */
+        const V32 rec_s = W::select(m_ex == 0u, s_ex + scale3, s_ex - (m_ex - 1u));
+        {
+            const uint32_t total = W::readlane(s_in, 63u), last = W::readlane(m_in, 63u);
+            scale3 = last ? total - (last - 1u) : scale3 + total;           /* pending after this batch */
+        }
         const V32 len = W::select(act, k1 + rec_s, W::splat(0u));
 #ifndef CBC_PACK_SERIAL_AT
 #define CBC_PACK_SERIAL_AT 32u                           /* tests lower it to exercise the piece-by-piece path */
 #endif
         if (W::ballot(act & (len > CBC_PACK_SERIAL_AT))) {    /* a long E3 run: piece by piece */
             for (uint32_t k = 0; k < m; k++) {
-                const uint32_t a = W::readlane(rec_a, k), sc = W::readlane(rec_s, k);
-                const uint32_t kk = a & 31u, bb = a >> 5;
+                const uint32_t kk = W::readlane(k1, k), bb = W::readlane(bits, k), sc = W::readlane(rec_s, k);
                 if (kk == 0u) continue;
                 if (sc == 0u) put(bb, kk);
                 else {
@@ -288,10 +303,10 @@ struct CbcEnc {
     /* one symbol through the coder; the step's output waits in rec_a / rec_s for pack() */
     CBC_MFN void step(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi)
     {
-        Uv k1, bits, sc;
-        code1(lo, hi, n, flo, fhi, k1, bits, sc);
-        W::set_lane_uv(rec_a, rec_n, k1 | (bits << 5));
-        W::set_lane_uv(rec_s, rec_n, sc);
+        Uv rec, k3;
+        code1(lo, hi, n, flo, fhi, rec, k3);
+        W::set_lane_uv(rec_a, rec_n, rec);
+        W::set_lane_uv(rec_s, rec_n, k3);
         nsym++;
         if (++rec_n == 64u) { pack(rec_a, rec_s, 64u); rec_n = 0; }
     }
@@ -372,14 +387,14 @@ struct CbcEnc {
      * and E3 loops (:296-341) in closed form -- within one step all E1/E2 iterations come first (they
      * strip the common leading bits of l and u), then all E3 iterations (the run of positions below the
      * MSB where l has 1 and u has 0); E3 leaves msb(l) = 0, msb(u) = 1, so E1/E2 cannot recur.
-     * k1 bits (`bits`, MSB first) leave through E1/E2; `sc` is the E3 count pending at that moment.
+     * The step records (l | k1 << 26, k3); what leaves the coder is assembled by pack().
      * The recurrence runs on the VECTOR unit although every lane holds the same value: a CU has one
      * scalar unit for all its wavefronts and four vector units, and with ten blocks resident per CU the
      * scalar unit is what the kernel queues on. */
-    CBC_MFN void code1(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi, Uv &k1, Uv &bits, Uv &sc)
+    CBC_MFN void code1(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi, Uv &rec, Uv &k3)
     {
 #ifdef CBC_ABLATE_CODER          /* timing experiments only: keeps the operands live, skips the coder */
-        l ^= lo; rng ^= hi + n; k1 = W::uv(0u); bits = k1; sc = k1; return;
+        l ^= lo; rng ^= hi + n; rec = W::uv(0u); k3 = rec; return;
 #endif
         const Uv range = rng;
         /* floor(range * c / n) for c = lo and c = hi, given f = floor(c * 2^32 / n) (clamped to 2^32 - 1
@@ -410,14 +425,12 @@ struct CbcEnc {
          * k3 = 0 make the respective part the identity: bit 25 of l is then 0 and of u is 1).  Each of
          * those shifts maps [l, u] with slope 2 (u' - l' + 1 = 2 (u - l + 1)), so instead of u' the
          * state keeps range' = (qh - ql) << (k1 + k3), which is also what the next step starts from.
-         * `sc` is the E3 count pending before this step; pack() ignores it when k1 = 0. */
+         * The pending-E3 bookkeeping is not done here: pack() derives it from the recorded k3 of all steps. */
         const Uv x = l ^ u;
-        k1 = W::clz_uv((x << 6) | 32u);                          /* leading zeros of the 26-bit x; 26 when x = 0 */
-        bits = l >> (26u - k1);                                  /* the k1 leading bits of l (k1 = 0: l >> 26 = 0) */
-        sc = scale3;
+        const Uv k1 = W::clz_uv((x << 6) | 32u);                 /* leading zeros of the 26-bit x; 26 when x = 0 */
+        rec = l | (k1 << 26);                                    /* pack() takes the k1 leading bits of l from here */
         const Uv y = (l & ~u) << ((k1 + 7u) & 31u);
-        const Uv k3 = W::clz_uv(~y);                             /* ~y != 0: its low 7 bits are set */
-        scale3 = (k1 ? 0u : scale3) + k3;
+        k3 = W::clz_uv(~y);                                      /* ~y != 0: its low 7 bits are set */
         const Uv sh = k1 + k3;
         l = (l << sh) & CBC_M25;
         rng = (qh - ql) << sh;
@@ -429,7 +442,7 @@ struct CbcEnc {
     {
         const uint32_t lf = W::uv_scalar(l);
         uint32_t msb = lf >> 25;
-        put(msb, 1u); put_run(msb ^ 1u, W::uv_scalar(scale3)); scale3 = W::uv(0u);
+        put(msb, 1u); put_run(msb ^ 1u, scale3); scale3 = 0u;
         put(lf & CBC_M25, 25u);
         const uint32_t nbytes = (bitpos >> 3) + 1u;          /* +1: the partial byte, or the extra 0x00 */
         const uint32_t nw = (nbytes + 3u) >> 2;              /* the ring is zero past the last bit */
@@ -921,7 +934,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
 
     E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
-    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = W::uv(0u); E.bitpos = 0; E.flushed = 0;
+    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
     E.ring = lds + CBC_LDS_RING;
     E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
     E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);

@@ -124,6 +124,16 @@ struct WaveGPU {
     /* emulation-only cross-check hook */
     static CBC_FN void expect_eq(uint32_t, uint32_t, const char *) {}
 
+    /* inclusive prefix maximum over the lanes (unsigned; the same DPP ladder, 0 is the identity) */
+    static CBC_FN V32 scan_incl_max(V32 v)
+    {
+        uint32_t x = v;
+#define CBC_DPP_MAX(ctrl, rmask) { uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false); x = x > y_ ? x : y_; }
+        CBC_DPP_MAX(0x111, 0xf) CBC_DPP_MAX(0x112, 0xf) CBC_DPP_MAX(0x114, 0xf) CBC_DPP_MAX(0x118, 0xf)
+        CBC_DPP_MAX(0x142, 0xa) CBC_DPP_MAX(0x143, 0xc)
+#undef CBC_DPP_MAX
+        return x;
+    }
     /* per-lane gathers / scatters; `m` false = lane does not touch memory */
     static CBC_FN V32 load32(const uint32_t *p, V32 idx, Mask m, uint32_t other) { return m ? p[idx] : other; }
     static CBC_FN void store32(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) p[idx] = val; }

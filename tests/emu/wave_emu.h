@@ -96,6 +96,7 @@ struct WaveEmu {
     static Uv clz_uv(Uv x) { return clz32(x); }
     static void set_lane_uv(V32 &v, uint32_t k, Uv val) { set_lane(v, k, val); }
     static void expect_eq(uint32_t a, uint32_t b, const char *what) { if (a != b) emu_oob(what); }
+    static V32 scan_incl_max(const V32 &v) { V32 r; uint32_t m = 0; for (int i = 0; i < 64; i++) { if (v.v[i] > m) m = v.v[i]; r.v[i] = m; } return r; }
     static V32 scan_incl_add(const V32 &v) { V32 r; uint32_t s = 0; for (int i = 0; i < 64; i++) { s += v.v[i]; r.v[i] = s; } return r; }
     static V32 load8(const uint8_t *p, const V32 &off, const Mask &m) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = m.b[i] ? p[off.v[i]] : 0u; return r; }
     static void store8(uint8_t *p, const V32 &off, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[off.v[i]] = (uint8_t)val.v[i]; }
