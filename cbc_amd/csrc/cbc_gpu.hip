@@ -27,7 +27,8 @@
  * ---------------------------------------------------------------------------------------------- */
 extern __shared__ uint32_t cbc_lds[];
 
-__global__ void __launch_bounds__(128)
+/* at least 5 wavefronts per SIMD = 10 resident blocks per CU: cfg2 needs 9.5, and one wave fewer costs 25 % */
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5)))
 cbc_encode_blocks_kernel(cbc_enc_args A)
 {
     /* One workgroup = one block = one arithmetic stream, coded by TWO wavefronts: wavefront 0 (model)
