@@ -260,7 +260,7 @@ def main():
                        "host_pack_seconds": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "cbc_%s_blocks_kernel" % args.mode, "kernel_ms": round(k_ms, 3),
+                         "kernel": "cbc_%s_blocks_kernel%s" % (args.mode, "_w6" if args.mode == "encode" and n_blocks > 10 * torch.cuda.get_device_properties(dev).multi_processor_count else ""), "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }

@@ -27,23 +27,31 @@
  * ---------------------------------------------------------------------------------------------- */
 extern __shared__ uint32_t cbc_lds[];
 
-/* at least 5 wavefronts per SIMD = 10 resident blocks per CU: cfg2 needs 9.5, and one wave fewer costs 25 % */
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5)))
-cbc_encode_blocks_kernel(cbc_enc_args A)
+/* One workgroup = one block = one arithmetic stream, coded by TWO wavefronts: wavefront 0 (model)
+ * runs the match test and the edit models and sends END-terminated segments of the symbol stream
+ * through an LDS ring; wavefront 1 (coder) owns the per-record models, computes their symbols one
+ * lane per record and runs the range coder (cbc_encode_body.h, CbcEnc::publish / pull).
+ * Workgroups are dealt round-robin to the 8 XCDs; blocks of one contig are neighbours in the
+ * batch and share nothing but read-only reference lines, so the identity map is kept and the
+ * per-XCD L2s each see a strided slice of the record stream. */
+static __device__ __forceinline__ void cbc_encode_block(const cbc_enc_args &A)
 {
-    /* One workgroup = one block = one arithmetic stream, coded by TWO wavefronts: wavefront 0 (model)
-     * runs the match test and the edit models and sends END-terminated segments of the symbol stream
-     * through an LDS ring; wavefront 1 (coder) owns the per-record models, computes their symbols one
-     * lane per record and runs the range coder (cbc_encode_body.h, CbcEnc::publish / pull).
-     * Workgroups are dealt round-robin to the 8 XCDs; blocks of one contig are neighbours in the
-     * batch and share nothing but read-only reference lines, so the identity map is kept and the
-     * per-XCD L2s each see a strided slice of the record stream. */
     uint32_t blk = blockIdx.x;
     if (blk >= A.n_blocks) return;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wid == 0u) cbc_encode_stream<WaveGPU, CBC_ROLE_MODEL>(A, blk, cbc_lds);
     else cbc_encode_stream<WaveGPU, CBC_ROLE_CODER>(A, blk, cbc_lds);
 }
+
+/* Two register budgets of the same code.  Up to ten blocks per CU (cfg2: 9.5) everything is resident at
+ * 5 wavefronts per SIMD and the kernel is latency-bound: the 84-register build is the faster one.  With
+ * more blocks than that (cfg3-sized input) the CU is throughput-bound and a sixth wavefront per SIMD (80
+ * registers, one spilled) gains 6 %; it costs 5 % at cfg2.  One wave fewer than 5 costs 25-30 %. */
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(5)))
+cbc_encode_blocks_kernel(cbc_enc_args A) { cbc_encode_block(A); }
+
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(6)))
+cbc_encode_blocks_kernel_w6(cbc_enc_args A) { cbc_encode_block(A); }
 
 __global__ void __launch_bounds__(64)
 cbc_decode_blocks_kernel(cbc_dec_args A)
@@ -97,6 +105,7 @@ struct cbc_gpu_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     int have_timing;
+    int n_cus;                     /* compute units of the device (block residency decides the kernel build) */
     uint8_t *d_ref; uint64_t ref_bytes;
     char err[512];
 };
@@ -132,8 +141,14 @@ API int cbc_gpu_init(int device_ordinal, cbc_gpu_ctx **out)
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx; return CBC_E_NODEV;
     }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) != hipSuccess || cus <= 0) cus = 256;
+        ctx->n_cus = cus;
+    }
     /* the kernel's dynamic LDS can exceed the 64 KiB default */
     (void)hipFuncSetAttribute((const void *)cbc_encode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)cbc_encode_blocks_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)cbc_decode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return CBC_OK;
@@ -189,7 +204,10 @@ API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b
     A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
     A.names_bytes = 0x7fffffffu;   /* names are NUL-terminated; bounded by CBC_CAP_NAME in the kernel */
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
-    hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(128), lds, s, A);
+    if ((uint64_t)b->n_blocks > 10ull * (uint64_t)ctx->n_cus)     /* more blocks than are resident at 5 waves per SIMD */
+        hipLaunchKernelGGL(cbc_encode_blocks_kernel_w6, dim3(b->n_blocks), dim3(128), lds, s, A);
+    else
+        hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(128), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_encode_blocks_kernel");
     HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
     ctx->have_timing = 1;
