@@ -509,10 +509,10 @@ struct CbcDec {
         if ((bw1 & bb1) && (bw2 & bb2)) {
             W::list_fence();
             const uint32_t nb = W::uni(nev);
-            for (uint32_t b = 0; b < nb; b += 256u) {             /* four loads in flight per trip */
-                V32 ev4[4];
-                for (uint32_t q = 0; q < 4u; q++) { V32 i = ln + (b + 64u * q); ev4[q] = W::load32_list(ev, i, i < nev, 0xffffffffu); }
-                for (uint32_t q = 0; q < 4u; q++) {
+            for (uint32_t b = 0; b < nb; b += 512u) {             /* eight coalesced loads in flight per trip */
+                V32 ev4[8];
+                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev4[q] = W::load32_list(ev, i, i < nev, 0xffffffffu); }
+                for (uint32_t q = 0; q < 8u; q++) {
                     const V32 e = ev4[q];
                     uint64_t bb = W::ballot((e >> 8) == ctx);     /* lanes past nev hold 0xffffffff: ctx 0xffffff never matches */
                     while (bb) {

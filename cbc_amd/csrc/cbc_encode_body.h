@@ -785,7 +785,7 @@ struct CbcEnc {
     /* ---- var (read_compression.c:230-245): 65535 contexts x L0, kept as the list of events.
      * Most contexts are seen once per block, so an 8192-bit Bloom filter on the context answers
      * "never seen" (n = L0, cum = sym) without touching the list; only on a filter hit is the list
-     * scanned, 256 events per iteration (4 independent LDS reads in flight per lane). ---- */
+     * scanned, 512 events per trip (eight coalesced loads in flight). ---- */
     CBC_MFN void var_code(uint32_t ctx, uint32_t sym)
     {
         if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
@@ -818,22 +818,17 @@ struct CbcEnc {
         if ((bw1 & bb1) && (bw2 & bb2)) {
             W::list_fence();
             const uint32_t nb = W::uni(nev);
-            for (uint32_t b = 0; b < nb; b += 256u) {
-                V32 i0 = ln * 4u + b;
-                V32 e0 = W::load32_list(var_ev, i0, i0 < nev, 0xffffffffu);
-                V32 e1 = W::load32_list(var_ev, i0 + 1u, (i0 + 1u) < nev, 0xffffffffu);
-                V32 e2 = W::load32_list(var_ev, i0 + 2u, (i0 + 2u) < nev, 0xffffffffu);
-                V32 e3 = W::load32_list(var_ev, i0 + 3u, (i0 + 3u) < nev, 0xffffffffu);
-                uint64_t b0 = W::ballot((e0 >> 8) == ctx), b1 = W::ballot((e1 >> 8) == ctx);
-                uint64_t b2 = W::ballot((e2 >> 8) == ctx), b3 = W::ballot((e3 >> 8) == ctx);
-                if (b0 | b1 | b2 | b3) {
-                    cn += W::popc64(b0) + W::popc64(b1) + W::popc64(b2) + W::popc64(b3);
-                    clo += W::popc64(W::ballot(((e0 >> 8) == ctx) & ((e0 & 0xffu) < sym))) +
-                           W::popc64(W::ballot(((e1 >> 8) == ctx) & ((e1 & 0xffu) < sym))) +
-                           W::popc64(W::ballot(((e2 >> 8) == ctx) & ((e2 & 0xffu) < sym))) +
-                           W::popc64(W::ballot(((e3 >> 8) == ctx) & ((e3 & 0xffu) < sym)));
-                    ceq += W::popc64(W::ballot(e0 == key)) + W::popc64(W::ballot(e1 == key)) +
-                           W::popc64(W::ballot(e2 == key)) + W::popc64(W::ballot(e3 == key));
+            for (uint32_t b = 0; b < nb; b += 512u) {           /* eight coalesced loads in flight per trip */
+                V32 ev[8];
+                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev[q] = W::load32_list(var_ev, i, i < nev, 0xffffffffu); }
+                for (uint32_t q = 0; q < 8u; q++) {
+                    const V32 e = ev[q];
+                    const uint64_t bc = W::ballot((e >> 8) == ctx);    /* lanes past nev hold 0xffffffff: never a context */
+                    if (bc) {
+                        cn += W::popc64(bc);
+                        clo += W::popc64(W::ballot(((e >> 8) == ctx) & ((e & 0xffu) < sym)));
+                        ceq += W::popc64(W::ballot(e == key));
+                    }
                 }
             }
         } else {
