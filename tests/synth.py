@@ -169,3 +169,27 @@ def dataset(seed, contig_lens, reads_per_contig, L, names=None, **kw):
         contigs.append((name, c))
         rbc.append((name, clen, make_reads(rng, c, nr, L, **kw)))
     return fasta_text(contigs), sam_text(rbc), rbc, contigs
+
+
+def shared_variant_dataset(seed, clen, n_reads, L, site_every, err, indel_sites=0):
+    """Reads whose SNPs are SHARED: every read covering a variant site carries the site's alternative base
+    (plus independent errors at rate `err`).  This is what real alignments look like, and it is the case
+    where var contexts repeat ("the known variant d bases ahead").  Returns (fasta_bytes, sam_bytes)."""
+    rng = np.random.default_rng(seed)
+    contig = make_contig(rng, clen)
+    alt = contig.copy()
+    sites = rng.choice(clen, size=max(clen // site_every, 1), replace=False)
+    for s in sites:
+        alt[s] = _ACGT[(int(np.where(_ACGT == contig[s])[0][0]) + 1 + int(rng.integers(0, 3))) % 4]
+    starts = np.sort(rng.integers(0, clen - L - 8, size=n_reads))
+    out = []
+    for i, s in enumerate(starts):
+        s = int(s)
+        seq = alt[s:s + L].copy()
+        ne = int(rng.binomial(L, err)) if err > 0 else 0
+        for q in (rng.choice(L, size=ne, replace=False) if ne else []):
+            seq[q] = _ACGT[(int(np.where(_ACGT == seq[q])[0][0]) + 1 + int(rng.integers(0, 3))) % 4]
+        md, nm = _md_and_nm(contig, s, [("M", L)], seq)
+        out.append(b"r%d\t%d\tc\t%d\t60\t%dM\t*\t0\t0\t%s\t%s\tMD:Z:%s\tNM:i:%d\n" % (
+            i, 16 * int(rng.integers(0, 2)), s + 1, L, seq.tobytes(), b"I" * L, md.encode(), nm))
+    return fasta_text([("c", contig)]), b"".join(out)

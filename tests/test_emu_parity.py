@@ -270,3 +270,18 @@ def test_soft_clips_match_oracle_and_round_trip(built):
     pb = host.pack_sam(sam, fa, block_reads=256)
     _check(pb, sam)
     _roundtrip(pb, sam, fa)
+
+
+@pytest.mark.parametrize("site_every,err,br", [(100, 0.0, 1500), (60, 0.004, 4096), (300, 0.001, 700)])
+def test_shared_variants_repeat_var_contexts(built, site_every, err, br):
+    """Every read covering a variant site carries it: var contexts repeat with one symbol each (context cache
+    hits), sequencing errors add second symbols (mixed entries -> filter + list scan) and other contexts
+    evict them.  Bytes == oracle, and the decode round trip returns the reads."""
+    fa, sam = synth.shared_variant_dataset(21, 60000, 3000, 100, site_every, err)
+    pb = host.pack_sam(sam, fa, block_reads=br)
+    payloads, _ = _check(pb, sam)
+    blob = blockref.container_from_payloads(pb, payloads)
+    plan = host.UnpackPlan(blob, fa)
+    recs, seq, res = blockref.emu_decode(plan)
+    assert (res["status"] == 0).all()
+    assert plan.text(recs, seq) == b"".join(l.split(b"\t")[9] + b"\n" for l in sam.split(b"\n") if l)

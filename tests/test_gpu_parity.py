@@ -316,3 +316,18 @@ def test_piece_by_piece_bit_packing_on_the_gpu(built):
     """ % (root, os.path.join(root, "tests")))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CBC_GPU_LIB=lib), capture_output=True, text=True)
     assert "SERIALPACK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("site_every,err", [(100, 0.0), (300, 0.001)])
+def test_shared_variants(enc, built, site_every, err):
+    """Shared variant sites (var contexts that repeat with one symbol: the context cache) on the GPU: bytes ==
+    oracle per block, decode round trip == the reads."""
+    fa, sam = synth.shared_variant_dataset(33, 400000, 20000, 150, site_every, err)
+    pb = host.pack_sam(sam, fa, block_reads=4096)
+    payloads = _check_blocks(enc, pb, sam)
+    blob = blockref.container_from_payloads(pb, payloads)
+    plan = host.UnpackPlan(blob, fa)
+    enc.upload_reference(plan.ref)
+    recs, seq, res = enc.decode_blocks(plan)
+    assert (res["status"] == 0).all()
+    assert plan.text(recs, seq) == b"".join(l.split(b"\t")[9] + b"\n" for l in sam.split(b"\n") if l)
