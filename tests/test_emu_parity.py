@@ -285,3 +285,10 @@ def test_shared_variants_repeat_var_contexts(built, site_every, err, br):
     recs, seq, res = blockref.emu_decode(plan)
     assert (res["status"] == 0).all()
     assert plan.text(recs, seq) == b"".join(l.split(b"\t")[9] + b"\n" for l in sam.split(b"\n") if l)
+
+
+def test_reads_with_dozens_of_edits(built):
+    """~65 SNPs per read plus indels (the queue is drained many times inside one record)."""
+    fa, sam, _, _ = synth.dataset(77, [60000], [600], 150, sub_rate=0.45, indel_frac=0.3)
+    pb = host.pack_sam(sam, fa, block_reads=256)
+    _check(pb, sam)

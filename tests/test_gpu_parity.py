@@ -331,3 +331,11 @@ def test_shared_variants(enc, built, site_every, err):
     recs, seq, res = enc.decode_blocks(plan)
     assert (res["status"] == 0).all()
     assert plan.text(recs, seq) == b"".join(l.split(b"\t")[9] + b"\n" for l in sam.split(b"\n") if l)
+
+
+def test_reads_with_dozens_of_edits(enc, built):
+    """~65 SNPs per read plus indels: one record's edit segment is longer than a hand-off batch, so it spans
+    several batches while the coder wave is inside it."""
+    fa, sam, _, _ = synth.dataset(77, [60000], [600], 150, sub_rate=0.45, indel_frac=0.3)
+    pb = host.pack_sam(sam, fa, block_reads=256)
+    _check_blocks(enc, pb, sam)
