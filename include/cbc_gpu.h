@@ -56,7 +56,8 @@ extern "C" {
 #define CBC_ST_CAP_VAR      5   /* more var symbols than lds.cap_var                            */
 #define CBC_ST_CAP_NAME     6   /* contig name longer than CBC_CAP_NAME-3                       */
 #define CBC_ST_UNSUPPORTED  7   /* raw leading-S / '*' op in the tokens (the packer emits a leading  */
-                                /* soft clip as an I op after rebuilding MD, quirk Q6)             */
+                                /* soft clip as an I op after rebuilding MD, quirk Q6); a block    */
+                                /* of more than CBC_MAX_BLOCK_READS records; a LOSSY stream         */
 
 /* ---- packed record layout (device and host share it) ---------------------------------------- */
 

@@ -292,3 +292,21 @@ def test_reads_with_dozens_of_edits(built):
     fa, sam, _, _ = synth.dataset(77, [60000], [600], 150, sub_rate=0.45, indel_frac=0.3)
     pb = host.pack_sam(sam, fa, block_reads=256)
     _check(pb, sam)
+
+
+def test_block_larger_than_the_contract_is_refused(built):
+    """The per-record models are coded as counting models, which holds while no total can reach the 2^20 rescale
+    point, i.e. up to CBC_MAX_BLOCK_READS records per block: a descriptor that claims more comes back as
+    CBC_ST_UNSUPPORTED (7) and the other blocks are unaffected (the decoder has the same check)."""
+    pb = host.synth(12, 3_000_000, 40000, 150, block_reads=16384)
+    assert pb.n_blocks == 3
+    ok_payloads, ok_res = blockref.emu_encode(pb)
+    assert (ok_res["status"] == 0).all()
+    saved = int(pb.blocks[0]["n_reads"])
+    pb.blocks[0]["n_reads"] = saved + 1                       # reaches into the next block's first record
+    try:
+        payloads, res = blockref.emu_encode(pb)
+    finally:
+        pb.blocks[0]["n_reads"] = saved
+    assert int(res[0]["status"]) == 7 and payloads[0] == b""
+    assert payloads[1:] == ok_payloads[1:]
