@@ -664,7 +664,9 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     uint8_t *tmpb = (uint8_t *)(lds + CBC_DLDS_TMP);
     uint32_t *dels = lds + CBC_DLDS_DELS, *insl = lds + CBC_DLDS_INS;
 
-    V32 pend_w = W::splat(0u); uint8_t *pend_dst = seqo; uint32_t pend_rl = 0;
+    /* a perfect read is its reference window: the window register of record r is stored at the top of record
+     * r + 1 (or after the loop), by when its load has long completed -- no copy, no wait */
+    V32 refw = W::splat(0u); uint8_t *pend_dst = seqo; uint32_t pend_rl = 0;
     V32 sr_fh = W::splat(0u), t_fh = W::splat(0u);
 #if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long dt_last = 0, dt_sum[16];
@@ -673,6 +675,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
 #endif
     for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) {
         D.cur_read = r;
+        if (pend_rl) { W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl); pend_rl = 0; }   /* record r - 1 was perfect */
         if ((r & 63u) == 0u) {                               /* scaled fractions of the closed-form symbols of 64 records */
             const V32 rdv = ln + r;
             sr_fh = W::frac32(rdv * 10u - 9u, rdv * 10u + 2u);     /* same_ref symbol 0 of record r >= 1 */
@@ -720,7 +723,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         if (pos == 0u || pos + rl + 3u + 256u > ref_lim) { D.fail(CBC_ST_ASSERT); break; }
         /* the reference window of the read, 4 bases per lane: issued now, needed after the match flag
          * (perfect read: it IS the read) or after the edits (SNP-only read: patched in place) */
-        const V32 refw = W::load32_bytes(refb + (pos - 1u), ln * 4u, (ln * 4u) < rl);
+        refw = W::load32_bytes(refb + (pos - 1u), ln * 4u, (ln * 4u) < rl);
 
         CBC_DT(3);                                            /* flag */
         /* -- match -- */
@@ -731,11 +734,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         V32 bo = ln * 4u;
         CBC_DT(4);                                            /* match */
         if (match) {
-            /* a perfect read is a copy of the reference window (loaded above): the store goes out when the
-             * next such read comes by (or at the end), so the wave never sits on the load */
-            if (pend_rl) W::store32_bytes(pend_dst, bo, pend_w, bo < pend_rl);
-            pend_w = refw;
-            pend_dst = dst; pend_rl = rl;                          /* stride >= rl rounded to 4 */
+            pend_dst = dst; pend_rl = rl;                          /* stored at the top of the next record; stride >= rl rounded to 4 */
         } else {
             uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
             CBC_DT(7);                                        /* snps count */
@@ -837,7 +836,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         CBC_DT(6);                                            /* record store */
     }
 
-    if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, pend_w, (ln * 4u) < pend_rl);
+    if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl);
 
     /* sentinel: same_ref(1), '\n', NUL (compression.c:152; decompress_rname returns -1 on it) */
     if (D.status == CBC_ST_OK) {
