@@ -70,7 +70,7 @@ struct CbcDec {
     V32 small, fkey, fexc, hkey, hexc, pval, pcnt;
     uint32_t fcount, fn, hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;
     uint32_t *lds, *evp;
-    uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, cap_var, L0;
+    uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, nev1, cap_var, L0;
     uint32_t prevPos, prevM, prevChar;
     uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
     uint32_t vtag0, vtag1, vsum0, vsum1;
@@ -508,10 +508,13 @@ struct CbcDec {
         uint32_t m = 0;
         if ((bw1 & bb1) && (bw2 & bb2)) {
             W::list_fence();
-            const uint32_t nb = W::uni(nev);
+            /* two lists by the context's strand bit, one from each end of the area (cf. CbcEnc::var_code) */
+            const uint32_t strand1 = ctx & 1u;
+            const uint32_t cnt_s = strand1 ? nev1 : nev, base_s = strand1 ? cap_var - nev1 : 0u;
+            const uint32_t nb = W::uni(cnt_s);
             for (uint32_t b = 0; b < nb; b += 512u) {             /* eight coalesced loads in flight per trip */
                 V32 ev4[8];
-                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev4[q] = W::load32_list(ev, i, i < nev, 0xffffffffu); }
+                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev4[q] = W::load32_list(ev, i + base_s, i < cnt_s, 0xffffffffu); }
                 for (uint32_t q = 0; q < 8u; q++) {
                     const V32 e = ev4[q];
                     uint64_t bb = W::ballot((e >> 8) == ctx);     /* lanes past nev hold 0xffffffff: ctx 0xffffff never matches */
@@ -539,9 +542,9 @@ struct CbcDec {
         if (status != CBC_ST_OK) return 0u;
         if (x >= L0) { fail(CBC_ST_ASSERT); return 0u; }
         step(lo, cnt, n);
-        if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return 0u; }
-        W::append_list(ev, nev, (ctx << 8) | x);
-        nev++;
+        if (nev + nev1 >= cap_var) { fail(CBC_ST_CAP_VAR); return 0u; }
+        if (ctx & 1u) { nev1++; W::append_list(ev, cap_var - nev1, (ctx << 8) | x); }
+        else { W::append_list(ev, nev, (ctx << 8) | x); nev++; }
         return x;
     }
 
@@ -623,7 +626,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
 
     for (uint32_t b = 0; b < CBC_DLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_DLDS_FIXED);
     D.rlen_n = 255u; D.rl123_c0 = 1u; D.rl123_n = 255u; D.snps_n = L0; D.indels_n = L0; D.rn_count = 0;
-    D.pos_card = 1u; D.pos_n = 1u; D.nev = 0;
+    D.pos_card = 1u; D.pos_n = 1u; D.nev = 0; D.nev1 = 0;
     D.pval = W::splat(0xffffffffu); D.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
     D.fkey = W::splat(0u); D.fexc = W::splat(0u); D.fcount = 0; D.fn = 65536u;
     D.hkey = W::splat(0u); D.hexc = W::splat(0u);

@@ -133,7 +133,7 @@ struct CbcEnc {
     uint32_t snps_n, indels_n;
     uint32_t rn_count;
     uint32_t pos_card, cap_pos;              /* pos alphabet: value / occurrences / prefix by index, in LDS */
-    uint32_t nev, cap_var;
+    uint32_t nev, nev1, cap_var;             /* var events of strand 0 (from the bottom of the area) / strand 1 (from the top) */
     uint32_t vtag0, vtag1, vsum0, vsum1;     /* hot var contexts: tag (context) and total excess  */
     uint32_t L0;
 
@@ -817,10 +817,15 @@ struct CbcEnc {
         const uint32_t bb1 = 1u << (h1 & 31u), bb2 = 1u << (h2 & 31u);
         if ((bw1 & bb1) && (bw2 & bb2)) {
             W::list_fence();
-            const uint32_t nb = W::uni(nev);
+            /* the context's strand bit picks the list: strand 0 grows up from the bottom of the event area,
+             * strand 1 down from its top, so a scan reads half of the block's events and the two share the
+             * capacity */
+            const uint32_t strand1 = ctx & 1u;
+            const uint32_t cnt_s = strand1 ? nev1 : nev, base_s = strand1 ? cap_var - nev1 : 0u;
+            const uint32_t nb = W::uni(cnt_s);
             for (uint32_t b = 0; b < nb; b += 512u) {           /* eight coalesced loads in flight per trip */
                 V32 ev[8];
-                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev[q] = W::load32_list(var_ev, i, i < nev, 0xffffffffu); }
+                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev[q] = W::load32_list(var_ev, i + base_s, i < cnt_s, 0xffffffffu); }
                 for (uint32_t q = 0; q < 8u; q++) {
                     const V32 e = ev[q];
                     const uint64_t bc = W::ballot((e >> 8) == ctx);    /* lanes past nev hold 0xffffffff: never a context */
@@ -836,9 +841,9 @@ struct CbcEnc {
             else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
         }
         encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
-        if (nev >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
-        W::append_list(var_ev, nev, key);
-        nev++;
+        if (nev + nev1 >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
+        if (ctx & 1u) { nev1++; W::append_list(var_ev, cap_var - nev1, key); }
+        else { W::append_list(var_ev, nev, key); nev++; }
     }
 
     /* ---- snpInRef window: 256 bits in four scalars, no runtime-indexed arrays ---- */
@@ -977,7 +982,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.snps_n = L0; E.indels_n = L0;
     E.rn_count = 0;
     E.pos_card = 1u;                                         /* initialize_stream_model_pos :132-162: the escape */
-    E.nev = 0;
+    E.nev = 0; E.nev1 = 0;
     E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
     E.hkey = W::splat(0u); E.hexc = W::splat(0u);
     E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
