@@ -2,25 +2,37 @@
 """bench.py -- Mbases/s encoded (bit-exact) on synthetic 150 bp SAM, BASELINE.json's metric.
 
 One process per GPU.  A "step" is one pass of the hot path over one resident batch: the encode
-launch (one arithmetic stream per workgroup over every block: a model wavefront feeding a coder wavefront) + the device-side compaction of the
-per-block bitstreams, and for N > 1 the gather of every rank's bitstreams to rank 0 over RCCL
-(the path's one real exchange step).  Inputs are packed and resident in HBM before the timed
-region starts.  Work per GPU is fixed as N grows (each rank codes its own shard of `--reads`
-records), so scaling is "weak".
+launch (one arithmetic stream per workgroup over every block: a model wavefront feeding a coder
+wavefront) + the device-side compaction of the per-block bitstreams, and for N > 1 the gather of
+every rank's bitstreams to rank 0 over RCCL (the path's one real exchange step).  Inputs are packed
+and resident in HBM before the timed region starts.
 
-Prints ONE JSON line on rank 0 (see the task contract), with two extra objects:
-  roofline     -- algorithmic bytes (2*L+18 per read) / HIP-event kernel time vs 8 TB/s
-  cpu_baseline -- the oracle (CPU restatement, kind "port") timed single-threaded on this host on a
-                  bounded sample of the same workload, SAM parsing included (N=1, rank 0 only)
+  python bench.py --gpus N ...        launched bare: the parent starts N rank processes of itself
+                                      (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything
+                                      touches the GPU, forwards rank 0's JSON line and exits non-zero
+                                      if any rank does
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   also works
+
+--scaling weak (default): every rank codes its own cfg2-sized shard (`--reads` records per GPU, seed +
+rank), work per GPU fixed as N grows.  --scaling strong: ONE dataset of `--reads` records is cut into
+contiguous block ranges (cbc_amd.shard.shard_ranges); the container gathered on rank 0 is checked byte
+for byte against a single-GPU encode of the whole dataset.
+
+Prints ONE JSON line on rank 0 (see the task contract), with extra objects:
+  roofline     -- algorithmic bytes (2*L+18 per read) / HIP-event kernel time vs 8 TB/s,
+                  plus `issue`: the instruction-issue picture of the committed SQ counter pass
+  cpu_baseline -- CPU legs timed single-threaded on this host on a bounded sample of the same workload
+                  (N=1, rank 0 only): the oracle on SAM text (parse included) and the packed-input CPU
+                  port (parse excluded)
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,17 +41,18 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CHR1_LEN = 248_956_422          # human chr1-sized contig
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="records per GPU (cfg2: 10M)")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="records per GPU (weak) or in total (strong); cfg2: 10M")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--contig-len", type=int, default=CHR1_LEN)
     ap.add_argument("--block-reads", type=int, default=4096)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000,
-                    help="records of the same workload timed on one host core by the oracle (10 M ~ 11 s of CPU)")
+                    help="records of the same workload timed on one host core by the CPU legs (10 M ~ 11 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="encode", choices=["encode", "decode"],
                     help="encode = BASELINE.json's metric (default); decode = the mirror kernel on the same workload "
@@ -47,21 +60,80 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real path); gloo = rehearsal of the N>1 host logic when "
                          "several ranks must share one GPU (payloads take a detour through host memory)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` launched bare: start N rank processes of this script.  Nothing in this
+    parent imports torch or touches HIP; it only waits, forwards rank 0's stdout and reports failures."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in bad), file=sys.stderr)
+        return max(1, max(abs(rc) for _, rc in bad) & 0xff or 1)
+    return 0
+
+
+def issue_picture(root, tag_glob, kernel_ms, n_recs):
+    """roofline.issue: what the committed SQ counter pass of this same command says about the issue ports
+    (the number that binds here; the HBM fraction does not).  Counter values are per launch, summed over the chip."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(root, "profiles", tag_glob)))
+    if not cands:
+        return None, None, None
+    try:
+        pm = json.load(open(cands[-1]))
+    except Exception:
+        return None, None, None
+    sq = pm.get("SQ_per_launch") or {}
+    issue = None
+    if sq.get("SQ_INSTS_SALU") and sq.get("SQ_BUSY_CYCLES"):
+        n_cu, simd_per_cu = 256, 4
+        # shader cycles of one launch at the 2.4 GHz engine clock; the profile's own kernel time when it carries one
+        kcyc = (pm.get("kernel_ms") or kernel_ms) * 2.4e6
+        salu, valu = sq["SQ_INSTS_SALU"], sq["SQ_INSTS_VALU"]
+        waves = sq.get("SQ_WAVES")
+        issue = {"source": os.path.relpath(cands[-1], root),
+                 "salu_per_record": round(salu / n_recs, 1), "valu_per_record": round(valu / n_recs, 1),
+                 "lds_per_record": round(sq.get("SQ_INSTS_LDS", 0) / n_recs, 2),
+                 "waves_per_launch": waves}
+        if kcyc:
+            # one scalar unit per CU issues one wave-instruction per cycle; a SIMD issues one VALU wave-instruction per
+            # 2 cycles in wave64 on 32-wide SIMDs (MI355X_MICROARCH.md)
+            issue["salu_busy"] = round(salu / (kcyc * n_cu), 3)
+            issue["valu_busy"] = round(valu * 2 / (kcyc * n_cu * simd_per_cu), 3)
+            issue["inst_per_cycle_per_simd"] = round((salu + valu) / (kcyc * n_cu * simd_per_cu), 3)
+            if sq.get("SQ_WAVE_CYCLES"):
+                issue["mean_waves_per_simd"] = round(sq["SQ_WAVE_CYCLES"] * 4 / (kcyc * n_cu * simd_per_cu), 2)
+    return pm.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], root), issue
+
+
+def run_rank(args):
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
-        if args.gpus != 1 or world != 1:
-            sys.exit(2)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
-    from cbc_amd import gpu, host
+    from cbc_amd import gpu, host, shard
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the cbc hot path has no CPU fallback")
@@ -79,16 +151,18 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend="gloo")
+    strong = args.scaling == "strong" and world > 1
 
-    # ---- workload: this rank's shard (cfg2 shape), packed on the host, then made resident ----
+    # ---- workload (cfg2 shape), packed on the host, then made resident ----
     t0 = time.time()
-    pb = host.synth(0xCBC00002 + rank, args.contig_len, args.reads, args.read_len, 0.003, 0.02, b"chr1",
-                    block_reads=args.block_reads)
+    seed = 0xCBC00002 + (0 if strong else rank)
+    pb = host.synth(seed, args.contig_len, args.reads, args.read_len, 0.003, 0.02, b"chr1", block_reads=args.block_reads)
     t_gen = time.time() - t0
     enc = gpu.Encoder(dev_index)
     L = gpu.lib()
     blocks = pb.blocks.copy()
     scratch_bytes = int(L.cbc_gpu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data))
+    b0, b1 = shard.shard_ranges(blocks["n_reads"], world)[rank] if strong else (0, pb.n_blocks)
 
     def to_dev(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
@@ -96,27 +170,36 @@ def main():
     d_recs, d_seq, d_tok = to_dev(pb.recs), to_dev(pb.seq), to_dev(pb.tok)
     d_names, d_blocks, d_ref = to_dev(pb.names), to_dev(blocks), to_dev(pb.ref)
     d_out = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
-    d_res = torch.zeros(pb.n_blocks * 16, dtype=torch.uint8, device=dev)
+    d_res = torch.full((pb.n_blocks * 16,), 0xff, dtype=torch.uint8, device=dev)   # a block that never reports reads as failed
     d_offs = torch.zeros(pb.n_blocks + 1, dtype=torch.int64, device=dev)
     packed_cap = max(1 << 20, 8 * pb.n_recs)
     d_packed = torch.empty(packed_cap, dtype=torch.uint8, device=dev)
     caps = host.LdsCaps(pb.cap_pos, pb.cap_var)
-    db = gpu.DeviceBatch(d_recs.data_ptr(), d_seq.data_ptr(), d_tok.data_ptr(), d_names.data_ptr(),
-                         d_blocks.data_ptr(), pb.n_blocks, d_ref.data_ptr(), d_ref.numel(),
-                         d_out.data_ptr(), scratch_bytes, d_res.data_ptr(), d_seq.numel(), max(pb.n_tok, 1),
-                         pb.n_recs, caps)
+
+    def batch(lo, hi):
+        return gpu.DeviceBatch(d_recs.data_ptr(), d_seq.data_ptr(), d_tok.data_ptr(), d_names.data_ptr(),
+                               d_blocks.data_ptr() + 64 * lo, hi - lo, d_ref.data_ptr(), d_ref.numel(),
+                               d_out.data_ptr(), scratch_bytes, d_res.data_ptr() + 16 * lo, d_seq.numel(), max(pb.n_tok, 1),
+                               pb.n_recs, caps)
+
+    db = batch(b0, b1)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    n_bases, n_recs, n_blocks = pb.n_bases, pb.n_recs, pb.n_blocks
+    my_blocks = b1 - b0
+    n_recs = int(blocks["n_reads"][b0:b1].sum())
+    n_bases = int(pb.info["n_bases"][b0:b1].sum())
     lds_bytes = int(L.cbc_gpu_lds_bytes(ctypes.byref(caps)))
 
     gather_cap = None
     gather_list = None
     dec = None
 
-    def encode_once():
-        enc.encode_device(db, stream)
-        enc.compact_device(d_out.data_ptr(), d_blocks.data_ptr(), d_res.data_ptr(), n_blocks, d_offs.data_ptr(),
-                           d_packed.data_ptr(), packed_cap, stream)
+    def encode_once(d=None, lo=None, n=None):
+        d, lo, n = (db, b0, my_blocks) if d is None else (d, lo, n)
+        if n == 0:
+            return
+        enc.encode_device(d, stream)
+        enc.compact_device(d_out.data_ptr(), d_blocks.data_ptr() + 64 * lo, d_res.data_ptr() + 16 * lo, n,
+                           d_offs.data_ptr(), d_packed.data_ptr(), packed_cap, stream)
 
     def step():
         if args.mode == "decode":
@@ -129,30 +212,48 @@ def main():
     # first launch: check every block finished and size the gather
     encode_once()
     torch.cuda.synchronize()
-    res = d_res.cpu().numpy().view(host.RESULT_DTYPE)
+    res = d_res.cpu().numpy().view(host.RESULT_DTYPE)[b0:b1]
     if (res["status"] != 0).any():
         bad = int(np.nonzero(res["status"])[0][0])
-        raise SystemExit("block %d failed: status %d at record %d" % (bad, res[bad]["status"], res[bad]["fail_read"]))
-    payload_bytes = int(d_offs[-1].item())
+        raise SystemExit("block %d failed: status %d at record %d" % (b0 + bad, res[bad]["status"], res[bad]["fail_read"]))
+    payload_bytes = int(d_offs[my_blocks].item()) if my_blocks else 0
     n_symbols = int(res["n_symbols"].sum())
     first_payload = d_packed[:payload_bytes].clone()       # every later step must reproduce these bytes
+    strong_check = None
     if world > 1:
         m = torch.tensor([payload_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         gather_cap = min(packed_cap, (int(m.item()) + 4095) // 4096 * 4096)
         if rank == 0:
             gather_list = [torch.empty(gather_cap, dtype=torch.uint8, device=cdev) for _ in range(world)]
+    if strong:
+        # the container rank 0 assembles from the ranks' ranges == what ONE GPU produces for the whole dataset
+        def my_range(lo, hi):
+            assert (lo, hi) == (b0, b1)
+            return first_payload.to(cdev), torch.from_numpy(res["nbytes"].astype(np.int64)).to(cdev)
+        _, allp, alls = shard.encode_sharded(dist, blocks["n_reads"], my_range, cdev, dst=0)
+        if rank == 0:
+            whole = batch(0, pb.n_blocks)
+            encode_once(whole, 0, pb.n_blocks)
+            torch.cuda.synchronize()
+            full_bytes = int(d_offs[pb.n_blocks].item())
+            full = d_packed[:full_bytes].to(cdev)
+            strong_check = bool(allp.numel() == full_bytes and torch.equal(allp, full))
+            if not strong_check:
+                raise SystemExit("bench.py: the gathered container differs from the single-GPU container")
+            encode_once()                                  # leave this rank's own range in d_packed again
+            torch.cuda.synchronize()
 
     if args.mode == "decode":
         # lay the decode launch out over the compacted payloads that are already resident
         stride = (args.read_len + 3) // 4 * 4
-        offs = d_offs.cpu().numpy().astype(np.uint64)
-        dblocks = np.zeros(n_blocks, dtype=host.DEC_BLOCK_DTYPE)
+        offs = d_offs.cpu().numpy().astype(np.uint64)[:my_blocks + 1]
+        dblocks = np.zeros(my_blocks, dtype=host.DEC_BLOCK_DTYPE)
         dblocks["in_off"] = offs[:-1]
         dblocks["in_bytes"] = (offs[1:] - offs[:-1]).astype(np.uint32)
-        dblocks["ref_off"] = blocks["ref_off"]
-        dblocks["n_reads"] = blocks["n_reads"]
-        rb = np.concatenate([[0], np.cumsum(blocks["n_reads"].astype(np.uint64))])[:-1]
+        dblocks["ref_off"] = blocks["ref_off"][b0:b1]
+        dblocks["n_reads"] = blocks["n_reads"][b0:b1]
+        rb = np.concatenate([[0], np.cumsum(blocks["n_reads"][b0:b1].astype(np.uint64))])[:-1]
         dblocks["rec_base"] = rb
         dblocks["seq_base"] = rb * stride
         dblocks["read_length"] = args.read_len
@@ -160,9 +261,9 @@ def main():
         dec = {"blocks": to_dev(dblocks),
                "recs": torch.zeros(n_recs * 16, dtype=torch.uint8, device=dev),
                "seq": torch.zeros(n_recs * stride + 16, dtype=torch.uint8, device=dev),
-               "res": torch.zeros(n_blocks * 16, dtype=torch.uint8, device=dev),
-               "vs": torch.zeros(max(n_blocks * pb.cap_var, 1), dtype=torch.int32, device=dev)}
-        dec["db"] = gpu.DecDeviceBatch(d_packed.data_ptr(), packed_cap, dec["blocks"].data_ptr(), n_blocks,
+               "res": torch.full((my_blocks * 16,), 0xff, dtype=torch.uint8, device=dev),
+               "vs": torch.zeros(max(my_blocks * pb.cap_var, 1), dtype=torch.int32, device=dev)}
+        dec["db"] = gpu.DecDeviceBatch(d_packed.data_ptr(), packed_cap, dec["blocks"].data_ptr(), my_blocks,
                                        d_ref.data_ptr(), d_ref.numel(), dec["recs"].data_ptr(), n_recs,
                                        dec["seq"].data_ptr(), dec["seq"].numel(), dec["res"].data_ptr(),
                                        dec["vs"].data_ptr(), dec["vs"].numel(), caps)
@@ -171,8 +272,9 @@ def main():
         dres = dec["res"].cpu().numpy().view(host.RESULT_DTYPE)
         if (dres["status"] != 0).any():
             raise SystemExit("decode failed: %r" % (dres[dres["status"] != 0][:1],))
+        r0 = int(blocks["rec_base"][b0]) if my_blocks else 0
         got = dec["seq"][:n_recs * stride].view(n_recs, stride)[:, :args.read_len].cpu().numpy()
-        if not (got == pb.seq[:n_recs * args.read_len].reshape(n_recs, args.read_len)).all():
+        if not (got == pb.seq[r0 * args.read_len:(r0 + n_recs) * args.read_len].reshape(n_recs, args.read_len)).all():
             raise SystemExit("decode does not reproduce the packed bases")
 
     for _ in range(args.warmup):
@@ -203,7 +305,8 @@ def main():
 
     if args.mode == "encode":
         torch.cuda.synchronize()
-        if int(d_offs[-1].item()) != payload_bytes or not torch.equal(d_packed[:payload_bytes], first_payload):
+        now_bytes = int(d_offs[my_blocks].item()) if my_blocks else 0
+        if now_bytes != payload_bytes or not torch.equal(d_packed[:payload_bytes], first_payload):
             raise SystemExit("bench.py: the timed launches did not reproduce the first launch's bitstreams")
 
     ms_per_step = elapsed * 1e3 / args.steps
@@ -212,20 +315,15 @@ def main():
     alg_bytes = (2 * args.read_len + 18) * n_recs          # per launch, this rank
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3
-    # passes of this same command (profiles/README.md) are reported when the workload is the default one.
-    traffic, traffic_src = None, None
-    if args.mode == "encode" and args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
-        if cands:
-            try:
-                traffic = json.load(open(cands[-1])).get("hbm_bytes_per_launch")
-                traffic_src = os.path.relpath(cands[-1], ROOT)
-            except Exception:
-                traffic = None
+    # HBM traffic and issue-port counters per launch: PMC counters cannot be read from inside this process; the
+    # committed rocprofv3 passes of this same command (profiles/README.md) are reported for the default workload.
+    traffic, traffic_src, issue = None, None, None
+    if args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096 and not strong:
+        traffic, traffic_src, issue = issue_picture(
+            ROOT, "r*_pmc_hbm.json" if args.mode == "encode" else "r*_decode_pmc.json", k_ms, n_recs)
 
     cpu = None
+    whole_file_bits = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle                            # checker, timed as the reported baseline
         sample = min(args.cpu_sample_reads, args.reads)
@@ -234,39 +332,60 @@ def main():
         t1 = time.perf_counter()
         data, st = oracle.encode(sam, fa, return_stats=True)
         t_cpu = time.perf_counter() - t1
+        whole_file_bits = round(len(data) * 8.0 / max(st.n_records, 1), 3)
         cpu = {"value": round(st.n_bases / t_cpu / 1e6, 2), "unit": "Mbases/s", "cores": 1, "kind": "port",
                "sample": "%d reads x %d bp of the same synthetic workload%s, one whole-file stream, SAM text "
                          "parsing and FASTA load included, %.1f s of CPU" % (
                              sample, args.read_len, " (all of it)" if sample == args.reads else "", t_cpu),
                "host_cpus": os.cpu_count()}
+        del sam, fa, data
+        if hasattr(oracle, "cpu_encode_blocks"):
+            # parse excluded: the same packed blocks the GPU codes, through the CPU port with the C ABI's signature
+            t1 = time.perf_counter()
+            cres = oracle.cpu_encode_blocks(spb)
+            t_blk = time.perf_counter() - t1
+            cpu["parse_excluded"] = {"value": round(spb.n_bases / t_blk / 1e6, 2), "unit": "Mbases/s", "cores": 1,
+                                     "sample": "the same %d reads as packed blocks (no text parsing), block by block, %.1f s" % (sample, t_blk),
+                                     "payload_bytes": int(cres)}
         spb.close()
 
     if rank == 0:
+        n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         out = {
             "metric": "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM" if args.mode == "encode"
                       else "Mbases/s decoded (round trip verified) on synthetic 150 bp SAM",
             "value": round(value, 2), "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %d bp SAM, %d reads per GPU vs a chr1-sized (%d bp) uniform-ACGT "
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %d bp SAM, %d reads %s vs a chr1-sized (%d bp) uniform-ACGT "
                                    "contig, block-parallel %s" % (
                                        {10_000_000: "cfg2", 49_791_284: "cfg3 (30x)"}.get(args.reads, "custom"),
-                                       args.read_len, args.reads, args.contig_len, args.mode),
-                       "reads_per_gpu": n_recs, "blocks_per_gpu": n_blocks, "block_reads": args.block_reads,
-                       "lds_bytes_per_block": lds_bytes, "payload_bytes_per_gpu": payload_bytes,
-                       "bits_per_read": round(payload_bytes * 8.0 / n_recs, 3),
-                       "symbols_per_read": round(n_symbols / n_recs, 3),
+                                       args.read_len, args.reads, "in total" if strong else "per GPU", args.contig_len, args.mode),
+                       "reads_rank0": n_recs, "blocks_rank0": my_blocks, "block_reads": args.block_reads,
+                       "lds_bytes_per_block": lds_bytes, "payload_bytes_rank0": payload_bytes,
+                       "bits_per_read": round(payload_bytes * 8.0 / max(n_recs, 1), 3),
+                       "whole_file_bits_per_read": whole_file_bits,
+                       "symbols_per_read": round(n_symbols / max(n_recs, 1), 3),
                        "parallelism": "blocks sharded over %d GPU(s), gather of bitstreams to rank 0 (%s)" % (world, args.backend),
+                       "gathered_equals_single_gpu": strong_check,
                        "host_pack_seconds": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "cbc_%s_blocks_kernel%s" % (args.mode, "_w6" if args.mode == "encode" and n_blocks > 10 * torch.cuda.get_device_properties(dev).multi_processor_count else ""), "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "cbc_%s_blocks_kernel%s" % (args.mode, "_w6" if args.mode == "encode" and my_blocks > 10 * n_cus else ""),
+                         "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
+                         "issue": issue},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

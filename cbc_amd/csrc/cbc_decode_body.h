@@ -615,9 +615,11 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = A.cap_var; D.L0 = L0;
     D.evp = A.var_scratch + (uint64_t)blk * A.cap_var;
     /* the payload buffer must leave 3 spare bytes after the last payload (whole-dword reads) */
-    bool args_ok = cbc_le64(in_off + (((uint64_t)in_bytes + 3u) & ~3ull), A.in_bytes) && cbc_le64(rec_base + n_reads, A.n_recs) &&
-                   cbc_le64(seq_base + (uint64_t)n_reads * stride + 8u, A.seq_bytes) && (L0 >= 1u && L0 <= 256u) &&
-                   (stride >= 4u && stride <= 256u && (stride & 3u) == 0u) && cbc_le64(ref_off, A.ref_bytes) &&
+    /* every range test is written without the sum base + length, which a crafted descriptor could make wrap */
+    bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
+                   (stride >= 4u && stride <= 256u && (stride & 3u) == 0u) &&
+                   cbc_fits64(seq_base, (uint64_t)n_reads * stride + 8u, A.seq_bytes) && (L0 >= 1u && L0 <= 256u) &&
+                   cbc_le64(ref_off, A.ref_bytes) &&
                    cbc_le64(((uint64_t)blk + 1u) * A.cap_var, A.var_scratch_words);
     D.nwords_in = (in_bytes + 3u) >> 2;
     D.tail_valid = in_bytes & 3u;
@@ -717,13 +719,14 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         if (D.status != CBC_ST_OK) break;
         if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); break; }
         uint32_t pos = D.prevPos + x - 1u;
+        if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); break; }     /* the 32-bit sum wrapped: not a position of this window */
         D.win_shift(r == 0u ? 256u : x - 1u);
         D.prevPos = pos;
         CBC_DT(2);                                            /* pos */
         uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
         if (D.status != CBC_ST_OK) break;
         const uint32_t strand = (flag >> 4) & 1u;
-        if (pos == 0u || pos + rl + 3u + 256u > ref_lim) { D.fail(CBC_ST_ASSERT); break; }
+        if (pos == 0u || pos > ref_lim || ref_lim - pos < rl + 3u + 256u) { D.fail(CBC_ST_ASSERT); break; }
         /* the reference window of the read, 4 bases per lane: issued now, needed after the match flag
          * (perfect read: it IS the read) or after the edits (SNP-only read: patched in place) */
         refw = W::load32_bytes(refb + (pos - 1u), ln * 4u, (ln * 4u) < rl);

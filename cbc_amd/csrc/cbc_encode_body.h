@@ -902,6 +902,12 @@ CBC_FN bool cbc_le64(uint64_t a, uint64_t b)
     uint32_t ah = (uint32_t)(a >> 32), al = (uint32_t)a, bh = (uint32_t)(b >> 32), bl = (uint32_t)b;
     return (ah < bh) | ((ah == bh) & (al <= bl));
 }
+/* [off, off + len) lies inside a buffer of `total` bytes; written without the sum off + len, which a
+ * crafted descriptor could make wrap */
+CBC_FN bool cbc_fits64(uint64_t off, uint64_t len, uint64_t total)
+{
+    return cbc_le64(off, total) && cbc_le64(len, total - off);
+}
 CBC_FN uint32_t cbc_avail32(uint64_t total, uint32_t off)
 {
     uint64_t a = total - off;                       /* callers guarantee off <= total or get 0 below */
@@ -951,9 +957,9 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.cap_words = payload_cap >> 2;
     E.var_ev = (uint32_t *)(A.out + out_off + payload_cap);
     E.cap_var = payload_cap <= out_cap ? (out_cap - payload_cap) >> 2 : 0u;
-    bool args_ok = cbc_le64(out_off + out_cap, A.out_bytes) && ((out_off & 3u) == 0) && ((payload_cap & 3u) == 0) &&
+    bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0) && ((payload_cap & 3u) == 0) &&
                    (payload_cap <= out_cap) &&
-                   cbc_le64(rec_base + n_reads, A.n_recs) && cbc_le64(tok_base + n_tok_blk, A.n_tok) &&
+                   cbc_fits64(rec_base, n_reads, A.n_recs) && cbc_fits64(tok_base, n_tok_blk, A.n_tok) &&
                    (L0 >= 1u && L0 <= 256u) && (name_off < A.names_bytes);
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
     /* the closed forms of fixed_group() hold while no per-record model can reach its rescale point */

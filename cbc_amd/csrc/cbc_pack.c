@@ -312,6 +312,60 @@ static int contig_open(packer_t *S, const char *rname, size_t nl)
     return 0;
 }
 
+
+/* ---- MD text derived from an alignment (quirk Q6: what the reference's compress_edits leaves in the record's
+ * MD buffer when the CIGAR starts with a soft clip and the read is imperfect, read_compression.c:357-468).
+ * Walk the ops after the clip with a cursor in the read (starts behind the clip) and one in the contig (starts
+ * at POS): an M op compares base by base and writes "<run><contig letter>" for every mismatch (run 0 included);
+ * I skips read bases; D closes the current run (only if > 0), writes '^' and the deleted contig letters -- taken
+ * one base FURTHER than the cursor (no -1 there, :425) -- and moves the contig cursor; a trailing S only closes
+ * the run; at the end the run is written if > 0.  Nothing terminates the text except the NUL that comes with a
+ * number, so when the last thing written is a letter the buffer's older content follows it (:460 clears a
+ * pointer, not the string) -- which is why this writes into the persistent buffer and not into a fresh one.
+ * Returns 0, -1 = an op runs past SEQ or past the contig + pad, -2 = no room in the buffer. */
+typedef struct { char *at, *end; } md_text;
+static int md_number(md_text *w, uint32_t v)
+{
+    if (w->end - w->at < 12) return -2;
+    w->at += sprintf(w->at, "%u", v);            /* leaves its NUL at *w->at */
+    return 0;
+}
+static int md_letter(md_text *w, uint8_t c)
+{
+    if (w->end - w->at < 2) return -2;
+    *w->at++ = (char)c;                          /* no terminator: see above */
+    return 0;
+}
+static int md_from_alignment(char *buf, size_t buf_len, const uint32_t *ops, uint32_t n_ops, uint32_t clip_len,
+                             const uint8_t *read, uint32_t read_len, const uint8_t *contig, uint32_t pos, uint64_t contig_avail)
+{
+    md_text w = { buf, buf + buf_len };
+    uint64_t in_read = clip_len, in_contig = pos;         /* next read index (0-based); next contig base (1-based) */
+    uint32_t run = 0;
+    int rc = 0;
+    for (uint32_t k = 0; k < n_ops && !rc; k++) {
+        const uint32_t kind = ops[k] & 15u; const uint64_t n = ops[k] >> 4;
+        if (kind == CBC_OP_M) {
+            if (in_read + n > read_len || in_contig - 1 + n > contig_avail) return -1;
+            for (uint64_t j = 0; j < n && !rc; j++) {
+                const uint8_t have = read[in_read + j], want = contig[in_contig - 1 + j];
+                if (have == want) run++;
+                else { rc = md_number(&w, run); if (!rc) rc = md_letter(&w, want); run = 0; }
+            }
+            in_read += n; in_contig += n;
+        } else if (kind == CBC_OP_I) in_read += n;
+        else if (kind == CBC_OP_D) {
+            if (in_contig + n > contig_avail) return -1;
+            if (run) { rc = md_number(&w, run); run = 0; }
+            if (!rc) rc = md_letter(&w, '^');
+            for (uint64_t j = 0; j < n && !rc; j++) rc = md_letter(&w, (uint8_t)toupper(contig[in_contig + j]));
+            in_contig += n;
+        } else if (kind == CBC_OP_S) { if (run) { rc = md_number(&w, run); run = 0; } }
+    }
+    if (!rc && run) rc = md_number(&w, run);
+    return rc;
+}
+
 /* CIGAR + MD of one mapped record -> token words tk[0..*nt_out) and the record's var-symbol bound.
  * Reads only shared, already final state (P->ref, the contig table), so worker threads may call it. */
 static int tokenise_record(packer_t *S, const cbc_contig_info *ctg, const char *rname, int32_t pos_i, const char *cigar,
@@ -328,6 +382,7 @@ static int tokenise_record(packer_t *S, const cbc_contig_info *ctg, const char *
     /* ---- tokens: CIGAR ---- */
     uint32_t nt = 2, n_cig = 0, n_md = 0;
     uint32_t ev = 0;                                    /* upper bound on var symbols of this record */
+    int lead_clip = 0;                                  /* the first CIGAR op is a soft clip (quirk Q6) */
     {
         const char *seg = cigar; int i = 0;
         while (*seg != 0) {                             /* read_compression.c:308-549 scanning rule */
@@ -343,59 +398,26 @@ static int tokenise_record(packer_t *S, const cbc_contig_info *ctg, const char *
                     if (nt >= 2 * LINE_BUF) return fail(S, CBC_E_INPUT, "CIGAR %s too long%lld", cigar, 0);
                     tk[nt++] = ((uint32_t)v << 4) | op; n_cig++;
                     if (op == CBC_OP_STAR) return fail(S, CBC_E_INPUT, "CIGAR '*' on a mapped record at %s:%lld (the reference aborts on it)", rname, pos);
-                    if (op == CBC_OP_S && n_cig == 1) {
-                        /* Leading soft clip (quirk Q6, read_compression.c:357-468).  For an imperfect read
-                         * the reference REBUILDS the MD string in place from the read and the reference
-                         * (over the ops that follow the clip), then treats the clipped bases exactly like an
-                         * insertion at matched coordinate 0 (Insers[].pos = 0, targetChar = read[ctrS], with
-                         * the add_snps_to_array early-return rule).  The rebuild is restated here on the
-                         * persistent MD buffer; the clip is then emitted as an I op, which the kernels
-                         * already code that way. */
-                        const uint8_t *refc = P->ref + ctg->ref_off;      /* reference[] of this contig, 0-based */
-                        if (memcmp(seq, refc + (pos - 1), rl) != 0) {      /* only reached when the match test fails */
-                            char *te = (char *)edits;
-                            uint32_t posRef = pos, posRead = (uint32_t)v, match = 0;
-                            const char *tc = seg + i + 1; int ti = 0;
-                            while (*tc != 0) {
-                                char c2 = tc[ti];
-                                if (c2 == 0) break;
-                                if (!isdigit((unsigned char)c2)) {
-                                    long tv = atoi(tc);
-                                    if (tv < 0 || tv > 4096) return fail(S, CBC_E_INPUT, "CIGAR %s: bad length %lld", cigar, tv);
-                                    if (c2 == 'M') {
-                                        for (long c3 = 0; c3 < tv; c3++) {
-                                            uint8_t rb = (size_t)(posRead + c3) < rl ? (uint8_t)seq[posRead + c3] : 0;
-                                            uint8_t fb = refc[posRef - 1 + c3];
-                                            if (rb == fb) match++;
-                                            else { te += sprintf(te, "%u", match); match = 0; *te++ = (char)fb; }
-                                            if (te - edits > 2 * LINE_BUF - 16) return fail(S, CBC_E_INPUT, "rebuilt MD too long at %s:%lld", rname, pos);
-                                        }
-                                        posRef += (uint32_t)tv; posRead += (uint32_t)tv; tc = tc + ti + 1; ti = -1;
-                                    } else if (c2 == 'I') { posRead += (uint32_t)tv; tc = tc + ti + 1; ti = -1; }
-                                    else if (c2 == 'D') {
-                                        if (match > 0) { te += sprintf(te, "%u", match); match = 0; }
-                                        *te++ = '^';
-                                        for (long c3 = 0; c3 < tv; c3++) *te++ = (char)toupper(refc[posRef + c3]);   /* sic: no -1 (:425) */
-                                        if (te - edits > 2 * LINE_BUF - 16) return fail(S, CBC_E_INPUT, "rebuilt MD too long at %s:%lld", rname, pos);
-                                        posRef += (uint32_t)tv; tc = tc + ti + 1; ti = -1;
-                                    } else if (c2 == 'S') {
-                                        if (match > 0) { te += sprintf(te, "%u", match); match = 0; }
-                                        tc = tc + ti + 1; ti = -1;
-                                    }
-                                }
-                                ti++;
-                            }
-                            if (match > 0) te += sprintf(te, "%u", match);
-                            /* ":460 tmpEdits = 0" nulls the pointer, not the string: the old MD's tail stays
-                             * unless the last thing written was a number (sprintf's own NUL) */
-                        }
-                        tk[nt - 1] = ((uint32_t)v << 4) | CBC_OP_I;
-                    }
+                    if (op == CBC_OP_S && n_cig == 1) { lead_clip = 1; tk[nt - 1] = ((uint32_t)v << 4) | CBC_OP_I; }
                     if (op != CBC_OP_M) ev += (uint32_t)v;
                     seg = seg + i + 1; i = -1;
                 }
             }
             i++;
+        }
+    }
+    if (lead_clip) {
+        /* Leading soft clip (quirk Q6, read_compression.c:357-468).  The clipped bases are coded exactly like
+         * an insertion at matched coordinate 0 (the op was stored as CBC_OP_I above, which the kernels
+         * already code that way), and for an IMPERFECT read the reference first replaces the record's MD
+         * text by one it derives from the alignment itself (over the ops after the clip).  Only then. */
+        const uint8_t *contig_bases = P->ref + ctg->ref_off;
+        if (memcmp(seq, contig_bases + (pos - 1), rl) != 0) {
+            int rc = md_from_alignment((char *)edits, 2 * LINE_BUF, tk + 3, n_cig - 1, tk[2] >> 4,
+                                       (const uint8_t *)seq, (uint32_t)rl, contig_bases, pos,
+                                       ctg->length + CBC_REF_PAD);
+            if (rc == -1) return fail(S, CBC_E_INPUT, "CIGAR of the soft-clipped record at %s:%lld runs past SEQ or past the contig", rname, pos);
+            if (rc == -2) return fail(S, CBC_E_INPUT, "derived MD too long at %s:%lld", rname, pos);
         }
     }
     /* ---- tokens: MD (add_snps_to_array scanning rule, consumption branch :661-695) ---- */
@@ -1175,7 +1197,9 @@ API int cbc_unpack_plan_create(const uint8_t *blob, uint64_t len, const char *fa
             const uint8_t *e = btab + 32ull * b;
             uint32_t contig = r32(e), nreads = r32(e + 4), pbytes = r32(e + 24);
             uint64_t w0 = r64(e + 8), poff = r64(e + 16);
-            if (contig >= nc || poff + pbytes > pay_bytes || w0 >= S->P->contigs[contig].length + 1) {
+            /* no sums of file-supplied values: poff + pbytes could wrap */
+            if (contig >= nc || poff > pay_bytes || pbytes > pay_bytes - poff || w0 >= S->P->contigs[contig].length + 1 ||
+                nreads > CBC_MAX_BLOCK_READS) {
                 rc = fail(S, CBC_E_INPUT, "corrupt block index entry %s%lld", "", b); goto fail; }
             cbc_dec_block_desc *d = &u->blocks[b];
             d->in_off = poff; d->in_bytes = pbytes; d->ref_off = S->P->contigs[contig].ref_off + w0;

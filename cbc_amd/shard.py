@@ -61,3 +61,18 @@ def gather_bitstreams(dist, local_packed, local_sizes, device, dst=0):
     payload = torch.cat([gl_b[r][:nbytes[r]] for r in range(world)])
     sizes = torch.cat([gl_s[r][:nblk[r]] for r in range(world)])
     return payload, sizes
+
+
+def encode_sharded(dist, block_reads, encode_range, device, dst=0):
+    """The strong-scaling step: ONE dataset, every rank codes its contiguous block range, rank `dst`
+    receives the bitstreams in global block order.
+
+    block_reads: per-block record counts of the WHOLE dataset (identical on every rank);
+    encode_range(b0, b1) -> (uint8 tensor of the range's payloads in block order, int64 tensor of their
+    sizes), both on `device`.  Returns (range, payload, sizes): payload/sizes are None off `dst`.
+    bench.py --scaling strong and tests/test_shard_gloo.py both go through here."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    b0, b1 = shard_ranges(block_reads, world)[rank]
+    local, sizes = encode_range(b0, b1)
+    payload, allsizes = gather_bitstreams(dist, local, sizes, device, dst=dst)
+    return (b0, b1), payload, allsizes

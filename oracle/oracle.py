@@ -23,8 +23,8 @@ class OracleStats(ctypes.Structure):
 
 def build(force=False):
     """Compile the restatement with gcc (seconds)."""
-    src = os.path.join(_HERE, "cbc_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "cbc_oracle.c"), os.path.join(_HERE, "cbc_cpu.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libcbc_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -46,6 +46,14 @@ def lib():
             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
             ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
         L.cbc_oracle_version.restype = ctypes.c_char_p
+        L.cbc_cpu_init.restype = ctypes.c_int
+        L.cbc_cpu_init.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.cbc_cpu_shutdown.argtypes = [ctypes.c_void_p]
+        L.cbc_cpu_upload_reference.restype = ctypes.c_int
+        L.cbc_cpu_upload_reference.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_cpu_encode_blocks.restype = ctypes.c_int
+        L.cbc_cpu_encode_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                            ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -81,3 +89,33 @@ def decode(stream: bytes, fasta: bytes, max_out: int = None):
     if n < 0:
         raise OracleError("oracle decode failed: %s (%d)" % (_ERR.get(n, "?"), n))
     return out.raw[:n], nr.value
+
+
+def cpu_encode_blocks(pb, blocks=None, return_payloads=False):
+    """The cbc_cpu_* entry points (oracle/cbc_cpu.c): the SAME packed batch the HIP library takes, coded block
+    by block on one core.  `blocks` = optional list of block indices (default: all).  Returns the total payload
+    bytes, or (list of payload bytes, results array) with return_payloads."""
+    import numpy as np
+    from cbc_amd import gpu, host          # struct layouts only (ctypes mirrors of include/cbc_gpu.h)
+    L = lib()
+    ctx = ctypes.c_void_p()
+    if L.cbc_cpu_init(0, ctypes.byref(ctx)) != 0:
+        raise OracleError("cbc_cpu_init failed")
+    try:
+        L.cbc_cpu_upload_reference(ctx, pb.ref.ctypes.data, pb.ref.size)
+        bl = pb.blocks.copy() if blocks is None else np.ascontiguousarray(pb.blocks[list(blocks)])
+        nb = len(bl)
+        hb = gpu.HostBatch(pb.recs.ctypes.data, pb.n_recs, pb.seq.ctypes.data, len(pb.seq), pb.tok.ctypes.data, pb.n_tok,
+                           pb.names.ctypes.data, len(pb.names), bl.ctypes.data, nb, host.LdsCaps(pb.cap_pos, pb.cap_var))
+        cap = int(4096 * nb + 48 * int(bl["n_reads"].sum()) + 8 * int(bl["n_tok"].sum())) + 4096
+        out = np.zeros(cap, dtype=np.uint8)
+        offs = np.zeros(nb + 1, dtype=np.uint64)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        rc = L.cbc_cpu_encode_blocks(ctx, ctypes.byref(hb), out.ctypes.data, cap, offs.ctypes.data, res.ctypes.data)
+        if rc not in (0, -4):
+            raise OracleError("cbc_cpu_encode_blocks failed: %d" % rc)
+        if not return_payloads:
+            return int(offs[nb])
+        return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res
+    finally:
+        L.cbc_cpu_shutdown(ctx)

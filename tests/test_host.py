@@ -389,3 +389,81 @@ def test_threaded_fasta_loader_equals_the_serial_one(built, threads):
     r1 = host.pack_sam(sam, fa2.replace(c[1].tobytes(), c[0][:100].tobytes()), threads=1)
     r2 = host.pack_sam(sam, fa2.replace(c[1].tobytes(), c[0][:100].tobytes()), threads=threads)
     assert np.array_equal(np.asarray(r1.ref), np.asarray(r2.ref))
+
+
+# ---------------------------------------------------------------- hostile inputs (advisor findings of round 1)
+def _container_with_block_entry(poff, pbytes, nreads=10):
+    """A syntactically valid one-contig, one-block container whose index entry holds the given values."""
+    import struct
+    fa, sam, _, _ = synth.dataset(3, [5000], [10], 100, sub_rate=0.0, indel_frac=0.0)
+    pb = host.pack_sam(sam, fa)
+    blob = bytearray(pb.container(np.zeros(4200, dtype=np.uint8), np.array([0, 4200], dtype=np.uint64)))
+    names_pad = (len(pb.names) + 3) & ~3
+    e = 36 + names_pad + 16 * 1                     # the block index follows the contig table
+    struct.pack_into("<IIQQII", blob, e, 0, nreads, 0, poff, pbytes, 0)
+    return bytes(blob), fa
+
+
+@pytest.mark.parametrize("poff,pbytes,nreads", [
+    (0xfffffffffffff000, 4100, 10),                 # poff + pbytes wraps to 4
+    (0xfffffffffffffff8, 16, 10),                   # wraps to 8
+    (0, 4200, 16385),                               # more records than a block may hold
+    (4000, 300, 10),                                # plain overrun
+])
+def test_unpack_plan_rejects_wrapping_block_index(built, poff, pbytes, nreads):
+    blob, fa = _container_with_block_entry(poff, pbytes, nreads)
+    with pytest.raises(host.CbcInputError, match="corrupt block index"):
+        host.UnpackPlan(blob, fa)
+    blob, fa = _container_with_block_entry(0, 4200, 10)      # the same entry with honest values parses
+    host.UnpackPlan(blob, fa).close()
+
+
+def test_decoder_refuses_descriptors_that_wrap(built):
+    """A descriptor whose in_off / rec_base / seq_base would wrap a 64-bit sum: the kernel body reports ASSERT
+    (emulation under bounds checks: no access happens)."""
+    import blockref
+    pb, sam, fa = host.synth(5, 300_000, 600, 100, want_text=True, block_reads=256)
+    payloads, res = blockref.emu_encode(pb)
+    plan = host.UnpackPlan(blockref.container_from_payloads(pb, payloads), fa)
+    good = plan.blocks.copy()
+    for field, val in (("in_off", 0xfffffffffffff000), ("rec_base", 0xffffffffffffff00), ("seq_base", 0xffffffffffff0000)):
+        plan.blocks[:] = good
+        plan.blocks[1][field] = val
+        recs, seq, dres = blockref.emu_decode(plan)
+        assert int(dres[1]["status"]) == 2, field
+        assert int(dres[0]["status"]) == 0 and int(dres[2]["status"]) == 0
+    plan.blocks[:] = good
+    plan.close()
+
+
+def test_soft_clip_cigar_past_the_contig_is_rejected_under_asan(built, tmp_path):
+    """CIGARs that walk off the reference / SEQ after a leading soft clip (the MD is derived from the alignment
+    there): input errors, checked on an AddressSanitizer build of the packer in a child process."""
+    import subprocess, sys, textwrap
+    csrc = os.path.join(ROOT, "cbc_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "libcbc_host_asan.so"], stdout=subprocess.DEVNULL)
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, synth
+        from cbc_amd import host
+        host.HOST_LIB = %r
+        rng = np.random.default_rng(1)
+        contig = synth.make_contig(rng, 3000)
+        fa = synth.fasta_text([("c", contig)])
+        def rec(cigar, md="5"):
+            seq = bytearray(contig[2800 - 1:2800 - 1 + 100].tobytes()); seq[0] = ord("A") if seq[0] != ord("A") else ord("C")
+            return synth.sam_text([("c", 3000, [dict(pos=2800, flag=0, cigar=cigar, seq=bytes(seq), md=md, nm=1)])])
+        n = 0
+        for cigar in ("1S" + "4096M" * 40, "1S10M4000D89M", "1S99M" + "300D" * 8, "1S200M"):
+            for threads in (1, 4):
+                try:
+                    host.pack_sam(rec(cigar), fa, threads=threads)
+                except host.CbcInputError as e:
+                    n += 1
+        print("REJECTED", n)
+    """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(csrc, "libcbc_host_asan.so")))
+    env = dict(os.environ, LD_PRELOAD=subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip(),
+               ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert "REJECTED 8" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

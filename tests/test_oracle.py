@@ -113,3 +113,46 @@ def test_leading_soft_clip_alone_round_trips():
     stream = oracle.encode(sam, fa)
     text, nr = oracle.decode(stream, fa)
     assert nr == 300 and text == _seqs(rbc)
+
+
+# ---- the packed-input CPU port (oracle/cbc_cpu.c: the cbc_cpu_* set with the C ABI's signatures) is pinned to
+# ---- the text path above: same bytes and same coder-step counts for every block
+def _cpu_port_equals_text_path(pb, sam):
+    import blockref
+    payloads, res = oracle.cpu_encode_blocks(pb, return_payloads=True)
+    assert (res["status"] == 0).all()
+    lines = blockref.mapped_sam_lines(sam)
+    for b in range(pb.n_blocks):
+        bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
+        exp, st = oracle.encode(bsam, bfa, return_stats=True)
+        assert payloads[b] == exp, "block %d" % b
+        assert int(res[b]["n_symbols"]) == st.n_symbols
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*_L*.json"))))
+def test_cpu_port_on_golden_vectors(built, path):
+    g = json.load(open(path))
+    pb = host.pack_sam(g["sam"].encode(), g["fasta"].encode(), block_reads=g["block_reads"])
+    payloads, res = oracle.cpu_encode_blocks(pb, return_payloads=True)
+    assert [p.hex() for p in payloads] == g["block_payload_hex"]
+
+
+@pytest.mark.parametrize("kw,L,br", [
+    (dict(), 150, 1024),
+    (dict(sub_rate=0.02, indel_frac=0.5, trailing_s_frac=0.2, dup_pos_frac=0.1), 100, 512),
+    (dict(flags=(0, 16, 83, 99, 147, 163)), 150, 2048),
+    (dict(sub_rate=0.45, indel_frac=0.3), 150, 256),
+])
+def test_cpu_port_equals_text_path(built, kw, L, br):
+    fa, sam, _, _ = synth.dataset(5, [300000, 120000], [2500, 900], L, **kw)
+    _cpu_port_equals_text_path(host.pack_sam(sam, fa, block_reads=br), sam)
+
+
+def test_cpu_port_soft_clips_and_subset(built):
+    from test_emu_parity import _soft_clip_sam
+    fa, sam = _soft_clip_sam(3)
+    pb = host.pack_sam(sam, fa, block_reads=256)
+    _cpu_port_equals_text_path(pb, sam)
+    allp, _ = oracle.cpu_encode_blocks(pb, return_payloads=True)
+    some, _ = oracle.cpu_encode_blocks(pb, blocks=[2, 0], return_payloads=True)
+    assert some == [allp[2], allp[0]]

@@ -34,14 +34,23 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pb = host.synth(21, 1_000_000, 6000, 100, block_reads=512)
-    payloads, res = blockref.emu_encode(pb)          # every rank can compute everything; it keeps its shard
-    b0, b1 = shard.shard_ranges(pb.blocks["n_reads"], world)[rank]
-    mine = payloads[b0:b1]
-    local = torch.from_numpy(np.frombuffer(b"".join(mine), dtype=np.uint8).copy()) if mine else torch.zeros(0, dtype=torch.uint8)
-    sizes = torch.tensor([len(p) for p in mine], dtype=torch.int64)
-    allp, alls = shard.gather_bitstreams(dist, local, sizes, torch.device("cpu"), dst=0)
+    payloads, res = blockref.emu_encode(pb)          # the single-rank result (every rank can compute it)
+    ran = []
+
+    def encode_range(b0, b1):
+        # this rank codes ONLY its block range (through the emulation of the kernel body: no GPU here)
+        mine = [p for _, p, _ in blockref.emu_encode_blocks(pb, range(b0, b1))]
+        ran.append((b0, b1))
+        local = torch.from_numpy(np.frombuffer(b"".join(mine), dtype=np.uint8).copy()) if mine else torch.zeros(0, dtype=torch.uint8)
+        return local, torch.tensor([len(p) for p in mine], dtype=torch.int64)
+
+    # the function bench.py --scaling strong runs: cut ONE dataset with shard_ranges, code the range, gather
+    (b0, b1), allp, alls = shard.encode_sharded(dist, pb.blocks["n_reads"], encode_range, torch.device("cpu"), dst=0)
+    assert ran == [(b0, b1)] and (b0, b1) == shard.shard_ranges(pb.blocks["n_reads"], world)[rank]
     if rank == 0:
-        q.put((allp.numpy().tobytes() == b"".join(payloads), alls.tolist() == [len(p) for p in payloads], pb.n_blocks))
+        offs = np.concatenate([[0], np.cumsum(alls.numpy())]).astype(np.uint64)
+        same_container = pb.container(allp.numpy(), offs) == blockref.container_from_payloads(pb, payloads)
+        q.put((allp.numpy().tobytes() == b"".join(payloads) and same_container, alls.tolist() == [len(p) for p in payloads], pb.n_blocks))
     dist.destroy_process_group()
 
 
@@ -58,3 +67,15 @@ def test_gather_two_ranks(built):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok_bytes and ok_sizes and nb >= 10
+
+
+def test_bench_spawns_its_own_ranks(built, tmp_path):
+    """`python bench.py --gpus N` launched bare (as the driver does) starts N rank processes before anything
+    touches the GPU and forwards rank 0's line; without a GPU every rank fails loudly and the parent reports
+    a non-zero status (the GPU run of the same command is in the -m gpu suite)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "1000",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr and "rank(s) failed: rank 0" in r.stderr
