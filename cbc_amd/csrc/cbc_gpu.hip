@@ -105,6 +105,7 @@ struct cbc_gpu_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     int have_timing;
+    int last_variant;              /* waves per SIMD of the encode build launched last */
     int n_cus;                     /* compute units of the device (block residency decides the kernel build) */
     uint8_t *d_ref; uint64_t ref_bytes;
     char err[512];
@@ -205,9 +206,9 @@ API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b
     A.names_bytes = 0x7fffffffu;   /* names are NUL-terminated; bounded by CBC_CAP_NAME in the kernel */
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
     if ((uint64_t)b->n_blocks > 10ull * (uint64_t)ctx->n_cus)     /* more blocks than are resident at 5 waves per SIMD */
-        hipLaunchKernelGGL(cbc_encode_blocks_kernel_w6, dim3(b->n_blocks), dim3(128), lds, s, A);
+        { hipLaunchKernelGGL(cbc_encode_blocks_kernel_w6, dim3(b->n_blocks), dim3(128), lds, s, A); ctx->last_variant = 6; }
     else
-        hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(128), lds, s, A);
+        { hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(128), lds, s, A); ctx->last_variant = 5; }
     HIPCHK(hipGetLastError(), "launch cbc_encode_blocks_kernel");
     HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
     ctx->have_timing = 1;
@@ -221,6 +222,8 @@ API int cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms)
     HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1), "hipEventElapsedTime");
     return CBC_OK;
 }
+
+API int cbc_gpu_last_kernel_variant(cbc_gpu_ctx *ctx) { return ctx ? ctx->last_variant : 0; }
 
 API int cbc_gpu_synchronize(cbc_gpu_ctx *ctx)
 {

@@ -101,6 +101,8 @@ def lib():
         L.cbc_gpu_lds_bytes.argtypes = [ctypes.POINTER(host.LdsCaps)]
         L.cbc_gpu_last_kernel_ms.restype = ctypes.c_int
         L.cbc_gpu_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.cbc_gpu_last_kernel_variant.restype = ctypes.c_int
+        L.cbc_gpu_last_kernel_variant.argtypes = [ctypes.c_void_p]
         L.cbc_gpu_synchronize.restype = ctypes.c_int
         L.cbc_gpu_synchronize.argtypes = [ctypes.c_void_p]
         if L.cbc_gpu_abi_version() != 1:
@@ -112,7 +114,7 @@ def lib():
 EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_gpu_shutdown", "cbc_gpu_last_error",
            "cbc_gpu_upload_reference", "cbc_gpu_encode_blocks", "cbc_gpu_encode_blocks_device", "cbc_gpu_compact_device",
            "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_decode_blocks_device", "cbc_gpu_decode_blocks",
-           "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_synchronize"]
+           "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_last_kernel_variant", "cbc_gpu_synchronize"]
 
 
 class Encoder:
@@ -183,6 +185,9 @@ class Encoder:
         ms = ctypes.c_float()
         self._check(lib().cbc_gpu_last_kernel_ms(self._ctx, ctypes.byref(ms)), "cbc_gpu_last_kernel_ms")
         return float(ms.value)
+
+    def last_kernel_variant(self):
+        return int(lib().cbc_gpu_last_kernel_variant(self._ctx))
 
     def synchronize(self):
         self._check(lib().cbc_gpu_synchronize(self._ctx), "cbc_gpu_synchronize")

@@ -231,6 +231,9 @@ uint32_t cbc_gpu_decode_lds_bytes(const cbc_lds_caps *caps);
 /* Timing of the most recent encode launch made through this context, measured with HIP events
  * recorded on the launch stream around the kernel (valid after the stream has been synchronised). */
 int  cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms);
+/* Which register budget of the encode kernel the most recent launch used: 5 or 6 wavefronts per SIMD
+ * (cbc_encode_blocks_kernel / cbc_encode_blocks_kernel_w6; chosen from blocks per CU), 0 before any launch. */
+int  cbc_gpu_last_kernel_variant(cbc_gpu_ctx *ctx);
 int  cbc_gpu_synchronize(cbc_gpu_ctx *ctx);
 
 #ifdef __cplusplus

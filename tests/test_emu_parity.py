@@ -310,3 +310,14 @@ def test_block_larger_than_the_contract_is_refused(built):
         pb.blocks[0]["n_reads"] = saved
     assert int(res[0]["status"]) == 7 and payloads[0] == b""
     assert payloads[1:] == ok_payloads[1:]
+
+
+def test_blocks_at_the_cap_limits(built):
+    """16 384-record blocks and blocks cut by the var-symbol cap (32 768): the largest the packer makes.  No
+    adaptive total reaches 2^20 inside them (the block contract); kernel body == the CPU port."""
+    for args in ((77, 3_000_000, 40_000, 150, 0.003, 0.02), (78, 400_000, 1_200, 150, 0.45, 0.3)):
+        p = host.synth(*args, block_reads=16384, max_cap_var=32768)
+        ep, eres = blockref.emu_encode(p)
+        cp, cres = oracle.cpu_encode_blocks(p, return_payloads=True)
+        assert (eres["status"] == 0).all() and ep == cp and (eres["n_symbols"] == cres["n_symbols"]).all()
+        p.close()

@@ -339,3 +339,114 @@ def test_reads_with_dozens_of_edits(enc, built):
     fa, sam, _, _ = synth.dataset(77, [60000], [600], 150, sub_rate=0.45, indel_frac=0.3)
     pb = host.pack_sam(sam, fa, block_reads=256)
     _check_blocks(enc, pb, sam)
+
+
+# ------------------------------------------------------------------ BASELINE.json configs at their full sizes
+def _decode_all(enc, pb, flat, offs, L):
+    """Decode every block of a packed batch from the compacted payloads; returns (recs, bases[n, L])."""
+    import ctypes
+    stride = (L + 3) // 4 * 4
+    nb = pb.n_blocks
+    blocks = np.zeros(nb, dtype=host.DEC_BLOCK_DTYPE)
+    rb = np.concatenate([[0], np.cumsum(pb.blocks["n_reads"].astype(np.uint64))])
+    blocks["in_off"] = offs[:-1]; blocks["in_bytes"] = (offs[1:] - offs[:-1]).astype(np.uint32)
+    blocks["ref_off"] = pb.blocks["ref_off"]; blocks["rec_base"] = rb[:-1]; blocks["seq_base"] = rb[:-1] * stride
+    blocks["n_reads"] = pb.blocks["n_reads"]; blocks["read_length"] = L; blocks["seq_stride"] = stride
+    nrec = int(rb[-1])
+    recs = np.zeros(nrec, dtype=host.REC_DTYPE)
+    seq = np.zeros(nrec * stride + 8, dtype=np.uint8)
+    dres = np.zeros(nb, dtype=host.RESULT_DTYPE)
+    caps = host.LdsCaps(pb.cap_pos, pb.cap_var)
+    pay = np.ascontiguousarray(flat)
+    rc = gpu.lib().cbc_gpu_decode_blocks(enc._ctx, pay.ctypes.data, pay.size, blocks.ctypes.data, nb, ctypes.byref(caps),
+                                         recs.ctypes.data, nrec, seq.ctypes.data, seq.size, dres.ctypes.data)
+    assert rc == 0 and (dres["status"] == 0).all(), dres[dres["status"] != 0][:4]
+    return recs, seq[:nrec * stride].reshape(nrec, stride)[:, :L], dres
+
+
+def test_cfg1_shape_every_block_vs_oracle(enc, built):
+    """BASELINE config 1's shape (15 072 434 bp contig, 100 k x 100 bp) on the HIP path: every one of the 25
+    blocks byte-equal to the oracle run on that block alone (SAM text path), and the GPU round trip."""
+    pb, sam, fa = host.synth(0xCBC00001, 15_072_434, 100_000, 100, want_text=True, block_reads=4096)
+    assert pb.n_blocks == 25
+    _check_blocks(enc, pb, sam)
+    assert enc.last_kernel_variant() == 5
+    _gpu_roundtrip(enc, pb, sam, fa)
+
+
+def test_cfg2_full_size_every_block_vs_cpu_port(enc, built):
+    """BASELINE config 2 in full (10 M x 150 bp vs a chr1-sized contig, 2442 blocks): every block's payload and
+    coder-step count == the oracle's packed-input CPU port run on that block alone; decode returns the packed
+    bases, POS and FLAG of all 10 M records."""
+    pb = host.synth(0xCBC00002, 248_956_422, 10_000_000, 150, block_reads=4096)
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)
+    assert (res["status"] == 0).all()
+    assert enc.last_kernel_variant() == 5                    # 2442 blocks <= 10 per CU: the 5-waves-per-SIMD build
+    cp, cres = oracle.cpu_encode_blocks(pb, return_payloads=True)
+    assert (cres["status"] == 0).all()
+    bad = [b for b in range(pb.n_blocks) if payloads[b] != cp[b]]
+    assert not bad, bad[:8]
+    assert (res["n_symbols"] == cres["n_symbols"]).all()
+    recs, bases, dres = _decode_all(enc, pb, flat, offs, 150)
+    assert (bases == pb.seq[:pb.n_recs * 150].reshape(pb.n_recs, 150)).all()
+    assert (recs["pos"] == pb.recs["pos"]).all() and (recs["flag"] == pb.recs["flag"]).all()
+    assert (dres["n_symbols"] == res["n_symbols"]).all()
+
+
+def test_cfg3_full_size_encode_decode_vs_cpu_port(enc, built):
+    """BASELINE config 3 (chr1-sized contig at 30x: 49 791 284 x 150 bp, 12 157 blocks -> the 6-waves-per-SIMD
+    build of the kernel): encode, decode, diff against the packed bases / POS / FLAG of every record, and every
+    8th block (plus the first and last 16) byte-equal to the CPU port run on the block alone."""
+    pb = host.synth(0xCBC00003, 248_956_422, 49_791_284, 150, block_reads=4096)
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)
+    assert (res["status"] == 0).all()
+    assert pb.n_blocks > 12000 and enc.last_kernel_variant() == 6
+    recs, bases, dres = _decode_all(enc, pb, flat, offs, 150)
+    assert (bases == pb.seq[:pb.n_recs * 150].reshape(pb.n_recs, 150)).all()
+    assert (recs["pos"] == pb.recs["pos"]).all() and (recs["flag"] == pb.recs["flag"]).all()
+    assert (dres["n_symbols"] == res["n_symbols"]).all()
+    which = sorted(set(range(0, pb.n_blocks, 8)) | set(range(16)) | set(range(pb.n_blocks - 16, pb.n_blocks)))
+    cp, cres = oracle.cpu_encode_blocks(pb, blocks=which, return_payloads=True)
+    bad = [b for i, b in enumerate(which) if payloads[b] != cp[i] or int(res[b]["n_symbols"]) != int(cres[i]["n_symbols"])]
+    assert len(which) > 1500 and not bad, bad[:8]
+
+
+def test_blocks_at_the_cap_limits(enc, built):
+    """The largest blocks the packer makes: 16 384 records, and ~65 edits per read so that the var-symbol cap
+    (32 768 per block) is what cuts them.  No adaptive total can reach the 2^20 rescale point inside such a block
+    (chars: 41 + 8 * 32768; snps: L + 10 * 16384; indels: L + 48 * 16384; flag: 65536 + 8 * 16384), which is the
+    block contract -- rescales are exercised by the whole-file stream tests.  GPU == CPU port, encode and decode."""
+    pb = host.synth(77, 3_000_000, 60_000, 150, 0.003, 0.02, block_reads=16384, max_cap_var=32768)
+    assert int(pb.blocks["n_reads"].max()) == 16384
+    pd = host.synth(78, 400_000, 4_000, 150, 0.45, 0.3, block_reads=16384, max_cap_var=32768)
+    assert pd.cap_var > 30000
+    for p in (pb, pd):
+        enc.upload_reference(p.ref)
+        payloads, res, offs, flat = enc.encode_blocks(p)
+        assert (res["status"] == 0).all()
+        cp, cres = oracle.cpu_encode_blocks(p, return_payloads=True)
+        assert payloads == cp and (res["n_symbols"] == cres["n_symbols"]).all()
+        recs, bases, dres = _decode_all(enc, p, flat, offs, 150)
+        assert (bases == p.seq[:p.n_recs * 150].reshape(p.n_recs, 150)).all()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launched_bare_with_two_ranks(built, scaling):
+    """`python bench.py --gpus 2` exactly as the driver starts it (no torch.distributed.run): the parent spawns
+    its own ranks.  Two ranks share the one GPU of this box, so the collectives go over gloo; strong scaling
+    checks the gathered container against the single-GPU container inside the run."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "300000",
+                        "--contig-len", "8000000", "--steps", "2", "--warmup", "1", "--scaling", scaling, "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["value"] > 0
+    if scaling == "strong":
+        assert j["config"]["gathered_equals_single_gpu"] is True
