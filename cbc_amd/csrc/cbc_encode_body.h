@@ -103,7 +103,35 @@ struct cbc_enc_args {
 #define CBC_TSM(k) do {} while (0)
 #endif
 
-template <class W>
+/* bytes readable from offset `off` of a buffer with `total` bytes, clamped to 32 bits */
+/* a <= b for 64-bit values using 32-bit compares only: gfx950's scalar ALU has no ordered 64-bit
+ * compare, and one VALU compare on a uniform value drags everything downstream onto the VALU */
+CBC_FN bool cbc_le64(uint64_t a, uint64_t b)
+{
+    uint32_t ah = (uint32_t)(a >> 32), al = (uint32_t)a, bh = (uint32_t)(b >> 32), bl = (uint32_t)b;
+    return (ah < bh) | ((ah == bh) & (al <= bl));
+}
+/* [off, off + len) lies inside a buffer of `total` bytes; written without the sum off + len, which a
+ * crafted descriptor could make wrap */
+CBC_FN bool cbc_fits64(uint64_t off, uint64_t len, uint64_t total)
+{
+    return cbc_le64(off, total) && cbc_le64(len, total - off);
+}
+CBC_FN uint32_t cbc_avail32(uint64_t total, uint32_t off)
+{
+    uint64_t a = total - off;                       /* callers guarantee off <= total or get 0 below */
+    if (!cbc_le64((uint64_t)off, total)) return 0u;
+    return (uint32_t)(a >> 32) ? 0xffffffffu : (uint32_t)a;
+}
+CBC_FN uint32_t cbc_basepair(uint32_t c)            /* char2basepair sam_models.c:11-21 */
+{
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+/* GEN = false: the block kernels (LDS-resident sparse tables, counting-model closed forms for the per-record
+ * models).  GEN = true: the whole-file stream kernel of cbc_stream_body.h -- the same coder, bit packer and edit
+ * walk, with the general (rescaling) form of every model and the var table dense in global memory. */
+template <class W, bool GEN = false>
 struct CbcEnc {
     typedef typename W::V32 V32;
     typedef typename W::Mask Mask;
@@ -131,7 +159,8 @@ struct CbcEnc {
     V32 hkey, hexc; uint32_t hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;   /* codebook ctx 0..3: sparse, 8 lanes each */
     uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_occ, *pos_pre, *var_ev, *bloom;
     uint32_t snps_n, indels_n;
-    uint32_t rn_count;
+    uint32_t rn_count, rn_cap;               /* contig-name pairs in use / capacity (CBC_CAP_NAME in the block kernels) */
+    uint32_t *vtab;                          /* GEN: var excess table in global memory, row = context, L0 words per row */
     uint32_t pos_card, cap_pos;              /* pos alphabet: value / occurrences / prefix by index, in LDS */
     uint32_t nev, nev1, cap_var;             /* var events of strand 0 (from the bottom of the area) / strand 1 (from the top) */
     uint32_t vtag0, vtag1, vsum0, vsum1;     /* hot var contexts: tag (context) and total excess  */
@@ -566,7 +595,7 @@ struct CbcEnc {
         encode(lo, cnt, n);
         if (found != CBC_NOMEMO) W::write_uni(rname_exc, found, cnt - 1u + 10u);
         else {
-            if (rn_count >= CBC_CAP_NAME) { fail(CBC_ST_CAP_NAME); return; }
+            if (rn_count >= rn_cap) { fail(CBC_ST_CAP_NAME); return; }
             W::write_uni(rname_key, rn_count, key);
             W::write_uni(rname_exc, rn_count, 10u);
             rn_count++;
@@ -786,9 +815,41 @@ struct CbcEnc {
      * Most contexts are seen once per block, so an 8192-bit Bloom filter on the context answers
      * "never seen" (n = L0, cum = sym) without touching the list; only on a filter hit is the list
      * scanned, 512 events per trip (eight coalesced loads in flight). ---- */
+    /* GEN: the reference's dense table (sam_models.c:311-348), kept as e = count - 1 in global memory (65535 rows
+     * of L0 words, zero = untouched).  One round trip per symbol: the row's L0 <= 256 words are fetched as four
+     * chunks of one word per lane, all in flight together; the same wavefront wrote them, through the L1-bypassing
+     * list accessors, and waits for its own stores first. */
+    CBC_MFN void var_code_dense(uint32_t ctx, uint32_t sym)
+    {
+        V32 ln = W::lane();
+        uint32_t *row = vtab + (uint64_t)ctx * L0;
+        W::list_fence();
+        V32 ev[4];
+        for (uint32_t q = 0; q < 4u; q++) { V32 i = ln + 64u * q; ev[q] = W::load32_list(row, i, i < L0, 0u); }
+        V32 alo = W::splat(0u), aall = W::splat(0u);
+        uint32_t esym = 0;
+        for (uint32_t q = 0; q < 4u; q++) {
+            V32 i = ln + 64u * q;
+            alo = alo + W::select(i < sym, ev[q], W::splat(0u));
+            aall = aall + ev[q];
+            if ((sym >> 6) == q) esym = W::readlane(ev[q], sym & 63u);
+        }
+        const uint32_t lo = sym + W::reduce_add(alo), n = L0 + W::reduce_add(aall);
+        encode(lo, 1u + esym, n);
+        W::append_list(row, sym, esym + 10u);
+        if (n + 10u >= CBC_RESCALE) {                       /* update_model stream_model.c:41-48 on e = count - 1 */
+            W::list_fence();
+            for (uint32_t q = 0; q < 4u; q++) {
+                V32 i = ln + 64u * q;
+                V32 e = W::load32_list(row, i, i < L0, 0u);
+                W::store32_list(row, i, (e + 1u) >> 1, i < L0);
+            }
+        }
+    }
     CBC_MFN void var_code(uint32_t ctx, uint32_t sym)
     {
         if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
+        if (GEN) { var_code_dense(ctx, sym); return; }
         /* Hot contexts.  The first SNP of a read with no known SNP ahead always has the same context
          * (delta = L+2, prev = 0) per strand, so a block codes hundreds of symbols in it.  The first
          * context seen on each strand claims a dense 256-entry excess table in LDS (exactly the
@@ -892,168 +953,14 @@ struct CbcEnc {
         w2 |= (kw == 2u) ? bit : 0ull;
         w3 |= (kw == 3u) ? bit : 0ull;
     }
-};
 
-/* bytes readable from offset `off` of a buffer with `total` bytes, clamped to 32 bits */
-/* a <= b for 64-bit values using 32-bit compares only: gfx950's scalar ALU has no ordered 64-bit
- * compare, and one VALU compare on a uniform value drags everything downstream onto the VALU */
-CBC_FN bool cbc_le64(uint64_t a, uint64_t b)
-{
-    uint32_t ah = (uint32_t)(a >> 32), al = (uint32_t)a, bh = (uint32_t)(b >> 32), bl = (uint32_t)b;
-    return (ah < bh) | ((ah == bh) & (al <= bl));
-}
-/* [off, off + len) lies inside a buffer of `total` bytes; written without the sum off + len, which a
- * crafted descriptor could make wrap */
-CBC_FN bool cbc_fits64(uint64_t off, uint64_t len, uint64_t total)
-{
-    return cbc_le64(off, total) && cbc_le64(len, total - off);
-}
-CBC_FN uint32_t cbc_avail32(uint64_t total, uint32_t off)
-{
-    uint64_t a = total - off;                       /* callers guarantee off <= total or get 0 below */
-    if (!cbc_le64((uint64_t)off, total)) return 0u;
-    return (uint32_t)(a >> 32) ? 0xffffffffu : (uint32_t)a;
-}
-CBC_FN uint32_t cbc_basepair(uint32_t c)            /* char2basepair sam_models.c:11-21 */
-{
-    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
-}
-
-/* ===========================================================================================
- * cbc_encode_stream: code block `blk` completely.  `lds` = this wavefront's table memory
- * (cbc_gpu_lds_bytes() bytes).
- * =========================================================================================== */
-template <class W, uint32_t ROLE>
-CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds)
-{
-    const uint32_t role = ROLE;
-    typedef typename W::V32 V32;
-    typedef typename W::Mask Mask;
-    const V32 ln = W::lane();
-    const cbc_block_desc *bd = A.blocks + blk;
-    CbcEnc<W> E;
-
-    /* ---- block descriptor (uniform) ---- */
-    const uint64_t rec_base = bd->rec_base, seq_base = bd->seq_base, tok_base = bd->tok_base;
-    const uint64_t ref_off = bd->ref_off, out_off = bd->out_off;
-    const uint32_t out_cap = bd->out_cap, n_reads = bd->n_reads, name_off = bd->name_off;
-    const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
-
-    E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
-    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
-    E.ring = lds + CBC_LDS_RING;
-    E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
-    E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);
-    E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
-    E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
-    E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH; E.ctl = lds + CBC_LDS_CTL;
-    if (ROLE != CBC_ROLE_FUSED) {                            /* the only barrier: the counters start at zero for both waves */
-        if (ROLE == CBC_ROLE_MODEL) { W::write_uni(E.ctl, 0u, 0u); W::write_uni(E.ctl, 1u, 0u); }
-        W::barrier();
-    }
-    /* the block's out area: [0, payload_cap) payload, [payload_cap, out_cap) its var-event list */
-    const uint32_t payload_cap = bd->reserved;
-    E.out32 = (uint32_t *)(A.out + out_off);
-    E.cap_words = payload_cap >> 2;
-    E.var_ev = (uint32_t *)(A.out + out_off + payload_cap);
-    E.cap_var = payload_cap <= out_cap ? (out_cap - payload_cap) >> 2 : 0u;
-    bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0) && ((payload_cap & 3u) == 0) &&
-                   (payload_cap <= out_cap) &&
-                   cbc_fits64(rec_base, n_reads, A.n_recs) && cbc_fits64(tok_base, n_tok_blk, A.n_tok) &&
-                   (L0 >= 1u && L0 <= 256u) && (name_off < A.names_bytes);
-    if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
-    /* the closed forms of fixed_group() hold while no per-record model can reach its rescale point */
-    if (n_reads > CBC_MAX_BLOCK_READS) E.fail(CBC_ST_UNSUPPORTED);
-
-    /* ---- model tables.  LDS words [0, 256) rlength, the output ring and the pos arrays belong to the
-     * wavefront that codes the fixed symbols (coder / fused); snps, indels, the name list, the Bloom
-     * filter and the hot var slots to the one that produces the segments (model / fused).
-     * (alloc_read_models_t sam_models.c:562-586 etc.) ---- */
-    E.L0 = L0;
-    E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
-    E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
-    E.bloom = lds + CBC_LDS_BLOOM;
-    E.pos_val = lds + CBC_LDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = E.pos_occ + A.cap_pos;
-    E.cap_pos = A.cap_pos;
-    if (ROLE != CBC_ROLE_MODEL) {
-        for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
-        for (uint32_t b = 0; b < 256u; b += 64u) W::store32(E.rlen_exc, ln + b, W::splat(0u), W::all());
-        W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 0u); W::write_uni(E.pos_pre, 0u, 0u);
-    }
-    if (ROLE != CBC_ROLE_CODER) {
-        for (uint32_t b = 0; b < 512u; b += 64u) W::store32(E.snps_exc, ln + b, W::splat(0u), W::all());   /* snps + indels */
-        for (uint32_t b = 0; b < CBC_BLOOM_WORDS + 512u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* Bloom + 2 slots */
-    }
-    E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
-    E.snps_n = L0; E.indels_n = L0;
-    E.rn_count = 0;
-    E.pos_card = 1u;                                         /* initialize_stream_model_pos :132-162: the escape */
-    E.nev = 0; E.nev1 = 0;
-    E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
-    E.hkey = W::splat(0u); E.hexc = W::splat(0u);
-    E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
-    {   /* lane table: match 1,1 (n=2); same_ref 1,1; chars rows (sam_models.c:372-401) */
-        V32 sm = W::splat(0u);
-        sm = W::select(ln < 10u, W::splat(1u), sm);
-        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
-        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
-        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
-        /* +8 on two entries per row: A:{C,G} C:{A,T} G:{A,T} T:{C,G} */
-        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
-                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
-        cv = W::select(bump, cv + 8u, cv);
-        sm = W::select(inch, cv, sm);
-        E.small = sm;
-    }
-    E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0;
-    E.win_clear();
-
-    const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
-    const uint8_t *seqb = A.seq + seq_base;
-    const uint32_t *tokb = A.tok + tok_base;
-    const uint8_t *refb = A.ref + ref_off;
-    const uint64_t seq_avail = cbc_le64(seq_base, A.seq_bytes) ? A.seq_bytes - seq_base : 0;
-    const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
-    const uint32_t seq_lim = cbc_avail32(seq_avail, 0u), ref_lim = cbc_avail32(ref_avail, 0u);
-#ifdef CBC_STAMP
-    for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
-    CBC_T0();
-#endif
-
-    /* ================================ segment generators ==================================== */
-    /* stream header: int(L0), 32 x int(WELL), int(LOSSLESS=8)  (sam_file_allocation.c:371, 392-403;
-     * compression.c:139; compress_int qv_codebook.c:14-50) */
-    auto gen_header = [&]() {
-        for (uint32_t k = 0; k < 34u && E.status == CBC_ST_OK; k++) {
-            uint32_t v = (k == 0u) ? L0 : (k == 33u) ? 8u : CBC_WELL_SEED;
-            E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
-            E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
-            E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
-            E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
-            if ((k & 7u) == 7u) E.drain();
-        }
-    };
-    /* the contig name of record 0, compress_rname (id_compression.c:39-65); a block holds one contig */
-    auto gen_rname = [&]() {
-        for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
-            uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
-            E.rname_code(E.prevChar, ch);
-            if ((q & 31u) == 31u) E.drain();                  /* long contig names: keep the queue short */
-            if (ch == 0u) break;
-            E.prevChar = ch;
-        }
-    };
-    /* end-of-stream sentinel compress_rname("\n") (compression.c:152), after its same_ref symbol */
-    auto gen_sentinel = [&]() {
-        if (E.q_len >= 56u) E.drain();
-        E.cur_read = n_reads;
-        E.rname_code(E.prevChar, (uint32_t)'\n');
-        E.rname_code((uint32_t)'\n', 0u);
-    };
     /* compress_edits for an imperfect read (read_compression.c:308-600).
      * The packer has already counted the edits (token word 1) and checked that the MD string is
      * consistent with the read, so every MD token becomes exactly one SNP: numSnps = n_md. */
-    auto gen_edits = [&](uint32_t pos, uint32_t flw, uint32_t tok_off, const V32 &seqv, const V32 &tokv) {
+    CBC_MFN void edits(uint32_t pos, uint32_t flw, uint32_t tok_off, const V32 &seqv, const V32 &tokv,
+                       const uint32_t *tokb, uint32_t n_tok_blk)
+    {
+            CbcEnc &E = *this;
             const uint32_t rl = flw >> 16, strand = (flw >> 4) & 1u;
             {   /* snpInRef window: slide it to this record's POS (chr_change clears it, compression.c:62-63;
                  * it is empty at the start of the block, so the first slide may be anything) */
@@ -1156,6 +1063,139 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
 #undef CBC_SNP
 #undef CBC_TOK
 #undef CBC_READ_BYTE
+    }
+};
+
+/* ===========================================================================================
+ * cbc_encode_stream: code block `blk` completely.  `lds` = this wavefront's table memory
+ * (cbc_gpu_lds_bytes() bytes).
+ * =========================================================================================== */
+template <class W, uint32_t ROLE>
+CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds)
+{
+    const uint32_t role = ROLE;
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+    const V32 ln = W::lane();
+    const cbc_block_desc *bd = A.blocks + blk;
+    CbcEnc<W> E;
+
+    /* ---- block descriptor (uniform) ---- */
+    const uint64_t rec_base = bd->rec_base, seq_base = bd->seq_base, tok_base = bd->tok_base;
+    const uint64_t ref_off = bd->ref_off, out_off = bd->out_off;
+    const uint32_t out_cap = bd->out_cap, n_reads = bd->n_reads, name_off = bd->name_off;
+    const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
+
+    E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
+    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
+    E.ring = lds + CBC_LDS_RING;
+    E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
+    E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);
+    E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
+    E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
+    E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH; E.ctl = lds + CBC_LDS_CTL;
+    if (ROLE != CBC_ROLE_FUSED) {                            /* the only barrier: the counters start at zero for both waves */
+        if (ROLE == CBC_ROLE_MODEL) { W::write_uni(E.ctl, 0u, 0u); W::write_uni(E.ctl, 1u, 0u); }
+        W::barrier();
+    }
+    /* the block's out area: [0, payload_cap) payload, [payload_cap, out_cap) its var-event list */
+    const uint32_t payload_cap = bd->reserved;
+    E.out32 = (uint32_t *)(A.out + out_off);
+    E.cap_words = payload_cap >> 2;
+    E.var_ev = (uint32_t *)(A.out + out_off + payload_cap);
+    E.cap_var = payload_cap <= out_cap ? (out_cap - payload_cap) >> 2 : 0u;
+    bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0) && ((payload_cap & 3u) == 0) &&
+                   (payload_cap <= out_cap) &&
+                   cbc_fits64(rec_base, n_reads, A.n_recs) && cbc_fits64(tok_base, n_tok_blk, A.n_tok) &&
+                   (L0 >= 1u && L0 <= 256u) && (name_off < A.names_bytes);
+    if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
+    /* the closed forms of fixed_group() hold while no per-record model can reach its rescale point */
+    if (n_reads > CBC_MAX_BLOCK_READS) E.fail(CBC_ST_UNSUPPORTED);
+
+    /* ---- model tables.  LDS words [0, 256) rlength, the output ring and the pos arrays belong to the
+     * wavefront that codes the fixed symbols (coder / fused); snps, indels, the name list, the Bloom
+     * filter and the hot var slots to the one that produces the segments (model / fused).
+     * (alloc_read_models_t sam_models.c:562-586 etc.) ---- */
+    E.L0 = L0;
+    E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
+    E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
+    E.bloom = lds + CBC_LDS_BLOOM;
+    E.pos_val = lds + CBC_LDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = E.pos_occ + A.cap_pos;
+    E.cap_pos = A.cap_pos;
+    if (ROLE != CBC_ROLE_MODEL) {
+        for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
+        for (uint32_t b = 0; b < 256u; b += 64u) W::store32(E.rlen_exc, ln + b, W::splat(0u), W::all());
+        W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 0u); W::write_uni(E.pos_pre, 0u, 0u);
+    }
+    if (ROLE != CBC_ROLE_CODER) {
+        for (uint32_t b = 0; b < 512u; b += 64u) W::store32(E.snps_exc, ln + b, W::splat(0u), W::all());   /* snps + indels */
+        for (uint32_t b = 0; b < CBC_BLOOM_WORDS + 512u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* Bloom + 2 slots */
+    }
+    E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
+    E.snps_n = L0; E.indels_n = L0;
+    E.rn_count = 0; E.rn_cap = CBC_CAP_NAME; E.vtab = nullptr;
+    E.pos_card = 1u;                                         /* initialize_stream_model_pos :132-162: the escape */
+    E.nev = 0; E.nev1 = 0;
+    E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
+    E.hkey = W::splat(0u); E.hexc = W::splat(0u);
+    E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
+    {   /* lane table: match 1,1 (n=2); same_ref 1,1; chars rows (sam_models.c:372-401) */
+        V32 sm = W::splat(0u);
+        sm = W::select(ln < 10u, W::splat(1u), sm);
+        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
+        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
+        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
+        /* +8 on two entries per row: A:{C,G} C:{A,T} G:{A,T} T:{C,G} */
+        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
+                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
+        cv = W::select(bump, cv + 8u, cv);
+        sm = W::select(inch, cv, sm);
+        E.small = sm;
+    }
+    E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0;
+    E.win_clear();
+
+    const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
+    const uint8_t *seqb = A.seq + seq_base;
+    const uint32_t *tokb = A.tok + tok_base;
+    const uint8_t *refb = A.ref + ref_off;
+    const uint64_t seq_avail = cbc_le64(seq_base, A.seq_bytes) ? A.seq_bytes - seq_base : 0;
+    const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
+    const uint32_t seq_lim = cbc_avail32(seq_avail, 0u), ref_lim = cbc_avail32(ref_avail, 0u);
+#ifdef CBC_STAMP
+    for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
+    CBC_T0();
+#endif
+
+    /* ================================ segment generators ==================================== */
+    /* stream header: int(L0), 32 x int(WELL), int(LOSSLESS=8)  (sam_file_allocation.c:371, 392-403;
+     * compression.c:139; compress_int qv_codebook.c:14-50) */
+    auto gen_header = [&]() {
+        for (uint32_t k = 0; k < 34u && E.status == CBC_ST_OK; k++) {
+            uint32_t v = (k == 0u) ? L0 : (k == 33u) ? 8u : CBC_WELL_SEED;
+            E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
+            E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
+            E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
+            E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
+            if ((k & 7u) == 7u) E.drain();
+        }
+    };
+    /* the contig name of record 0, compress_rname (id_compression.c:39-65); a block holds one contig */
+    auto gen_rname = [&]() {
+        for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
+            uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
+            E.rname_code(E.prevChar, ch);
+            if ((q & 31u) == 31u) E.drain();                  /* long contig names: keep the queue short */
+            if (ch == 0u) break;
+            E.prevChar = ch;
+        }
+    };
+    /* end-of-stream sentinel compress_rname("\n") (compression.c:152), after its same_ref symbol */
+    auto gen_sentinel = [&]() {
+        if (E.q_len >= 56u) E.drain();
+        E.cur_read = n_reads;
+        E.rname_code(E.prevChar, (uint32_t)'\n');
+        E.rname_code((uint32_t)'\n', 0u);
     };
     /* match test of a group's records (read_compression.c:291-296): lane l compares bases 4l..4l+3;
      * the loads of 8 records are in flight together */
@@ -1229,7 +1269,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                     nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
                     nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
                 }
-                gen_edits(W::readlane(r_pos, j), W::readlane(r_fl, j), W::readlane(r_tok, j), seqv, tokv);
+                E.edits(W::readlane(r_pos, j), W::readlane(r_fl, j), W::readlane(r_tok, j), seqv, tokv, tokb, n_tok_blk);
                 E.seg_end();
                 CBC_TS(1);                                    /* edits of one record */
                 if (E.q_len >= CBC_BATCH_MIN) E.drain();      /* hand over once a few records' symbols are pending */
@@ -1314,7 +1354,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                     const V32 bo = ln * 4u;
                     const V32 seqv = W::load32_bytes(seqb + so, bo, bo < (flw >> 16));
                     const V32 tokv = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
-                    gen_edits(W::readlane(r_pos, j), flw, to, seqv, tokv);
+                    E.edits(W::readlane(r_pos, j), flw, to, seqv, tokv, tokb, n_tok_blk);
                     E.seg_end();
                 } else E.seg_consume();
             }

@@ -1,0 +1,293 @@
+/*
+ * cbc_stream_body.h -- the WHOLE-FILE stream: the reference's own output format ("compat" mode).
+ *
+ *   compress()    src/compression.c:112-170   one arithmetic stream per file; the models are never reset, not
+ *                                             even at a contig change (:58-64 resets only cumsumP / snpInRef,
+ *                                             compress_pos :123-124 resets prevPos)
+ *   decompress()  src/compression.c:173-216
+ *
+ * The block kernels (cbc_encode_body.h / cbc_decode_body.h) cut the record stream into independent blocks and
+ * use, inside a block, what holds while no adaptive total can reach the 2^20 rescale point: counting-model
+ * closed forms, LDS-sized sparse tables.  None of that holds for a file of millions of records, so this body
+ * codes ONE stream with ONE wavefront and the GENERAL form of every model (stream_model.c:31-51: add the step,
+ * and once the total reaches 2^20 halve every count and add one):
+ *   - same_ref, match, chars: literal counts in a lane table (CbcEnc::small_code / CbcDec::small_dec)
+ *   - rlength[0], snps, indels: dense excess tables in LDS with their rescale sweep (dense_code / dense_dec);
+ *     rlength[1..3] only ever see symbol 0 (quirk Q1): two scalars (count of 0, total) with the same rescale
+ *   - pos: the alphabet in order of appearance with LITERAL counts in LDS (cap_pos entries), linear lookup;
+ *     pos_alpha's four byte models are derived from the registered values (valid while 256 + 10 * cap_pos < 2^20)
+ *   - flag, codebook: value/excess pairs in registers (<= CBC_CAP_FLAG distinct FLAG values per file)
+ *   - rname: (context, char) pairs in LDS (cap_name of them)
+ *   - var: the reference's dense 65535 x L0 table as excess words in GLOBAL memory (39 MB at L0 = 150), one
+ *     round trip per var symbol
+ * The record stream arrives as SEGMENTS (cbc_block_desc): consecutive records of one contig with their POS as in
+ * the SAM (not rebased); a segment whose name_off differs from its predecessor's starts a new contig: same_ref 1,
+ * the name, prevPos = 0, an empty snpInRef window, the next reference.  Speed is secondary here (the serial
+ * chain of one stream on one wavefront); the output is byte-identical to the reference encoder's file, which
+ * the reference's own `-x` reads.
+ *
+ * The same body also runs one stream PER segment (cbc_stream_args.per_segment): the rescale-capable fallback
+ * for block descriptors the block kernels refuse (more than CBC_MAX_BLOCK_READS records).
+ */
+#ifndef CBC_STREAM_BODY_H
+#define CBC_STREAM_BODY_H
+
+#include "cbc_encode_body.h"
+#include "cbc_decode_body.h"
+
+/* LDS words of the stream kernels; then rname key/excess (cap_name each), pos value/count (cap_pos each) */
+#define CBC_SLDS_RLEN    0u        /* 256: rlength[0] excess  */
+#define CBC_SLDS_SNPS    256u
+#define CBC_SLDS_INDELS  512u
+#define CBC_SLDS_RING    768u      /* CBC_RING_WORDS: output bit ring (encode) / scratch read + lists (decode) */
+#define CBC_SLDS_DEC_TMP  768u     /* decode: 80 words insertion-free read, 256 deletions, 256 insertions, 512 pos_alpha histograms */
+#define CBC_SLDS_DEC_DELS (768u + 80u)
+#define CBC_SLDS_DEC_INS  (768u + 336u)
+#define CBC_SLDS_DEC_HIST (768u + 592u)
+#define CBC_SLDS_FIXED   (768u + 1104u)
+
+struct cbc_stream_caps { uint32_t cap_pos, cap_name; };
+static inline uint32_t cbc_stream_lds_bytes(const cbc_stream_caps *c) { return 4u * (CBC_SLDS_FIXED + 2u * c->cap_name + 2u * c->cap_pos); }
+
+struct cbc_stream_args {
+    const cbc_read_rec   *recs;
+    const uint8_t        *seq;
+    const uint32_t       *tok;
+    const uint8_t        *names;
+    const cbc_block_desc *segs;
+    const uint8_t        *ref;
+    uint8_t              *out;
+    cbc_block_result     *results;      /* one per stream */
+    uint32_t             *vtab;         /* n_vtab tables of 65535 * 256 words, zero-filled by the caller */
+    uint64_t ref_bytes, out_bytes, seq_bytes, n_tok, n_recs;
+    uint32_t n_segs, cap_pos, cap_name, names_bytes, per_segment, n_vtab;
+};
+#define CBC_VTAB_WORDS (65535ull * 256ull)
+
+template <class W>
+CBC_FN void cbc_encode_whole(const cbc_stream_args &A, uint32_t stream, uint32_t slot, uint32_t *lds)
+{
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+    typedef CbcEnc<W, true> Enc;
+    const V32 ln = W::lane();
+    Enc E;
+    const uint32_t seg0 = A.per_segment ? stream : 0u, seg1 = A.per_segment ? stream + 1u : A.n_segs;
+    const cbc_block_desc *first = A.segs + seg0;
+    const uint64_t out_off = first->out_off;
+    const uint32_t out_cap = first->out_cap, L0 = first->read_length;
+
+    E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
+    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
+    E.ring = lds + CBC_SLDS_RING;
+    E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
+    E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
+    E.role = CBC_ROLE_FUSED; E.batch_i = 0; E.batch = nullptr; E.ctl = nullptr;
+    E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
+    E.out32 = (uint32_t *)(A.out + out_off);
+    E.cap_words = out_cap >> 2;
+    bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0u) && (L0 >= 1u && L0 <= 256u) &&
+                   (slot < A.n_vtab) && (A.cap_pos >= 2u) && (A.cap_name >= 4u) && (seg0 < A.n_segs);
+    if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
+
+    /* ---- model tables ---- */
+    E.L0 = L0;
+    E.rlen_exc = lds + CBC_SLDS_RLEN; E.snps_exc = lds + CBC_SLDS_SNPS; E.indels_exc = lds + CBC_SLDS_INDELS;
+    E.rname_key = lds + CBC_SLDS_FIXED; E.rname_exc = E.rname_key + A.cap_name; E.rn_cap = A.cap_name; E.rn_count = 0;
+    E.pos_val = E.rname_exc + A.cap_name; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = nullptr; E.cap_pos = A.cap_pos;
+    E.bloom = nullptr; E.var_ev = nullptr; E.nev = E.nev1 = 0; E.cap_var = 0;
+    E.vtab = A.vtab + (uint64_t)slot * CBC_VTAB_WORDS;
+    for (uint32_t b = 0; b < CBC_SLDS_RING + CBC_RING_WORDS; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
+    W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);      /* the escape: counts[0] = 1 (sam_models.c:132-162) */
+    E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
+    E.snps_n = L0; E.indels_n = L0;
+    E.pos_card = 1u;
+    E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
+    E.hkey = W::splat(0u); E.hexc = W::splat(0u);
+    E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
+    {   /* lane table: match 1,1; same_ref 1,1; chars rows (sam_models.c:372-401) -- as in cbc_encode_stream */
+        V32 sm = W::select(ln < 10u, W::splat(1u), W::splat(0u));
+        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
+        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
+        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
+        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
+                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
+        cv = W::select(bump, cv + 8u, cv);
+        E.small = W::select(inch, cv, sm);
+    }
+    E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0;
+    E.win_clear();
+    uint32_t rlen_n = 255u, rl123_c0 = 1u, rl123_n = 255u, flag_n = 65536u, pos_n = 1u;
+
+    /* stream header: int(L0), 32 x int(WELL), int(LOSSLESS) */
+    for (uint32_t k = 0; k < 34u && E.status == CBC_ST_OK; k++) {
+        uint32_t v = (k == 0u) ? L0 : (k == 33u) ? 8u : CBC_WELL_SEED;
+        E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
+        if ((k & 7u) == 7u) E.drain_q();
+    }
+    E.drain_q();
+
+    /* pos model, general form (compress_pos read_compression.c:113-159): literal counts, step 10 */
+    auto pos_update = [&](uint32_t idx) {
+        W::write_uni(E.pos_occ, idx, W::read_uni(E.pos_occ, idx) + 10u);
+        pos_n += 10u;
+        if (pos_n >= CBC_RESCALE) {
+            V32 a = W::splat(0u);
+            const uint32_t cb = W::uni(E.pos_card);
+            for (uint32_t b = 0; b < cb; b += 64u) {
+                V32 i = ln + b; Mask m = i < E.pos_card;
+                V32 c = (W::load32(E.pos_occ, i, m, 0u) >> 1) + 1u;
+                W::store32(E.pos_occ, i, c, m);
+                a = a + W::select(m, c, W::splat(0u));
+            }
+            pos_n = W::reduce_add(a);
+        }
+    };
+    auto pos_code = [&](uint32_t x) {
+        uint32_t idx = 0;
+        const uint32_t cb = W::uni(E.pos_card);
+        for (uint32_t b = 0; b < cb; b += 64u) {
+            V32 i = ln + b;
+            V32 v = W::load32(E.pos_val, i, (i != 0u) & (i < E.pos_card), 0xffffffffu);
+            uint64_t hit = W::ballot(v == x);
+            if (hit) { idx = b + W::ctz64(hit); break; }
+        }
+        if (idx) {
+            V32 a = W::splat(0u);
+            const uint32_t ib = W::uni(idx);
+            for (uint32_t b = 0; b < ib; b += 64u) { V32 i = ln + b; a = a + W::load32(E.pos_occ, i, i < idx, 0u); }
+            E.encode(W::reduce_add(a), W::read_uni(E.pos_occ, idx), pos_n);
+            pos_update(idx);
+            return;
+        }
+        if (E.pos_card >= E.cap_pos) { E.fail(CBC_ST_CAP_POS); return; }
+        E.encode(0u, W::read_uni(E.pos_occ, 0u), pos_n);
+        pos_update(0u);
+        E.pos_alpha(x, E.pos_card);                            /* the four byte models, derived from the registered values */
+        W::write_uni(E.pos_val, E.pos_card, x); W::write_uni(E.pos_occ, E.pos_card, 0u);
+        E.pos_card++;
+        pos_update(E.pos_card - 1u);                           /* update_model(P, alphabetCard++) without a send (:153) */
+    };
+
+    uint32_t prev_name = 0xffffffffu;
+    uint64_t rec_index = 0;
+    for (uint32_t sg = seg0; sg < seg1 && E.status == CBC_ST_OK; sg++) {
+        const cbc_block_desc *bd = A.segs + sg;
+        const uint64_t rec_base = bd->rec_base, seq_base = bd->seq_base, tok_base = bd->tok_base, ref_off = bd->ref_off;
+        const uint32_t n_reads = bd->n_reads, name_off = bd->name_off, n_tok_blk = bd->n_tok;
+        if (!(cbc_fits64(rec_base, n_reads, A.n_recs) && cbc_fits64(tok_base, n_tok_blk, A.n_tok) && name_off < A.names_bytes &&
+              bd->read_length == L0)) { E.fail(CBC_ST_ASSERT); break; }
+        const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
+        const uint8_t *seqb = A.seq + seq_base;
+        const uint32_t *tokb = A.tok + tok_base;
+        const uint8_t *refb = A.ref + ref_off;
+        const uint64_t seq_avail = cbc_le64(seq_base, A.seq_bytes) ? A.seq_bytes - seq_base : 0;
+        const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
+        const uint32_t seq_lim = cbc_avail32(seq_avail, 0u), ref_lim = cbc_avail32(ref_avail, 0u);
+        const bool new_contig = name_off != prev_name;
+        prev_name = name_off;
+
+        for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
+            V32 r_pos, r_fl, r_seq, r_tok;
+            const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
+            E.cur_read = (uint32_t)rec_index;
+            W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
+            {   /* validated one lane each so that the per-record loads need no clamping */
+                V32 vrl = r_fl >> 16;
+                Mask live = (ln + c0) < n_reads;
+                Mask bad = live & ((vrl == 0u) | (vrl > CBC_MAX_READ_LEN) | (r_pos == 0u) | (r_seq > seq_lim) | ((seq_lim - r_seq) < (vrl + 4u)) |
+                                   (r_pos > ref_lim) | ((ref_lim - r_pos) < (vrl + 3u)) | (r_tok >= n_tok_blk));
+                uint64_t bb = W::ballot(bad);
+                if (bb) { E.cur_read = (uint32_t)rec_index + W::ctz64(bb); E.fail(CBC_ST_ASSERT); break; }
+            }
+            /* match test of the group (read_compression.c:291-296): lane l compares bases 4l..4l+3, 8 records in flight */
+            uint64_t neq = 0;
+            for (uint32_t j0 = 0; j0 < cn; j0 += 8u) {
+                V32 sv[8], rv[8]; uint32_t rls[8];
+                const V32 bo = ln * 4u;
+                for (uint32_t q = 0; q < 8u; q++) {
+                    const uint32_t jj = (j0 + q) & 63u;
+                    const uint32_t pos = W::readlane(r_pos, jj), so = W::readlane(r_seq, jj);
+                    rls[q] = (j0 + q < cn) ? W::readlane(r_fl, jj) >> 16 : 0u;
+                    sv[q] = W::load32_bytes(seqb + so, bo, bo < rls[q]);
+                    rv[q] = W::load32_bytes(refb + (pos - 1u), bo, bo < rls[q]);
+                }
+                for (uint32_t q = 0; q < 8u; q++) {
+                    const uint32_t rl = rls[q];
+                    V32 bmask = W::select(bo + 4u <= rl, W::splat(0xffffffffu),
+                                          W::select(bo < rl, (W::splat(1u) << ((W::splat(rl) - bo) * 8u)) - 1u, W::splat(0u)));
+                    if (W::ballot(((sv[q] ^ rv[q]) & bmask) != 0u)) neq |= 1ull << ((j0 + q) & 63u);
+                }
+            }
+            for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
+                const uint32_t r = c0 + j;
+                E.cur_read = (uint32_t)(rec_index + j);
+                if (E.q_len >= 32u) E.drain_q();
+                /* -- compress_rname (id_compression.c:39-65) -- */
+                const bool chr_change = new_contig && r == 0u;
+                if (chr_change) {
+                    E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+                    for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
+                        uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
+                        E.rname_code(E.prevChar, ch);
+                        if ((q & 31u) == 31u) E.drain_q();
+                        if (ch == 0u) break;
+                        E.prevChar = ch;
+                    }
+                    E.drain_q();
+                    E.prevPos = 0; E.win_clear(); E.win_pos = 0;      /* compress_pos :123-124; compression.c:62-63 */
+                } else E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
+                const uint32_t pos = W::readlane(r_pos, j), flw = W::readlane(r_fl, j), rl = flw >> 16;
+                /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1): the low byte, then three zeros -- */
+                E.dense_code(E.rlen_exc, 255u, 10u, rl & 0xffu, rlen_n);
+                for (int k = 1; k < 4; k++) {
+                    E.encode(0u, rl123_c0, rl123_n);
+                    if (k == 3) {                                    /* the three contexts evolve in lock step */
+                        rl123_c0 += 10u; rl123_n += 10u;
+                        if (rl123_n >= CBC_RESCALE) { rl123_c0 = (rl123_c0 >> 1) + 1u; rl123_n = 254u + rl123_c0; }
+                    }
+                }
+                /* -- compress_pos -- */
+                if (pos < E.prevPos) { E.fail(CBC_ST_ASSERT); break; }                  /* unsorted: x <= 0 aborts there */
+                const uint32_t x = pos - E.prevPos + 1u;
+                if (x >= 5000000u) { E.fail(CBC_ST_ASSERT); break; }                     /* MAX_ALPHA, sam_block.h:54 */
+                pos_code(x);
+                E.prevPos = pos;
+                /* -- compress_flag, compress_match -- */
+                E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);
+                const uint32_t imperfect = (uint32_t)((neq >> j) & 1ull);
+                E.small_code(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | E.prevM) * 2u, 2u, 1u, imperfect ^ 1u);
+                E.prevM = imperfect ^ 1u;
+                if (imperfect && E.status == CBC_ST_OK) {
+                    if (E.q_len >= 32u) E.drain_q();
+                    const uint32_t so = W::readlane(r_seq, j), to = W::readlane(r_tok, j);
+                    const V32 bo = ln * 4u;
+                    const V32 seqv = W::load32_bytes(seqb + so, bo, bo < rl);
+                    const V32 tokv = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
+                    E.edits(pos, flw, to, seqv, tokv, tokb, n_tok_blk);
+                }
+            }
+            rec_index += cn;
+        }
+    }
+    /* ---- end-of-stream sentinel (compression.c:152): same_ref 1, '\n', NUL; flush ---- */
+    uint32_t nbytes = 0;
+    if (E.status == CBC_ST_OK) {
+        E.cur_read = (uint32_t)rec_index;
+        if (E.q_len >= 32u) E.drain_q();
+        E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+        E.rname_code(E.prevChar, (uint32_t)'\n');
+        E.rname_code((uint32_t)'\n', 0u);
+        E.drain_q();
+    }
+    if (E.status == CBC_ST_OK) { E.flush_recs(); nbytes = E.finish(); }
+    if (E.status != CBC_ST_OK) nbytes = 0;
+    V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),
+               W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
+    W::store32((uint32_t *)(A.results + stream), ln, resv, ln < 4u);
+}
+
+#endif /* CBC_STREAM_BODY_H */

@@ -160,6 +160,10 @@ struct WaveGPU {
     {
         return m ? __hip_atomic_load(p + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : other;
     }
+    static CBC_FN void store32_list(uint32_t *p, V32 idx, V32 val, Mask m)
+    {
+        if (m) __hip_atomic_store(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     static CBC_FN void append_list(uint32_t *p, uint32_t idx, uint32_t val)
     {
         if (lane() == 0) __hip_atomic_store(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
