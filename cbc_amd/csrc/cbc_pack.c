@@ -63,6 +63,7 @@ typedef struct {
     uint64_t blk_first_pos;        /* absolute POS of the block's first record */
     uint32_t blk_prev_pos;         /* absolute POS of the previous record in the block */
     uint32_t blk_reads, blk_var, blk_nflags, blk_ndelta;
+    int seg_continues;             /* whole-file mode: the segment being opened continues the previous one's contig */
     uint64_t blk_bases;
     uint16_t blk_flags[CBC_CAP_FLAG];
     uint32_t *dset; uint32_t *dstamp; uint32_t dmask, depoch;   /* distinct-delta hash set */
@@ -271,11 +272,16 @@ static int open_block(packer_t *S, uint32_t pos)
     memset(bd, 0, sizeof *bd); memset(bi, 0, sizeof *bi);
     const cbc_contig_info *c = &P->contigs[S->contig];
     bd->rec_base = P->n_recs; bd->seq_base = P->seq_bytes; bd->tok_base = P->n_tok;
+    if (S->o.whole_file) pos = 1;                       /* a segment of the whole-file stream keeps the SAM's POS */
     bd->ref_off = c->ref_off + (uint64_t)(pos - 1);
     bd->name_off = c->name_off; bd->read_length = P->read_length;
     bi->contig = S->contig; bi->window_start = (uint64_t)(pos - 1);
-    S->blk_open = 1; S->blk_first_pos = pos; S->blk_prev_pos = 0;
-    S->blk_reads = 0; S->blk_var = 0; S->blk_nflags = 0; S->blk_ndelta = 0; S->blk_bases = 0;
+    S->blk_open = 1; S->blk_first_pos = pos;
+    S->blk_reads = 0; S->blk_bases = 0;
+    if (S->o.whole_file && S->seg_continues) { S->seg_continues = 0; return 0; }   /* same contig, same stream state */
+    S->blk_prev_pos = 0;
+    if (S->o.whole_file) return 0;                      /* the models run on: flags and POS steps count per file */
+    S->blk_var = 0; S->blk_nflags = 0; S->blk_ndelta = 0;
     S->depoch++;
     if (S->depoch == 0) { memset(S->dstamp, 0, sizeof(uint32_t) * (S->dmask + 1)); S->depoch = 1; }
     return 0;
@@ -489,6 +495,27 @@ static int place_record(packer_t *S, uint32_t pos, uint32_t flag, size_t rl, uin
     const char *rname = (const char *)P->names + P->contigs[S->contig].name_off;
     int need_new = !S->blk_open;
     uint32_t x = 0;
+    if (S->o.whole_file) {
+        /* one stream per file: cut only where a 32-bit offset of cbc_read_rec would overflow */
+        if (S->blk_open) {
+            const cbc_block_desc *cur = &P->blocks[P->n_blocks];
+            if (pos < S->blk_prev_pos) return fail(S, CBC_E_INPUT, "SAM is not sorted by position at %s:%lld", rname, pos);
+            if (P->seq_bytes - cur->seq_base + rl > 0xfff00000ull || P->n_tok - cur->tok_base + nt > 0xfff00000ull ||
+                S->blk_reads >= 0xfff00000u) { need_new = 1; S->seg_continues = 1; }
+        }
+        x = pos - (S->blk_open ? S->blk_prev_pos : 0u) + 1;   /* prevPos is 0 at a contig's first record (compress_pos :123-124) */
+        if (x >= 5000000u)
+            return fail(S, CBC_E_INPUT, "POS step of 5 000 000 or more at %s:%lld: outside the reference's pos alphabet (MAX_ALPHA); use block mode", rname, pos);
+        if (need_new) { close_block(S); int rc = open_block(S, pos); if (rc) return rc; }
+        if (!delta_seen(S, x, 1)) { S->blk_ndelta++; if (S->blk_ndelta + 3 > S->o.max_cap_pos) return fail(S, CBC_E_INPUT, "more than %s%lld distinct POS steps in one file: beyond the whole-file stream kernel's table; use block mode", "", (long long)S->o.max_cap_pos - 3); }
+        int newflag = 1;
+        for (uint32_t i = 0; i < S->blk_nflags; i++) if (S->blk_flags[i] == (uint16_t)flag) { newflag = 0; break; }
+        if (newflag) {
+            if (S->blk_nflags >= CBC_CAP_FLAG) return fail(S, CBC_E_INPUT, "more than %s%lld distinct FLAG values in one file; use block mode", "", (long long)CBC_CAP_FLAG);
+            S->blk_flags[S->blk_nflags++] = (uint16_t)flag;
+        }
+        goto record;
+    }
     if (S->blk_open) {
         if (pos < S->blk_prev_pos) return fail(S, CBC_E_INPUT, "SAM is not sorted by position at %s:%lld", rname, pos);
         x = pos - S->blk_prev_pos + 1;
@@ -516,6 +543,7 @@ static int place_record(packer_t *S, uint32_t pos, uint32_t flag, size_t rl, uin
     }
     S->blk_var += ev;
 
+record:;
     /* ---- record ---- */
     cbc_block_desc *bd = &P->blocks[P->n_blocks];
     if (grow((void **)&P->recs, &P->cap_recs, P->n_recs + 1, sizeof(cbc_read_rec))) return CBC_E_NOMEM;
@@ -566,6 +594,7 @@ static int finish_pack(packer_t *S)
     P->caps.cap_pos = (P->caps.cap_pos + 63u) & ~63u;
     P->caps.cap_var = (P->caps.cap_var + 63u) & ~63u;
     if (P->n_tok == 0) { if (grow((void **)&P->tok, &P->cap_tok, 1, sizeof(uint32_t))) return CBC_E_NOMEM; P->tok[0] = 0; }
+    P->whole_file = S->o.whole_file ? 1u : 0u;
     return 0;
 }
 
@@ -577,7 +606,8 @@ static int packer_init(packer_t *S, const cbc_pack_opts *opts, char *errbuf, siz
     if (S->o.block_reads > CBC_MAX_BLOCK_READS) S->o.block_reads = CBC_MAX_BLOCK_READS;
     if (S->o.max_cap_pos < 64) S->o.max_cap_pos = 2048;
     if (S->o.max_cap_var < 64) S->o.max_cap_var = 8192;
-    if (S->o.max_cap_pos > 4096) S->o.max_cap_pos = 4096;
+    if (S->o.whole_file) S->o.max_cap_pos = 8192;                  /* the stream kernel's pos table (cbc_stream_body.h) */
+    if (S->o.max_cap_pos > 4096 && !S->o.whole_file) S->o.max_cap_pos = 4096;
     if (S->o.max_cap_var > 32768) S->o.max_cap_var = 32768;       /* keeps L0 + 10*uses < 2^20 */
     S->err = errbuf; S->errlen = errlen;
     if (errbuf && errlen) errbuf[0] = 0;
@@ -594,7 +624,7 @@ static void packer_release(packer_t *S) { free(S->dset); free(S->dstamp); }
 
 API void cbc_pack_default_opts(cbc_pack_opts *o)
 {
-    o->block_reads = 4096; o->max_cap_pos = 2048; o->max_cap_var = 8192; o->var_length = 0; o->n_threads = 0;
+    o->block_reads = 4096; o->max_cap_pos = 2048; o->max_cap_var = 8192; o->var_length = 0; o->n_threads = 0; o->whole_file = 0;
 }
 
 API void cbc_packed_free(cbc_packed *p)

@@ -89,7 +89,7 @@ class UnpackPlanC(ctypes.Structure):
 class PackOpts(ctypes.Structure):
     _fields_ = [("block_reads", ctypes.c_uint32), ("max_cap_pos", ctypes.c_uint32),
                 ("max_cap_var", ctypes.c_uint32), ("var_length", ctypes.c_uint32),
-                ("n_threads", ctypes.c_uint32)]
+                ("n_threads", ctypes.c_uint32), ("whole_file", ctypes.c_uint32)]
 
 
 class SynthOpts(ctypes.Structure):
@@ -141,7 +141,7 @@ def lib():
     return _lib
 
 
-def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False, threads=None):
+def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False, threads=None, whole_file=False):
     o = PackOpts()
     lib().cbc_pack_default_opts(ctypes.byref(o))
     if block_reads is not None:
@@ -153,6 +153,7 @@ def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False
     o.var_length = 1 if var_length else 0
     if threads is not None:
         o.n_threads = threads                  # 0 = one per online CPU, 1 = serial text path
+    o.whole_file = 1 if whole_file else 0      # "compat": one stream per file, the reference's own format
     return o
 
 
@@ -201,6 +202,8 @@ class PackedBatch:
         self.n_tok = int(p.n_tok)
         self.n_blocks = int(p.n_blocks)
         self.n_skipped_unmapped = int(p.n_skipped_unmapped)
+        self.whole_file = bool(p.whole_file)
+        self.max_read_len = int(p.max_read_len)
 
     @property
     def c_ptr(self):

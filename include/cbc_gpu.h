@@ -228,6 +228,38 @@ int  cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_byte
                            cbc_block_result *results /* n_blocks or NULL */);
 uint32_t cbc_gpu_decode_lds_bytes(const cbc_lds_caps *caps);
 
+/* ---- whole-file stream ("compat" mode): the reference's own file format --------------------------------------
+ * compress() / decompress(), src/compression.c:112-216: ONE arithmetic stream per file, models never reset.
+ * `batch` is a cbc_host_batch packed with cbc_pack_opts.whole_file = 1: its `blocks` are SEGMENTS of the one
+ * stream (POS not rebased).  The bytes written to `out` are the bytes `program -c 1 in.sam out ref.fa` (-DDEBUG
+ * build) writes, decodable by the reference's `-x`.  One wavefront codes the stream with the general (rescaling)
+ * form of every model (cbc_stream_body.h); throughput is that of one serial chain.
+ * cbc_gpu_encode_stream_blocks() runs the same general-form coder over ordinary (rebased) blocks, one stream per
+ * block, in cbc_gpu_encode_blocks' output format: the fallback for blocks of more than CBC_MAX_BLOCK_READS records. */
+typedef struct cbc_stream_result {
+    uint64_t nbytes;       /* stream bytes written / records decoded                               */
+    uint32_t status;       /* CBC_ST_*                                                              */
+    uint32_t fail_read;    /* index (in stream order, low 32 bits) of the record being coded        */
+    uint64_t n_symbols;
+} cbc_stream_result;
+
+int  cbc_gpu_encode_stream(cbc_gpu_ctx *ctx, const cbc_host_batch *batch, uint8_t *out, uint64_t out_cap,
+                           cbc_stream_result *result);
+int  cbc_gpu_encode_stream_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *batch, uint8_t *out, uint64_t out_cap,
+                                  uint64_t *out_offsets /* n_blocks+1 */, cbc_block_result *results /* or NULL */);
+
+/* Decode a whole-file stream.  contig_off[c] / contig_len[c]: where contig c (FASTA order) starts in the uploaded
+ * reference and its length; the stream names contigs only by "next one" (decompress_line, compression.c:71-108).
+ * recs[r] = { POS (1-based in its contig), FLAG, length, r * seq_stride (mod 2^32), contig index }, bases of record
+ * r at seq[r * seq_stride].  result->nbytes = records decoded; CBC_ST_OUT_FULL with rec_cap too small (the caller
+ * retries with larger buffers). */
+int  cbc_gpu_decode_stream(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes,
+                           const uint64_t *contig_off, const uint64_t *contig_len, uint32_t n_contigs,
+                           cbc_read_rec *recs, uint64_t rec_cap, uint8_t *seq, uint64_t seq_bytes, uint32_t seq_stride,
+                           cbc_stream_result *result);
+/* header read length of a whole-file stream (its first four bytes come out verbatim), 0 if too short */
+uint32_t cbc_stream_read_length(const uint8_t *in, uint64_t in_bytes);
+
 /* Timing of the most recent encode launch made through this context, measured with HIP events
  * recorded on the launch stream around the kernel (valid after the stream has been synchronised). */
 int  cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms);

@@ -46,7 +46,7 @@ typedef struct cbc_packed {
     uint64_t         n_bases;
     uint64_t         n_skipped_unmapped;
     uint32_t         max_read_len;                    /* longest SEQ packed                        */
-    uint32_t         reserved0;
+    uint32_t         whole_file;                      /* 1: packed for the whole-file stream (cbc_pack_opts.whole_file) */
     /* allocation bookkeeping (private) */
     uint64_t cap_recs, cap_seq, cap_tok, cap_ref; uint32_t cap_names, cap_blocks, cap_contigs;
 } cbc_packed;
@@ -57,6 +57,12 @@ typedef struct cbc_pack_opts {
     uint32_t max_cap_var;   /* cut a block before it can hold more var symbols (default 8192)     */
     uint32_t var_length;    /* reference's -l: header read length = max over the file             */
     uint32_t n_threads;     /* text-path worker threads: 0 = one per online CPU, 1 = serial       */
+    uint32_t whole_file;    /* 1 = "compat" mode: pack for ONE stream per file, the reference's own output format
+                             * (compress(), src/compression.c:112-170): POS is NOT rebased, `blocks` become SEGMENTS
+                             * (consecutive records of one contig; a new segment only at a contig change or when a
+                             * 32-bit offset would overflow), caps.cap_pos counts the distinct POS steps of the whole
+                             * file.  Inputs the reference cannot represent are refused: a POS step of 5 000 000 or
+                             * more (MAX_ALPHA, sam_block.h:54), more than CBC_CAP_FLAG distinct FLAG values. */
 } cbc_pack_opts;
 
 void cbc_pack_default_opts(cbc_pack_opts *o);

@@ -154,3 +154,45 @@ def mapped_sam_lines(sam: bytes):
             continue
         out.append(ln)
     return out
+
+
+class StreamArgs(ctypes.Structure):
+    """cbc_stream_args of cbc_amd/csrc/cbc_stream_body.h."""
+    _fields_ = [("recs", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("tok", ctypes.c_void_p), ("names", ctypes.c_void_p),
+                ("segs", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("out", ctypes.c_void_p), ("results", ctypes.c_void_p),
+                ("vtab", ctypes.c_void_p),
+                ("ref_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64), ("seq_bytes", ctypes.c_uint64),
+                ("n_tok", ctypes.c_uint64), ("n_recs", ctypes.c_uint64),
+                ("n_segs", ctypes.c_uint32), ("cap_pos", ctypes.c_uint32), ("cap_name", ctypes.c_uint32),
+                ("names_bytes", ctypes.c_uint32), ("per_segment", ctypes.c_uint32), ("n_vtab", ctypes.c_uint32)]
+
+
+def emu_encode_stream(pb, per_segment=False):
+    """The whole-file stream body on the CPU wave emulation.  pb: packed with whole_file=True (one stream) or an
+    ordinary block batch with per_segment=True (one general-form stream per block).  Returns (payload list, results)."""
+    L = emu_lib()
+    L.emu_encode_stream.restype = ctypes.c_int
+    L.emu_encode_stream.argtypes = [ctypes.POINTER(StreamArgs)]
+    segs = pb.blocks.copy()
+    n_streams = pb.n_blocks if per_segment else 1
+    off = 0
+    for b in range(pb.n_blocks):                       # each stream's area starts at its first segment's out_off
+        cap = (4096 + 48 * int(segs[b]["n_reads"]) + 8 * int(segs[b]["n_tok"]) + 255) & ~255
+        if not per_segment:
+            cap = (4096 + 48 * pb.n_recs + 8 * pb.n_tok + 255) & ~255 if b == 0 else 0
+        segs[b]["out_off"] = off; segs[b]["out_cap"] = cap
+        off += cap
+    out = np.full(off, 0xAA, dtype=np.uint8)
+    res = np.zeros(n_streams, dtype=host.RESULT_DTYPE)
+    vtab = np.zeros(65535 * 256, dtype=np.uint32)
+    a = StreamArgs(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data, segs.ctypes.data,
+                   pb.ref.ctypes.data, out.ctypes.data, res.ctypes.data, vtab.ctypes.data,
+                   len(pb.ref), off, len(pb.seq), pb.n_tok, pb.n_recs,
+                   pb.n_blocks, max(pb.cap_pos, 64), len(pb.names) + 2 * pb.n_blocks + 16, len(pb.names), 1 if per_segment else 0, 1)
+    if L.emu_encode_stream(ctypes.byref(a)) != 0:
+        raise RuntimeError("emulation reported an invariant violation")
+    payloads = []
+    for s in range(n_streams):
+        o = int(segs[s]["out_off"])
+        payloads.append(out[o:o + int(res[s]["nbytes"])].tobytes())
+    return payloads, res

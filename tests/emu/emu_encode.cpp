@@ -9,6 +9,7 @@
 #include "../../cbc_amd/csrc/cbc_encode_body.h"
 #include "../../cbc_amd/csrc/cbc_decode_body.h"
 #include "../../cbc_amd/csrc/cbc_plan.h"
+#include "../../cbc_amd/csrc/cbc_stream_body.h"
 
 static int g_emu_errors = 0;
 #ifdef CBC_EMU_TRACE
@@ -55,6 +56,22 @@ int emu_decode_blocks(const cbc_dec_device_batch *b)
     for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
         std::vector<uint32_t> lds(words, 0xdeadbeefu);
         cbc_decode_stream<WaveEmu>(A, blk, lds.data());
+    }
+    return g_emu_errors ? -100 : 0;
+}
+
+/* whole-file stream (cbc_stream_body.h): args as the HIP library builds them; vtab zero-filled by the caller */
+extern "C" __attribute__((visibility("default")))
+int emu_encode_stream(const cbc_stream_args *A)
+{
+    g_emu_errors = 0;
+    cbc_stream_caps caps = { A->cap_pos, A->cap_name };
+    uint32_t words = cbc_stream_lds_bytes(&caps) / 4;
+    uint32_t n_streams = A->per_segment ? A->n_segs : 1u;
+    for (uint32_t s = 0; s < n_streams; s++) {
+        std::vector<uint32_t> lds(words, 0xdeadbeefu);
+        if (A->per_segment) memset(A->vtab, 0, (size_t)CBC_VTAB_WORDS * 4);
+        cbc_encode_whole<WaveEmu>(*A, s, 0u, lds.data());
     }
     return g_emu_errors ? -100 : 0;
 }
