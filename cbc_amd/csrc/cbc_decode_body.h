@@ -55,7 +55,14 @@ struct cbc_dec_args {
     uint32_t n_blocks, cap_pos, cap_var;
 };
 
-template <class W>
+CBC_FN uint32_t cbc_basechar(uint32_t b)             /* basepair2char sam_models.c:23-33 */
+{
+    return b == 0u ? 'A' : b == 1u ? 'C' : b == 2u ? 'G' : b == 3u ? 'T' : 'N';
+}
+
+/* GEN = false: the block decoder.  GEN = true: the whole-file stream decoder of cbc_stream_body.h (dense var table in
+ * global memory, table pointers and capacities set by the caller, no closed forms). */
+template <class W, bool GEN = false>
 struct CbcDec {
     typedef typename W::V32 V32;
     typedef typename W::Mask Mask;
@@ -70,6 +77,7 @@ struct CbcDec {
     V32 small, fkey, fexc, hkey, hexc, pval, pcnt;
     uint32_t fcount, fn, hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;
     uint32_t *lds, *evp;
+    uint32_t *rname_key, *rname_exc, *histp, *pos_valp, *pos_cntp, *vtab; uint32_t rn_cap;   /* set by the stream function */
     uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, nev1, cap_var, L0;
     uint32_t prevPos, prevM, prevChar;
     uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
@@ -78,8 +86,8 @@ struct CbcDec {
 
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
     CBC_MFN uint32_t *tab(uint32_t off) { return lds + off; }
-    CBC_MFN uint32_t *pos_val_p() { return lds + CBC_DLDS_FIXED; }
-    CBC_MFN uint32_t *pos_cnt_p() { return lds + CBC_DLDS_FIXED + cap_pos; }
+    CBC_MFN uint32_t *pos_val_p() { return pos_valp; }
+    CBC_MFN uint32_t *pos_cnt_p() { return pos_cntp; }
     CBC_MFN uint32_t *var_ev_p() { return evp; }
 
     /* ---- bit input: 64 big-endian words staged in a VGPR, refilled with one coalesced load ---- */
@@ -354,7 +362,7 @@ struct CbcDec {
     CBC_MFN uint32_t rname_dec(uint32_t ctx)
     {
         V32 ln = W::lane();
-        uint32_t *rkey = tab(CBC_LDS_RNKEY), *rexc = tab(CBC_LDS_RNEXC);
+        uint32_t *rkey = rname_key, *rexc = rname_exc;
         V32 gk = W::splat(0u), ge = W::splat(0u), gi = W::splat(0u);
         uint32_t m = 0, nsum = 0;
         const uint32_t rb = W::uni(rn_count);
@@ -382,7 +390,7 @@ struct CbcDec {
         step(lo, cnt, n);
         if (hit) W::write_uni(rexc, W::readlane(gi, hl), cnt - 1u + 10u);
         else {
-            if (rn_count >= CBC_CAP_NAME) { fail(CBC_ST_CAP_NAME); return 0u; }
+            if (rn_count >= rn_cap) { fail(CBC_ST_CAP_NAME); return 0u; }
             W::write_uni(rkey, rn_count, (ctx << 8) | x);
             W::write_uni(rexc, rn_count, 10u);
             rn_count++;
@@ -419,7 +427,7 @@ struct CbcDec {
         if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return 0u; }
         uint32_t tg = target(n), lo, cnt;
         /* symbols 4*lane..4*lane+3 of context k = two words of u16 counts; excess = 10 per registered delta */
-        const uint32_t *h = tab(CBC_DLDS_HIST) + 128u * k;
+        const uint32_t *h = histp + 128u * k;
         V32 ln = W::lane();
         V32 wa = W::load32(h, ln * 2u, W::all(), 0u), wb = W::load32(h, ln * 2u + 1u, W::all(), 0u);
         uint32_t x = search4((wa & 0xffffu) * 10u, (wa >> 16) * 10u, (wb & 0xffffu) * 10u, (wb >> 16) * 10u, 256u, tg, lo, cnt);
@@ -429,7 +437,7 @@ struct CbcDec {
     }
     CBC_MFN void hist_inc(uint32_t k, uint32_t b)
     {
-        uint32_t *h = tab(CBC_DLDS_HIST) + 128u * k;
+        uint32_t *h = histp + 128u * k;
         W::write_uni(h, b >> 1, W::read_uni(h, b >> 1) + (1u << ((b & 1u) * 16u)));
     }
     CBC_MFN uint32_t pos_dec()                           /* returns x = delta + 1 */
@@ -476,9 +484,36 @@ struct CbcDec {
     }
 
     /* ---- var: Bloom filter, then gather the context's events (each worth 10) into lanes ---- */
+    /* GEN: the dense table of CbcEnc::var_code_dense, searched: lane l takes symbols 4l .. 4l+3 of the row */
+    CBC_MFN uint32_t var_dec_dense(uint32_t ctx)
+    {
+        V32 ln = W::lane();
+        uint32_t *row = vtab + (uint64_t)ctx * L0;
+        W::list_fence();
+        V32 s0 = ln * 4u;
+        V32 e0 = W::load32_list(row, s0, s0 < L0, 0u), e1 = W::load32_list(row, s0 + 1u, (s0 + 1u) < L0, 0u);
+        V32 e2 = W::load32_list(row, s0 + 2u, (s0 + 2u) < L0, 0u), e3 = W::load32_list(row, s0 + 3u, (s0 + 3u) < L0, 0u);
+        const uint32_t n = L0 + W::reduce_add(e0 + e1 + e2 + e3);
+        uint32_t tg = target(n), lo, cnt;
+        if (status != CBC_ST_OK) return 0u;
+        uint32_t x = search4(e0, e1, e2, e3, L0, tg, lo, cnt);
+        if (status != CBC_ST_OK) return 0u;
+        step(lo, cnt, n);
+        W::append_list(row, x, cnt - 1u + 10u);
+        if (n + 10u >= CBC_RESCALE) {
+            W::list_fence();
+            for (uint32_t q = 0; q < 4u; q++) {
+                V32 i = ln + 64u * q;
+                V32 e = W::load32_list(row, i, i < L0, 0u);
+                W::store32_list(row, i, (e + 1u) >> 1, i < L0);
+            }
+        }
+        return x;
+    }
     CBC_MFN uint32_t var_dec(uint32_t ctx)
     {
         if (ctx >= CBC_NVARCTX) { fail(CBC_ST_ASSERT); return 0u; }
+        if (GEN) return var_dec_dense(ctx);
         {   /* hot contexts: dense table, same claim rule as CbcEnc::var_code */
             const uint32_t slot = ctx & 1u;
             uint32_t tag = slot ? vtag1 : vtag0;
@@ -587,12 +622,109 @@ struct CbcDec {
         w0 |= (kw == 0u) ? bit : 0ull; w1 |= (kw == 1u) ? bit : 0ull;
         w2 |= (kw == 2u) ? bit : 0ull; w3 |= (kw == 3u) ? bit : 0ull;
     }
+
+    /* the edits of an imperfect read and the read itself (read_decompression.c:404-529): counts, deletions, SNPs
+     * (the reference-derived base is the chars context, :454-455), insertions.  `refw` = the read's reference window,
+     * 4 bases per lane; tmpb / tmpw = 320 bytes of LDS scratch, dels / insl = 256 words each.  false = failed. */
+    CBC_MFN bool edits_dec(uint32_t pos, uint32_t rl, uint32_t strand, const V32 &refw, uint8_t *dst, const uint8_t *refb,
+                           uint8_t *tmpb, uint32_t *tmpw, uint32_t *dels, uint32_t *insl)
+    {
+            CbcDec &D = *this;
+            const V32 ln = W::lane();
+            const V32 bo = ln * 4u;
+            uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
+            if (D.status == CBC_ST_OK && nSnp == 0u) {
+                nSnp = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nDel = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nIns = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+            }
+            if (D.status != CBC_ST_OK) return false;
+            if (nIns > rl) { D.fail(CBC_ST_ASSERT); return false; }
+            if ((nDel | nIns) == 0u) {
+                /* SNPs only (read_decompression.c:440-458): the read is the reference window with a few
+                 * bytes replaced -- patched in the register that holds 4 bases per lane, no LDS scratch read */
+                V32 w = refw;
+                uint32_t p = 0;
+                for (uint32_t sidx = 0; sidx < nSnp && D.status == CBC_ST_OK; sidx++) {
+                    uint32_t dl = D.win_first(p, rl);
+                    uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
+                    if (D.status != CBC_ST_OK) return false;
+                    uint32_t at = p + g;
+                    p += g + 1u;
+                    D.win_set(p - 1u);
+                    const uint32_t shf = (at & 3u) * 8u;
+                    uint32_t refch = at < rl ? ((W::readlane(w, (at >> 2) & 63u) >> shf) & 0xffu) : 0u;
+                    uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
+                    if (at < rl)
+                        w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w);
+                }
+                if (D.status != CBC_ST_OK) return false;
+                W::store32_bytes(dst, bo, w, bo < rl);
+            } else {
+            const uint32_t T = rl - nIns;                          /* insertion-free length */
+            /* deletions: cumulative matched coordinate of each deleted base */
+            uint32_t p = 0;
+            for (uint32_t d = 0; d < nDel && D.status == CBC_ST_OK; d++) {
+                uint32_t g = D.var_dec((p << 1) | strand);
+                p += g;
+                W::write_uni(dels, d, p);
+            }
+            if (D.status != CBC_ST_OK) return false;
+            /* insertion-free read from the reference: base m comes from ref[pos-1 + m + #{dels at <= m}] */
+            for (uint32_t b = 0; b < T; b += 64u) {
+                V32 m = ln + b;
+                V32 sh = W::splat(0u);
+                for (uint32_t d = 0; d < nDel; d++) { uint32_t dc = W::read_uni(dels, d); sh = sh + W::select(m >= dc, W::splat(1u), W::splat(0u)); }
+                V32 ch = W::load8(refb + (pos - 1u), m + sh, (m < T) & ((m + sh) < 512u));
+                W::store8(tmpb, m, ch, m < T);
+            }
+            /* SNPs (read_decompression.c:440-458) */
+            p = 0;
+            for (uint32_t s = 0; s < nSnp && D.status == CBC_ST_OK; s++) {
+                uint32_t dl = D.win_first(p, rl);
+                uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
+                if (D.status != CBC_ST_OK) return false;
+                uint32_t at = p + g;
+                p += g + 1u;
+                D.win_set(p - 1u);
+                uint32_t refch = at < T ? ((W::read_uni(tmpw, at >> 2) >> ((at & 3u) * 8u)) & 0xffu) : 0u;
+                uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
+                if (at < T) {
+                    uint32_t wv = W::read_uni(tmpw, at >> 2), shf = (at & 3u) * 8u;
+                    W::write_uni(tmpw, at >> 2, (wv & ~(0xffu << shf)) | (cbc_basechar(alt) << shf));
+                }
+            }
+            if (D.status != CBC_ST_OK) return false;
+            /* insertions: output index = matched coordinate + number of earlier insertions */
+            p = 0;
+            for (uint32_t i = 0; i < nIns && D.status == CBC_ST_OK; i++) {
+                uint32_t g = D.var_dec((p << 1) | strand);
+                p += g;
+                uint32_t base = D.small_dec(CBC_LT_CHARS + 5u * 8u, 5u, 8u);
+                W::write_uni(insl, i, ((p + i) << 8) | cbc_basechar(base));
+            }
+            if (D.status != CBC_ST_OK) return false;
+            for (uint32_t b = 0; b < rl; b += 64u) {
+                V32 q = ln + b;
+                V32 nb = W::splat(0u), isins = W::splat(0u), ich = W::splat(0u);
+                for (uint32_t i = 0; i < nIns; i++) {
+                    uint32_t e = W::read_uni(insl, i), oi = e >> 8;
+                    nb = nb + W::select(q > oi, W::splat(1u), W::splat(0u));
+                    Mask here = q == oi;
+                    isins = W::select(here, W::splat(1u), isins);
+                    ich = W::select(here, W::splat(e & 0xffu), ich);
+                }
+                V32 m = q - nb;
+                V32 ch = W::load8(tmpb, m, (q < rl) & (m < 320u) & (isins == 0u));
+                ch = W::select(isins != 0u, ich, ch);
+                W::store8(dst, q, ch, q < rl);
+            }
+            }
+        
+            return true;
+    }
 };
 
-CBC_FN uint32_t cbc_basechar(uint32_t b)             /* basepair2char sam_models.c:23-33 */
-{
-    return b == 0u ? 'A' : b == 1u ? 'C' : b == 2u ? 'G' : b == 3u ? 'T' : 'N';
-}
 
 /* ===========================================================================================
  * cbc_decode_stream: decode block `blk` completely.
@@ -614,6 +746,8 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     D.inb = A.in + in_off;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = A.cap_var; D.L0 = L0;
     D.evp = A.var_scratch + (uint64_t)blk * A.cap_var;
+    D.rname_key = lds + CBC_LDS_RNKEY; D.rname_exc = lds + CBC_LDS_RNEXC; D.rn_cap = CBC_CAP_NAME; D.histp = lds + CBC_DLDS_HIST;
+    D.pos_valp = lds + CBC_DLDS_FIXED; D.pos_cntp = lds + CBC_DLDS_FIXED + A.cap_pos; D.vtab = nullptr;
     /* the payload buffer must leave 3 spare bytes after the last payload (whole-dword reads) */
     /* every range test is written without the sum base + length, which a crafted descriptor could make wrap */
     bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
@@ -737,103 +871,11 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         if (D.status != CBC_ST_OK) break;
         D.prevM = match;
         uint8_t *dst = seqo + (uint64_t)r * stride;
-        V32 bo = ln * 4u;
         CBC_DT(4);                                            /* match */
         if (match) {
             pend_dst = dst; pend_rl = rl;                          /* stored at the top of the next record; stride >= rl rounded to 4 */
         } else {
-            uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
-            CBC_DT(7);                                        /* snps count */
-            if (D.status == CBC_ST_OK && nSnp == 0u) {
-                nSnp = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-                nDel = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-                nIns = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-            }
-            if (D.status != CBC_ST_OK) break;
-            if (nIns > rl) { D.fail(CBC_ST_ASSERT); break; }
-            if ((nDel | nIns) == 0u) {
-                /* SNPs only (read_decompression.c:440-458): the read is the reference window with a few
-                 * bytes replaced -- patched in the register that holds 4 bases per lane, no LDS scratch read */
-                V32 w = refw;
-                uint32_t p = 0;
-                for (uint32_t sidx = 0; sidx < nSnp && D.status == CBC_ST_OK; sidx++) {
-                    uint32_t dl = D.win_first(p, rl);
-                    CBC_DT(8);                                /* win_first */
-                    uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
-                    CBC_DT(9);                                /* var_dec */
-                    if (D.status != CBC_ST_OK) break;
-                    uint32_t at = p + g;
-                    p += g + 1u;
-                    D.win_set(p - 1u);
-                    const uint32_t shf = (at & 3u) * 8u;
-                    uint32_t refch = at < rl ? ((W::readlane(w, (at >> 2) & 63u) >> shf) & 0xffu) : 0u;
-                    uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
-                    if (at < rl)
-                        w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w);
-                    CBC_DT(10);                               /* chars + patch */
-                }
-                if (D.status != CBC_ST_OK) break;
-                W::store32_bytes(dst, bo, w, bo < rl);
-            } else {
-            const uint32_t T = rl - nIns;                          /* insertion-free length */
-            /* deletions: cumulative matched coordinate of each deleted base */
-            uint32_t p = 0;
-            for (uint32_t d = 0; d < nDel && D.status == CBC_ST_OK; d++) {
-                uint32_t g = D.var_dec((p << 1) | strand);
-                p += g;
-                W::write_uni(dels, d, p);
-            }
-            if (D.status != CBC_ST_OK) break;
-            /* insertion-free read from the reference: base m comes from ref[pos-1 + m + #{dels at <= m}] */
-            for (uint32_t b = 0; b < T; b += 64u) {
-                V32 m = ln + b;
-                V32 sh = W::splat(0u);
-                for (uint32_t d = 0; d < nDel; d++) { uint32_t dc = W::read_uni(dels, d); sh = sh + W::select(m >= dc, W::splat(1u), W::splat(0u)); }
-                V32 ch = W::load8(refb + (pos - 1u), m + sh, (m < T) & ((m + sh) < 512u));
-                W::store8(tmpb, m, ch, m < T);
-            }
-            /* SNPs (read_decompression.c:440-458) */
-            p = 0;
-            for (uint32_t s = 0; s < nSnp && D.status == CBC_ST_OK; s++) {
-                uint32_t dl = D.win_first(p, rl);
-                uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
-                if (D.status != CBC_ST_OK) break;
-                uint32_t at = p + g;
-                p += g + 1u;
-                D.win_set(p - 1u);
-                uint32_t refch = at < T ? ((W::read_uni(lds + CBC_DLDS_TMP, at >> 2) >> ((at & 3u) * 8u)) & 0xffu) : 0u;
-                uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
-                if (at < T) {
-                    uint32_t wv = W::read_uni(lds + CBC_DLDS_TMP, at >> 2), shf = (at & 3u) * 8u;
-                    W::write_uni(lds + CBC_DLDS_TMP, at >> 2, (wv & ~(0xffu << shf)) | (cbc_basechar(alt) << shf));
-                }
-            }
-            if (D.status != CBC_ST_OK) break;
-            /* insertions: output index = matched coordinate + number of earlier insertions */
-            p = 0;
-            for (uint32_t i = 0; i < nIns && D.status == CBC_ST_OK; i++) {
-                uint32_t g = D.var_dec((p << 1) | strand);
-                p += g;
-                uint32_t base = D.small_dec(CBC_LT_CHARS + 5u * 8u, 5u, 8u);
-                W::write_uni(insl, i, ((p + i) << 8) | cbc_basechar(base));
-            }
-            if (D.status != CBC_ST_OK) break;
-            for (uint32_t b = 0; b < rl; b += 64u) {
-                V32 q = ln + b;
-                V32 nb = W::splat(0u), isins = W::splat(0u), ich = W::splat(0u);
-                for (uint32_t i = 0; i < nIns; i++) {
-                    uint32_t e = W::read_uni(insl, i), oi = e >> 8;
-                    nb = nb + W::select(q > oi, W::splat(1u), W::splat(0u));
-                    Mask here = q == oi;
-                    isins = W::select(here, W::splat(1u), isins);
-                    ich = W::select(here, W::splat(e & 0xffu), ich);
-                }
-                V32 m = q - nb;
-                V32 ch = W::load8(tmpb, m, (q < rl) & (m < 320u) & (isins == 0u));
-                ch = W::select(isins != 0u, ich, ch);
-                W::store8(dst, q, ch, q < rl);
-            }
-            }
+            if (!D.edits_dec(pos, rl, strand, refw, dst, refb, tmpb, lds + CBC_DLDS_TMP, dels, insl)) break;
         }
         CBC_DT(5);                                            /* copy / edits + reconstruction */
         /* record */

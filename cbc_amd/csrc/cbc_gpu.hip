@@ -17,6 +17,7 @@
 #include "cbc_encode_body.h"
 #include "cbc_decode_body.h"
 #include "cbc_plan.h"
+#include "cbc_stream_body.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 /* internal marker: "use the context's own stream" (host-buffer entry points only) */
@@ -60,6 +61,25 @@ cbc_decode_blocks_kernel(cbc_dec_args A)
     if (blk >= A.n_blocks) return;
     cbc_decode_stream<WaveGPU>(A, blk, cbc_lds);
 }
+
+/* Whole-file stream / general-form fallback (cbc_stream_body.h): one wavefront per stream.  Workgroup w codes streams
+ * w, w + gridDim, ... with var table w of the pool, which it re-zeroes between streams. */
+__global__ void __launch_bounds__(64)
+cbc_encode_whole_kernel(cbc_stream_args A)
+{
+    const uint32_t n_streams = A.per_segment ? A.n_segs : 1u;
+    for (uint32_t s = blockIdx.x; s < n_streams; s += gridDim.x) {
+        if (s != blockIdx.x) {
+            uint4 *t = (uint4 *)(A.vtab + (uint64_t)blockIdx.x * CBC_VTAB_WORDS);
+            for (uint64_t i = threadIdx.x; i < CBC_VTAB_WORDS / 4; i += 64) t[i] = make_uint4(0, 0, 0, 0);
+            __threadfence();
+        }
+        cbc_encode_whole<WaveGPU>(A, s, blockIdx.x, cbc_lds);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+cbc_decode_whole_kernel(cbc_dstream_args A) { cbc_decode_whole<WaveGPU>(A, cbc_lds); }
 
 /* exclusive scan of the per-block payload sizes -> offsets[n_blocks+1]; one workgroup */
 __global__ void __launch_bounds__(1024)
@@ -151,6 +171,8 @@ API int cbc_gpu_init(int device_ordinal, cbc_gpu_ctx **out)
     (void)hipFuncSetAttribute((const void *)cbc_encode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)cbc_encode_blocks_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)cbc_decode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)cbc_encode_whole_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)cbc_decode_whole_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return CBC_OK;
 }
@@ -402,5 +424,185 @@ done:
     if (res && res != results) free(res);
     if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
     if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vs) (void)hipFree(d_vs);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * whole-file stream ("compat" mode) and the general-form fallback over blocks
+ * ---------------------------------------------------------------------------------------------- */
+API uint32_t cbc_stream_read_length(const uint8_t *in, uint64_t in_bytes)
+{
+    /* the header's first int goes through four untouched 256-symbol models: its bytes come out verbatim */
+    if (!in || in_bytes < 4) return 0;
+    return ((uint32_t)in[0] << 24) | ((uint32_t)in[1] << 16) | ((uint32_t)in[2] << 8) | in[3];
+}
+
+static int stream_encode(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, int per_segment, uint8_t *out, uint64_t out_cap,
+                         uint64_t *out_offsets, cbc_block_result *results, cbc_stream_result *sres)
+{
+    if (!ctx || !hb || !out) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    const uint32_t nb = hb->n_blocks;
+    if (nb == 0) return set_err(ctx, CBC_E_ARG, "no records", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const uint32_t n_streams = per_segment ? nb : 1u;
+    cbc_block_desc *segs = (cbc_block_desc *)malloc((size_t)nb * sizeof(cbc_block_desc));
+    cbc_block_result *res = (cbc_block_result *)malloc((size_t)n_streams * sizeof(cbc_block_result));
+    if (!segs || !res) { free(segs); free(res); return CBC_E_NOMEM; }
+    memcpy(segs, hb->blocks, (size_t)nb * sizeof(cbc_block_desc));
+    /* output areas: < 20 bits per coded symbol; symbols per record <= 17 + 2 per edit (cf. cbc_plan_output) */
+    uint64_t scratch = 0;
+    {
+        uint64_t whole = 4096;
+        for (uint32_t b = 0; b < nb; b++) {
+            uint64_t cap = (4096 + 48ull * segs[b].n_reads + 8ull * segs[b].n_tok + 255) & ~255ull;
+            if (per_segment) {
+                if (cap > 0xffffff00ull) cap = 0xffffff00ull;
+                segs[b].out_off = scratch; segs[b].out_cap = (uint32_t)cap; scratch += cap;
+            } else whole += cap;
+        }
+        if (!per_segment) {
+            if (whole > 0xffffff00ull) whole = 0xffffff00ull;
+            whole &= ~255ull;
+            for (uint32_t b = 0; b < nb; b++) { segs[b].out_off = 0; segs[b].out_cap = (uint32_t)whole; }
+            scratch = whole;
+        }
+    }
+    cbc_stream_caps caps; caps.cap_pos = hb->caps.cap_pos < 64 ? 64 : hb->caps.cap_pos; caps.cap_name = hb->names_bytes + 2u * (per_segment ? 1u : nb) + 16u;
+    const uint32_t lds = cbc_stream_lds_bytes(&caps);
+    int rc = CBC_OK;
+    void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_segs = NULL, *d_out = NULL, *d_res = NULL, *d_vtab = NULL;
+    const uint64_t ntok = hb->n_tok ? hb->n_tok : 1;
+    uint32_t grid = n_streams < 32u ? n_streams : 32u;            /* pool of var tables: 67 MB each */
+    if (lds > 160u * 1024u) { free(segs); free(res); return set_err(ctx, CBC_E_ARG, "stream tables need more than 160 KiB of LDS", hipSuccess); }
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_recs, hb->n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
+    GO(hipMalloc(&d_seq, hb->seq_bytes + 16), "hipMalloc seq");
+    GO(hipMalloc(&d_tok, ntok * 4 + 16), "hipMalloc tok");
+    GO(hipMalloc(&d_names, hb->names_bytes + 16), "hipMalloc names");
+    GO(hipMalloc(&d_segs, (uint64_t)nb * sizeof(cbc_block_desc)), "hipMalloc segments");
+    GO(hipMalloc(&d_out, scratch), "hipMalloc out");
+    GO(hipMalloc(&d_res, (uint64_t)n_streams * sizeof(cbc_block_result)), "hipMalloc results");
+    GO(hipMalloc(&d_vtab, (uint64_t)grid * CBC_VTAB_WORDS * 4), "hipMalloc var tables");
+    GO(hipMemsetAsync(d_vtab, 0, (uint64_t)grid * CBC_VTAB_WORDS * 4, ctx->stream), "memset var tables");
+    GO(hipMemcpyAsync(d_recs, hb->recs, hb->n_recs * sizeof(cbc_read_rec), hipMemcpyHostToDevice, ctx->stream), "H2D recs");
+    GO(hipMemcpyAsync(d_seq, hb->seq, hb->seq_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D seq");
+    GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
+    GO(hipMemcpyAsync(d_names, hb->names, hb->names_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D names");
+    GO(hipMemcpyAsync(d_segs, segs, (uint64_t)nb * sizeof(cbc_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D segments");
+    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)n_streams * sizeof(cbc_block_result), ctx->stream), "memset results");
+    {
+        cbc_stream_args A;
+        memset(&A, 0, sizeof A);
+        A.recs = (const cbc_read_rec *)d_recs; A.seq = (const uint8_t *)d_seq; A.tok = (const uint32_t *)d_tok;
+        A.names = (const uint8_t *)d_names; A.segs = (const cbc_block_desc *)d_segs; A.ref = ctx->d_ref;
+        A.out = (uint8_t *)d_out; A.results = (cbc_block_result *)d_res; A.vtab = (uint32_t *)d_vtab;
+        A.ref_bytes = ctx->ref_bytes; A.out_bytes = scratch; A.seq_bytes = hb->seq_bytes; A.n_tok = ntok; A.n_recs = hb->n_recs;
+        A.n_segs = nb; A.cap_pos = caps.cap_pos; A.cap_name = caps.cap_name; A.names_bytes = hb->names_bytes;
+        A.per_segment = per_segment ? 1u : 0u; A.n_vtab = grid;
+        GO(hipEventRecord(ctx->ev0, ctx->stream), "hipEventRecord");
+        hipLaunchKernelGGL(cbc_encode_whole_kernel, dim3(grid), dim3(64), lds, ctx->stream, A);
+        GO(hipGetLastError(), "launch cbc_encode_whole_kernel");
+        GO(hipEventRecord(ctx->ev1, ctx->stream), "hipEventRecord");
+        ctx->have_timing = 1;
+    }
+    GO(hipMemcpyAsync(res, d_res, (uint64_t)n_streams * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
+    GO(hipStreamSynchronize(ctx->stream), "stream encode kernel");
+    {
+        uint64_t off = 0;
+        if (out_offsets) out_offsets[0] = 0;
+        for (uint32_t s = 0; s < n_streams; s++) {
+            if (res[s].status != CBC_ST_OK) {
+                if (rc == CBC_OK) { snprintf(ctx->err, sizeof ctx->err, "stream %u failed with status %u at record %u", s, res[s].status, res[s].fail_read); rc = CBC_E_BLOCK; }
+                res[s].nbytes = 0;
+            }
+            if (off + res[s].nbytes > out_cap) { rc = set_err(ctx, CBC_E_ARG, "out_cap too small for the stream", hipSuccess); goto done; }
+            if (res[s].nbytes) GO(hipMemcpyAsync(out + off, (uint8_t *)d_out + segs[per_segment ? s : 0].out_off, res[s].nbytes, hipMemcpyDeviceToHost, ctx->stream), "D2H stream");
+            off += res[s].nbytes;
+            if (out_offsets) out_offsets[s + 1] = off;
+            if (results) results[s] = res[s];
+        }
+        GO(hipStreamSynchronize(ctx->stream), "D2H stream");
+        if (sres) { sres->nbytes = off; sres->status = res[0].status; sres->fail_read = res[0].fail_read; sres->n_symbols = res[0].n_symbols; }
+    }
+done:
+#undef GO
+    free(segs); free(res);
+    if (d_recs) (void)hipFree(d_recs); if (d_seq) (void)hipFree(d_seq); if (d_tok) (void)hipFree(d_tok);
+    if (d_names) (void)hipFree(d_names); if (d_segs) (void)hipFree(d_segs); if (d_out) (void)hipFree(d_out);
+    if (d_res) (void)hipFree(d_res); if (d_vtab) (void)hipFree(d_vtab);
+    return rc;
+}
+
+API int cbc_gpu_encode_stream(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_t *out, uint64_t out_cap, cbc_stream_result *result)
+{
+    return stream_encode(ctx, hb, 0, out, out_cap, NULL, NULL, result);
+}
+API int cbc_gpu_encode_stream_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_t *out, uint64_t out_cap,
+                                     uint64_t *out_offsets, cbc_block_result *results)
+{
+    if (!out_offsets) return CBC_E_ARG;
+    return stream_encode(ctx, hb, 1, out, out_cap, out_offsets, results, NULL);
+}
+
+API int cbc_gpu_decode_stream(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes,
+                              const uint64_t *contig_off, const uint64_t *contig_len, uint32_t n_contigs,
+                              cbc_read_rec *recs, uint64_t rec_cap, uint8_t *seq, uint64_t seq_bytes, uint32_t seq_stride,
+                              cbc_stream_result *result)
+{
+    if (!ctx || !in || !contig_off || !contig_len || !recs || !seq || !result || n_contigs == 0) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    const uint32_t L0 = cbc_stream_read_length(in, in_bytes);
+    if (L0 < 1 || L0 > 256 || seq_stride < 4 || seq_stride > 256 || (seq_stride & 3u) || rec_cap == 0 || rec_cap > 0xffffffffull ||
+        seq_bytes < rec_cap * seq_stride + 8) return set_err(ctx, CBC_E_ARG, "bad stream header or buffer sizes", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    cbc_stream_caps caps; caps.cap_pos = 8192; caps.cap_name = 2048;
+    const uint32_t lds = cbc_stream_lds_bytes(&caps);
+    void *d_in = NULL, *d_co = NULL, *d_cl = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL, *d_vtab = NULL;
+    cbc_block_result res; memset(&res, 0xff, sizeof res);
+    int rc = CBC_OK;
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_in, in_bytes + 16), "hipMalloc in");
+    GO(hipMalloc(&d_co, (uint64_t)n_contigs * 8), "hipMalloc contigs");
+    GO(hipMalloc(&d_cl, (uint64_t)n_contigs * 8), "hipMalloc contigs");
+    GO(hipMalloc(&d_recs, rec_cap * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
+    GO(hipMalloc(&d_seq, seq_bytes + 16), "hipMalloc seq");
+    GO(hipMalloc(&d_res, sizeof(cbc_block_result)), "hipMalloc result");
+    GO(hipMalloc(&d_vtab, CBC_VTAB_WORDS * 4), "hipMalloc var table");
+    GO(hipMemsetAsync(d_vtab, 0, CBC_VTAB_WORDS * 4, ctx->stream), "memset var table");
+    GO(hipMemsetAsync((uint8_t *)d_in + in_bytes, 0, 16, ctx->stream), "memset pad");
+    GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D stream");
+    GO(hipMemcpyAsync(d_co, contig_off, (uint64_t)n_contigs * 8, hipMemcpyHostToDevice, ctx->stream), "H2D contigs");
+    GO(hipMemcpyAsync(d_cl, contig_len, (uint64_t)n_contigs * 8, hipMemcpyHostToDevice, ctx->stream), "H2D contigs");
+    GO(hipMemsetAsync(d_res, 0xff, sizeof(cbc_block_result), ctx->stream), "memset result");
+    {
+        cbc_dstream_args A;
+        memset(&A, 0, sizeof A);
+        A.in = (const uint8_t *)d_in; A.ref = ctx->d_ref; A.contig_off = (const uint64_t *)d_co; A.contig_len = (const uint64_t *)d_cl;
+        A.recs = (cbc_read_rec *)d_recs; A.seq = (uint8_t *)d_seq; A.results = (cbc_block_result *)d_res; A.vtab = (uint32_t *)d_vtab;
+        A.in_bytes = in_bytes; A.ref_bytes = ctx->ref_bytes; A.rec_cap = rec_cap; A.seq_bytes = seq_bytes + 16;
+        A.n_contigs = n_contigs; A.cap_pos = caps.cap_pos; A.cap_name = caps.cap_name; A.seq_stride = seq_stride; A.read_length = L0;
+        GO(hipEventRecord(ctx->ev0, ctx->stream), "hipEventRecord");
+        hipLaunchKernelGGL(cbc_decode_whole_kernel, dim3(1), dim3(64), lds, ctx->stream, A);
+        GO(hipGetLastError(), "launch cbc_decode_whole_kernel");
+        GO(hipEventRecord(ctx->ev1, ctx->stream), "hipEventRecord");
+        ctx->have_timing = 1;
+    }
+    GO(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream), "D2H result");
+    GO(hipStreamSynchronize(ctx->stream), "stream decode kernel");
+    result->nbytes = res.nbytes; result->status = res.status; result->fail_read = res.fail_read; result->n_symbols = res.n_symbols;
+    if (res.nbytes <= rec_cap && res.nbytes) {
+        GO(hipMemcpyAsync(recs, d_recs, (uint64_t)res.nbytes * sizeof(cbc_read_rec), hipMemcpyDeviceToHost, ctx->stream), "D2H recs");
+        GO(hipMemcpyAsync(seq, d_seq, (uint64_t)res.nbytes * seq_stride, hipMemcpyDeviceToHost, ctx->stream), "D2H seq");
+        GO(hipStreamSynchronize(ctx->stream), "D2H");
+    }
+    if (res.status != CBC_ST_OK) {
+        snprintf(ctx->err, sizeof ctx->err, "stream decode stopped with status %u at record %u", res.status, res.fail_read);
+        rc = CBC_E_BLOCK;
+    }
+done:
+#undef GO
+    if (d_in) (void)hipFree(d_in); if (d_co) (void)hipFree(d_co); if (d_cl) (void)hipFree(d_cl); if (d_recs) (void)hipFree(d_recs);
+    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vtab) (void)hipFree(d_vtab);
     return rc;
 }

@@ -10,7 +10,10 @@
  * Exactly three positional file names, in the reference's order (src/main.c:88-108, 200-204).
  * Network / QV modes of the reference (-u -s -r -D -w -t, and -d with user@host:file) are outside
  * the hot path and are refused with a message.  Extra options: --block-reads N, --device N,
- * --threads N, --verbose.
+ * --threads N, --verbose, and --compat: write the reference's OWN file format (one arithmetic stream for the whole
+ * file, compress() src/compression.c:112-170) instead of the block container -- byte-identical to what
+ * `program -c 1` (-DDEBUG build) writes and readable by its `-x`; one wavefront codes it, so it is slow.
+ * `cbc -d` recognises either format.
  * Exit status: 0 on success (the reference returns 1 on success, src/main.c:370 -- not reproduced).
  *
  * There is no CPU encoder or decoder in this program: without an MI355X it exits with an error.
@@ -32,7 +35,8 @@ static void usage(const char *p)
             "usage: %s -c [1] <in.sam> <out.cbc> <ref.fa>   compress the reads of a position-sorted SAM\n"
             "       %s -d|-x <in.cbc> <out.txt> <ref.fa>    reconstruct the reads, one per line\n"
             "options: -l (header read length = longest read)  --block-reads N (default 4096)  --device N (default 0)\n"
-            "         --threads N (SAM parser threads, default one per CPU)  --verbose (stage times)\n", p, p);
+            "         --threads N (SAM parser threads, default one per CPU)  --verbose (stage times)\n"
+            "         --compat (write the reference's own single-stream format; slow: one stream = one wavefront)\n", p, p);
 }
 
 /* Input files are mapped, not copied: the packer only ever reads [0, len). */
@@ -62,7 +66,7 @@ static int is_number(const char *s)
     return e && *e == 0;
 }
 
-static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose)
+static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose, int compat)
 {
     size_t sam_len = 0, fa_len = 0;
     double t0 = now_s();
@@ -74,6 +78,7 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     if (block_reads) po.block_reads = block_reads;
     po.var_length = (uint32_t)var_length;
     po.n_threads = (uint32_t)threads;
+    po.whole_file = compat ? 1u : 0u;
     cbc_packed *p = NULL;
     int rc = cbc_pack_sam(sam, sam_len, fa, fa_len, &po, &p, err, sizeof err);
     unmap_file(sam, sam_len); unmap_file(fa, fa_len);
@@ -89,6 +94,23 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     hb.recs = p->recs; hb.n_recs = p->n_recs; hb.seq = p->seq; hb.seq_bytes = p->seq_bytes;
     hb.tok = p->tok; hb.n_tok = p->n_tok; hb.names = p->names; hb.names_bytes = p->names_bytes;
     hb.blocks = p->blocks; hb.n_blocks = p->n_blocks; hb.caps = p->caps;
+    if (compat) {
+        /* the reference's format: the stream IS the file (no container, no index) */
+        uint64_t scap = 4096 + 48ull * p->n_recs + 8ull * p->n_tok;
+        uint8_t *stream = (uint8_t *)malloc(scap);
+        cbc_stream_result sr;
+        if (!stream) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
+        double t2 = now_s();
+        rc = cbc_gpu_encode_stream(ctx, &hb, stream, scap, &sr);
+        if (rc) { fprintf(stderr, "cbc: encode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
+        FILE *fo = fopen(out, "wb");
+        if (!fo || fwrite(stream, 1, (size_t)sr.nbytes, fo) != (size_t)sr.nbytes || fclose(fo) != 0) { fprintf(stderr, "cbc: cannot write %s\n", out); return 1; }
+        printf("Final Size: %llu\n", (unsigned long long)sr.nbytes);
+        printf("%llu reads in one stream, %llu bases, %llu coded symbols\n", (unsigned long long)p->n_recs, (unsigned long long)p->n_bases, (unsigned long long)sr.n_symbols);
+        if (verbose) printf("time: pack %.3f s, device init + reference upload %.3f s, encode %.3f s\n", t1 - t0, t2 - t1, now_s() - t2);
+        free(stream); cbc_gpu_shutdown(ctx); cbc_packed_free(p);
+        return 0;
+    }
     uint64_t cap = cbc_gpu_plan_output(p->blocks, p->n_blocks, p->recs, p->tok);
     uint8_t *payloads = (uint8_t *)malloc(cap ? cap : 1);
     uint64_t *offs = (uint64_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint64_t));
@@ -119,7 +141,7 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, int dev
 int main(int argc, char **argv)
 {
     const char *files[3] = { 0, 0, 0 };
-    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0;
+    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0;
     uint32_t block_reads = 0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -132,6 +154,7 @@ int main(int argc, char **argv)
         if (!strcmp(a, "--device") && i + 1 < argc) { device = atoi(argv[++i]); continue; }
         if (!strcmp(a, "--threads") && i + 1 < argc) { threads = atoi(argv[++i]); if (threads < 0) threads = 0; continue; }
         if (!strcmp(a, "--verbose")) { verbose = 1; continue; }
+        if (!strcmp(a, "--compat")) { compat = 1; continue; }
         if (!strcmp(a, "-h") || !strcmp(a, "--help")) { usage(argv[0]); return 0; }
         switch (a[1]) {
         case 'c':
@@ -166,6 +189,6 @@ int main(int argc, char **argv)
         fprintf(stderr, "cbc: user@host:file download mode (src/main.c:306-326) is out of scope\n");
         return 1;
     }
-    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose)
+    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat)
                      : cbc_cli_decompress(files[0], files[1], files[2], device);
 }

@@ -618,6 +618,7 @@ static int packer_init(packer_t *S, const cbc_pack_opts *opts, char *errbuf, siz
     S->dset = (uint32_t *)calloc(sz, sizeof(uint32_t));
     S->dstamp = (uint32_t *)calloc(sz, sizeof(uint32_t));
     if (!S->dset || !S->dstamp) return CBC_E_NOMEM;
+    S->depoch = 1;                                  /* stamps start at 0 = "never used" */
     return 0;
 }
 static void packer_release(packer_t *S) { free(S->dset); free(S->dstamp); }
@@ -1174,6 +1175,40 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
     }
     memcpy(d, payloads, (size_t)out_offsets[p->n_blocks]);
     return (int64_t)total;
+}
+
+/* ================================= reference alone ======================================== */
+API void cbc_reference_free(cbc_reference *r)
+{
+    if (!r) return;
+    free(r->bases); free(r->contig_off); free(r->contig_len); free(r);
+}
+API int cbc_reference_load(const char *fasta, size_t fasta_len, uint32_t n_threads, cbc_reference **out, char *errbuf, size_t errlen)
+{
+    if (!fasta || !out) return CBC_E_ARG;
+    *out = NULL;
+    packer_t *S = (packer_t *)calloc(1, sizeof(packer_t));
+    cbc_reference *r = (cbc_reference *)calloc(1, sizeof(cbc_reference));
+    if (!S || !r) { free(S); free(r); return CBC_E_NOMEM; }
+    S->err = errbuf; S->errlen = errlen;
+    if (errbuf && errlen) errbuf[0] = 0;
+    int rc = CBC_E_NOMEM;
+    S->P = (cbc_packed *)calloc(1, sizeof(cbc_packed));
+    if (S->P) rc = load_reference(S, fasta, fasta_len, n_threads);
+    if (!rc && S->n_fasta == 0) rc = fail(S, CBC_E_INPUT, "the FASTA holds no sequence%s%lld", "", 0);
+    if (!rc) {
+        r->contig_off = (uint64_t *)calloc(S->n_fasta, sizeof(uint64_t));
+        r->contig_len = (uint64_t *)calloc(S->n_fasta, sizeof(uint64_t));
+        if (!r->contig_off || !r->contig_len) rc = CBC_E_NOMEM;
+    }
+    if (!rc) {
+        for (uint32_t i = 0; i < S->n_fasta; i++) { r->contig_off[i] = S->P->contigs[i].ref_off; r->contig_len[i] = S->P->contigs[i].length; }
+        r->n_contigs = S->n_fasta; r->bases = S->P->ref; r->n_bytes = S->P->ref_bytes; S->P->ref = NULL;
+        *out = r;
+    } else cbc_reference_free(r);
+    if (S->P) cbc_packed_free(S->P);
+    free(S);
+    return rc;
 }
 
 /* ================================= unpack side ============================================ */

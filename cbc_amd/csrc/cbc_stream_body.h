@@ -290,4 +290,157 @@ CBC_FN void cbc_encode_whole(const cbc_stream_args &A, uint32_t stream, uint32_t
     W::store32((uint32_t *)(A.results + stream), ln, resv, ln < 4u);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * decode direction: decompress() src/compression.c:173-216, decompress_line :71-108 -- the exact inverse of
+ * cbc_encode_whole (same model forms), one wavefront, records until the end-of-stream sentinel.
+ * ------------------------------------------------------------------------------------------------------------- */
+struct cbc_dstream_args {
+    const uint8_t  *in;
+    const uint8_t  *ref;
+    const uint64_t *contig_off, *contig_len;   /* FASTA order: the stream only ever says "next contig" */
+    cbc_read_rec   *recs;
+    uint8_t        *seq;
+    cbc_block_result *results;
+    uint32_t       *vtab;
+    uint64_t in_bytes, ref_bytes, rec_cap, seq_bytes;
+    uint32_t n_contigs, cap_pos, cap_name, seq_stride, read_length;
+};
+
+template <class W>
+CBC_FN void cbc_decode_whole(const cbc_dstream_args &A, uint32_t *lds)
+{
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+    const V32 ln = W::lane();
+    CbcDec<W, true> D;
+    const uint32_t L0 = A.read_length, stride = A.seq_stride;
+
+    D.status = CBC_ST_OK; D.nsym = 0; D.fail_read = 0; D.cur_read = 0;
+    D.l = 0; D.u = CBC_M26; D.t = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
+    D.inb = A.in;
+    D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = 0; D.L0 = L0; D.evp = nullptr;
+    D.rname_key = lds + CBC_SLDS_FIXED; D.rname_exc = D.rname_key + A.cap_name; D.rn_cap = A.cap_name;
+    D.pos_valp = D.rname_exc + A.cap_name; D.pos_cntp = D.pos_valp + A.cap_pos; D.histp = lds + CBC_SLDS_DEC_HIST;
+    D.vtab = A.vtab;
+    bool args_ok = (L0 >= 1u && L0 <= 256u) && (stride >= 4u && stride <= 256u && (stride & 3u) == 0u) && A.n_contigs >= 1u &&
+                   A.cap_pos >= 2u && A.cap_name >= 4u && cbc_le64(A.in_bytes, 0x3fffffff0ull) &&
+                   cbc_le64(A.rec_cap, 0xffffffffull) && cbc_le64(A.rec_cap * (uint64_t)stride + 8u, A.seq_bytes);
+    D.nwords_in = (uint32_t)((A.in_bytes + 3u) >> 2);
+    D.tail_valid = (uint32_t)A.in_bytes & 3u;
+    if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
+    for (uint32_t b = 0; b < CBC_SLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_SLDS_FIXED);
+    D.rlen_n = 255u; D.rl123_c0 = 1u; D.rl123_n = 255u; D.snps_n = L0; D.indels_n = L0; D.rn_count = 0;
+    D.pos_card = 1u; D.pos_n = 1u; D.nev = 0; D.nev1 = 0;
+    D.pval = W::splat(0xffffffffu); D.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
+    D.fkey = W::splat(0u); D.fexc = W::splat(0u); D.fcount = 0; D.fn = 65536u;
+    D.hkey = W::splat(0u); D.hexc = W::splat(0u);
+    D.hc0 = D.hc1 = D.hc2 = D.hc3 = 0; D.hn0 = D.hn1 = D.hn2 = D.hn3 = 256u;
+    {
+        V32 s = W::select(ln < 10u, W::splat(1u), W::splat(0u));
+        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
+        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
+        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
+        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
+                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
+        cv = W::select(bump, cv + 8u, cv);
+        D.small = W::select(inch, cv, s);
+    }
+    D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
+    D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
+    D.vtag0 = D.vtag1 = CBC_NOMEMO; D.vsum0 = D.vsum1 = 0;
+
+    if (D.status == CBC_ST_OK) D.t = D.take(26u);                 /* the tag (alloc_arithmetic_stream :260-263) */
+    for (uint32_t k = 0; k < 34u && D.status == CBC_ST_OK; k++) {  /* header: int(L0), 32 x int(WELL), int(8) */
+        uint32_t v = D.regsparse_dec(D.hkey, D.hexc, 0u, 8u, D.hc0, D.hn0, 256u, 1u, CBC_ST_ASSERT) << 24;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 8u, 8u, D.hc1, D.hn1, 256u, 1u, CBC_ST_ASSERT) << 16;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 16u, 8u, D.hc2, D.hn2, 256u, 1u, CBC_ST_ASSERT) << 8;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 24u, 8u, D.hc3, D.hn3, 256u, 1u, CBC_ST_ASSERT);
+        if (D.status != CBC_ST_OK) break;
+        if (k == 0u && v != L0) D.fail(CBC_ST_ASSERT);
+        if (k == 33u && v != 8u) D.fail(CBC_ST_UNSUPPORTED);       /* LOSSY streams are out of scope */
+    }
+
+    uint4 *recs4 = (uint4 *)A.recs;
+    uint8_t *tmpb = (uint8_t *)(lds + CBC_SLDS_DEC_TMP);
+    uint32_t *dels = lds + CBC_SLDS_DEC_DELS, *insl = lds + CBC_SLDS_DEC_INS;
+    const uint8_t *refb = A.ref; uint32_t ref_lim = 0, contig = 0xffffffffu;
+    V32 refw = W::splat(0u); uint8_t *pend_dst = A.seq; uint32_t pend_rl = 0;
+    uint32_t r = 0;
+    bool done = false;
+    while (D.status == CBC_ST_OK && !done) {
+        D.cur_read = r;
+        if (pend_rl) { W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl); pend_rl = 0; }
+        /* -- decompress_rname (id_compression.c:67-94) -- */
+        uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
+        if (D.status != CBC_ST_OK) break;
+        if (sr) {
+            for (uint32_t q = 0; D.status == CBC_ST_OK; q++) {
+                uint32_t ch = D.rname_dec(D.prevChar);
+                if (D.status != CBC_ST_OK || ch == 0u) break;
+                if (ch == (uint32_t)'\n') {                        /* the end-of-stream sentinel (compression.c:152) */
+                    if (q != 0u || D.rname_dec((uint32_t)'\n') != 0u) D.fail(CBC_ST_ASSERT);
+                    done = true; break;
+                }
+                if (q >= CBC_CAP_NAME) { D.fail(CBC_ST_CAP_NAME); break; }
+                D.prevChar = ch;
+            }
+            if (done || D.status != CBC_ST_OK) break;
+            contig++;                                              /* the next FASTA record (read_decompression.c:28-42) */
+            if (contig >= A.n_contigs) { D.fail(CBC_ST_ASSERT); break; }
+            const uint64_t co = W::read_uni((const uint32_t *)(A.contig_off + contig), 0u) | ((uint64_t)W::read_uni((const uint32_t *)(A.contig_off + contig), 1u) << 32);
+            const uint64_t cl = W::read_uni((const uint32_t *)(A.contig_len + contig), 0u) | ((uint64_t)W::read_uni((const uint32_t *)(A.contig_len + contig), 1u) << 32);
+            if (!cbc_fits64(co, cl + CBC_REF_PAD, A.ref_bytes)) { D.fail(CBC_ST_ASSERT); break; }
+            refb = A.ref + co;
+            ref_lim = cbc_avail32(cl + CBC_REF_PAD, 0u);
+            D.prevPos = 0; D.win_clear();
+        } else if (contig == 0xffffffffu) { D.fail(CBC_ST_ASSERT); break; }
+        if (!cbc_le64((uint64_t)r + 1u, A.rec_cap)) { D.fail(CBC_ST_OUT_FULL); break; }
+
+        /* -- read length (read_decompression.c:68-74, quirk Q1): the low byte, then three symbols that can only be 0 -- */
+        uint32_t rl = D.rlen_dec();
+        for (int k = 1; k < 4 && D.status == CBC_ST_OK; k++) {
+            D.nsym++;
+            const uint32_t range = D.u - D.l + 1u;
+            uint32_t q0, qn;
+            float inv = W::lane_float(W::recip_v(W::splat(D.rl123_n)), 0u);
+            W::muldiv2(range, D.rl123_c0, D.rl123_n, D.rl123_n, inv, q0, qn);
+            if (q0 == 0u || D.t - D.l >= q0) { D.fail(CBC_ST_ASSERT); break; }   /* another symbol was coded here */
+            D.u = D.l + q0 - 1u;
+            D.renorm();
+        }
+        D.rl123_c0 += 10u; D.rl123_n += 10u;
+        if (D.rl123_n >= CBC_RESCALE) { D.rl123_c0 = (D.rl123_c0 >> 1) + 1u; D.rl123_n = 254u + D.rl123_c0; }
+        if (D.status != CBC_ST_OK) break;
+        if (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride) { D.fail(CBC_ST_ASSERT); break; }
+
+        /* -- pos, flag -- */
+        uint32_t x = D.pos_dec();
+        if (D.status != CBC_ST_OK) break;
+        if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); break; }
+        uint32_t pos = D.prevPos + x - 1u;
+        if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); break; }
+        D.win_shift(x - 1u > 256u ? 256u : x - 1u);
+        D.prevPos = pos;
+        uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
+        if (D.status != CBC_ST_OK) break;
+        const uint32_t strand = (flag >> 4) & 1u;
+        if (pos == 0u || pos > ref_lim || ref_lim - pos < rl + 3u + 256u) { D.fail(CBC_ST_ASSERT); break; }
+        refw = W::load32_bytes(refb + (pos - 1u), ln * 4u, (ln * 4u) < rl);
+
+        uint32_t match = D.small_dec(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | D.prevM) * 2u, 2u, 1u);
+        if (D.status != CBC_ST_OK) break;
+        D.prevM = match;
+        uint8_t *dst = A.seq + (uint64_t)r * stride;
+        if (match) { pend_dst = dst; pend_rl = rl; }
+        else if (!D.edits_dec(pos, rl, strand, refw, dst, refb, tmpb, lds + CBC_SLDS_DEC_TMP, dels, insl)) break;
+        V32 rv0 = W::splat(pos), rv1 = W::splat(flag | (rl << 16)), rv2 = W::splat(r * stride), rv3 = W::splat(contig);
+        W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
+        r++;
+    }
+    if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl);
+    V32 resv = W::select(ln == 0u, W::splat(r), W::select(ln == 1u, W::splat(D.status),
+               W::select(ln == 2u, W::splat(D.nsym), W::splat(D.fail_read))));
+    W::store32((uint32_t *)A.results, ln, resv, ln < 4u);
+}
+
 #endif /* CBC_STREAM_BODY_H */

@@ -54,6 +54,11 @@ class DecDeviceBatch(ctypes.Structure):
     ]
 
 
+class StreamResult(ctypes.Structure):
+    _fields_ = [("nbytes", ctypes.c_uint64), ("status", ctypes.c_uint32), ("fail_read", ctypes.c_uint32),
+                ("n_symbols", ctypes.c_uint64)]
+
+
 class CbcGpuError(RuntimeError):
     pass
 
@@ -101,6 +106,18 @@ def lib():
         L.cbc_gpu_lds_bytes.argtypes = [ctypes.POINTER(host.LdsCaps)]
         L.cbc_gpu_last_kernel_ms.restype = ctypes.c_int
         L.cbc_gpu_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.cbc_gpu_encode_stream.restype = ctypes.c_int
+        L.cbc_gpu_encode_stream.argtypes = [ctypes.c_void_p, ctypes.POINTER(HostBatch), ctypes.c_void_p, ctypes.c_uint64,
+                                            ctypes.POINTER(StreamResult)]
+        L.cbc_gpu_encode_stream_blocks.restype = ctypes.c_int
+        L.cbc_gpu_encode_stream_blocks.argtypes = [ctypes.c_void_p, ctypes.POINTER(HostBatch), ctypes.c_void_p, ctypes.c_uint64,
+                                                   ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_gpu_decode_stream.restype = ctypes.c_int
+        L.cbc_gpu_decode_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                            ctypes.c_uint32, ctypes.POINTER(StreamResult)]
+        L.cbc_stream_read_length.restype = ctypes.c_uint32
+        L.cbc_stream_read_length.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         L.cbc_gpu_last_kernel_variant.restype = ctypes.c_int
         L.cbc_gpu_last_kernel_variant.argtypes = [ctypes.c_void_p]
         L.cbc_gpu_synchronize.restype = ctypes.c_int
@@ -114,7 +131,8 @@ def lib():
 EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_gpu_shutdown", "cbc_gpu_last_error",
            "cbc_gpu_upload_reference", "cbc_gpu_encode_blocks", "cbc_gpu_encode_blocks_device", "cbc_gpu_compact_device",
            "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_decode_blocks_device", "cbc_gpu_decode_blocks",
-           "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_last_kernel_variant", "cbc_gpu_synchronize"]
+           "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_last_kernel_variant", "cbc_gpu_synchronize",
+           "cbc_gpu_encode_stream", "cbc_gpu_encode_stream_blocks", "cbc_gpu_decode_stream", "cbc_stream_read_length"]
 
 
 class Encoder:
@@ -170,6 +188,60 @@ class Encoder:
         if rc != 0 and rc != -4:
             self._check(rc, "cbc_gpu_decode_blocks")
         return recs, seq, res
+
+    def _host_batch(self, pb):
+        blocks = pb.blocks.copy()
+        hb = HostBatch(pb.recs.ctypes.data, pb.n_recs, pb.seq.ctypes.data, len(pb.seq), pb.tok.ctypes.data, pb.n_tok,
+                       pb.names.ctypes.data, len(pb.names), blocks.ctypes.data, pb.n_blocks, host.LdsCaps(pb.cap_pos, pb.cap_var))
+        return hb, blocks
+
+    def encode_stream(self, pb: "host.PackedBatch"):
+        """Whole-file stream ("compat" mode): pb packed with whole_file=True.  Returns (stream bytes, StreamResult)."""
+        hb, keep = self._host_batch(pb)
+        cap = int(4096 + 48 * pb.n_recs + 8 * pb.n_tok)
+        out = np.zeros(cap, dtype=np.uint8)
+        sr = StreamResult()
+        rc = lib().cbc_gpu_encode_stream(self._ctx, ctypes.byref(hb), out.ctypes.data, cap, ctypes.byref(sr))
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_encode_stream")
+        return out[:int(sr.nbytes)].tobytes() if rc == 0 else b"", sr
+
+    def encode_stream_blocks(self, pb: "host.PackedBatch"):
+        """The general-form coder over ordinary blocks (fallback for blocks of more than CBC_MAX_BLOCK_READS records)."""
+        hb, keep = self._host_batch(pb)
+        nb = pb.n_blocks
+        cap = int(4096 * nb + 48 * pb.n_recs + 8 * pb.n_tok)
+        out = np.zeros(cap, dtype=np.uint8)
+        offs = np.zeros(nb + 1, dtype=np.uint64)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        rc = lib().cbc_gpu_encode_stream_blocks(self._ctx, ctypes.byref(hb), out.ctypes.data, cap, offs.ctypes.data, res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_encode_stream_blocks")
+        return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res
+
+    def decode_stream(self, stream: bytes, contigs, rec_cap=None):
+        """Decode a whole-file stream against the uploaded reference; contigs = the packer's contig table
+        (ref_off / length in FASTA order).  Retries with larger buffers while the kernel reports OUT_FULL."""
+        L0 = int(lib().cbc_stream_read_length(stream, len(stream)))
+        stride = (max(L0, 4) + 3) // 4 * 4
+        stride = min(256, max(stride, 256 if L0 > 252 else stride))
+        buf = np.frombuffer(stream, dtype=np.uint8)
+        co = np.ascontiguousarray(contigs["ref_off"], dtype=np.uint64)
+        cl = np.ascontiguousarray(contigs["length"], dtype=np.uint64)
+        cap = int(rec_cap) if rec_cap else max(1 << 16, 2 * len(stream))
+        while True:
+            recs = np.zeros(cap, dtype=host.REC_DTYPE)
+            seq = np.zeros(cap * 256 + 8, dtype=np.uint8)
+            sr = StreamResult()
+            rc = lib().cbc_gpu_decode_stream(self._ctx, buf.ctypes.data, buf.size, co.ctypes.data, cl.ctypes.data, len(co),
+                                             recs.ctypes.data, cap, seq.ctypes.data, seq.size, 256, ctypes.byref(sr))
+            if rc == -4 and sr.status == 1 and cap < (1 << 31):      # OUT_FULL: more records than the buffers hold
+                cap *= 4
+                continue
+            if rc != 0 and rc != -4:
+                self._check(rc, "cbc_gpu_decode_stream")
+            n = int(sr.nbytes) if sr.status == 0 else 0
+            return recs[:n], seq[:n * 256].reshape(n, 256), sr
 
     def decode_device(self, db: DecDeviceBatch, stream=None):
         self._check(lib().cbc_gpu_decode_blocks_device(self._ctx, ctypes.byref(db), stream), "cbc_gpu_decode_blocks_device")

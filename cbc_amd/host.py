@@ -64,7 +64,7 @@ class Packed(ctypes.Structure):
         ("read_length", ctypes.c_uint32),
         ("n_bases", ctypes.c_uint64),
         ("n_skipped_unmapped", ctypes.c_uint64),
-        ("max_read_len", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("max_read_len", ctypes.c_uint32), ("whole_file", ctypes.c_uint32),
         ("cap_recs", ctypes.c_uint64), ("cap_seq", ctypes.c_uint64), ("cap_tok", ctypes.c_uint64),
         ("cap_ref", ctypes.c_uint64), ("cap_names", ctypes.c_uint32), ("cap_blocks", ctypes.c_uint32),
         ("cap_contigs", ctypes.c_uint32),

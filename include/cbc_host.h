@@ -103,6 +103,16 @@ int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets);
 int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
                             uint8_t *dst, uint64_t dst_cap);
 
+/* ---- the reference alone (whole-file stream decode: the stream names contigs only by "next one") ----
+ * FASTA text -> upper-cased contig bases, each + CBC_REF_PAD zero bytes, and the contig table in file order
+ * (store_reference_in_memory, src/read_decompression.c:17-53).  Free with cbc_reference_free. */
+typedef struct cbc_reference {
+    uint8_t *bases; uint64_t n_bytes;
+    uint64_t *contig_off, *contig_len; uint32_t n_contigs;
+} cbc_reference;
+int  cbc_reference_load(const char *fasta, size_t fasta_len, uint32_t n_threads, cbc_reference **out, char *errbuf, size_t errlen);
+void cbc_reference_free(cbc_reference *r);
+
 /* ---- unpack side: container + FASTA -> decode launch plan -> text ------------------------- */
 typedef struct cbc_unpack_plan {
     cbc_dec_block_desc *blocks;   uint32_t n_blocks;

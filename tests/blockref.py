@@ -196,3 +196,34 @@ def emu_encode_stream(pb, per_segment=False):
         o = int(segs[s]["out_off"])
         payloads.append(out[o:o + int(res[s]["nbytes"])].tobytes())
     return payloads, res
+
+
+class DStreamArgs(ctypes.Structure):
+    """cbc_dstream_args of cbc_amd/csrc/cbc_stream_body.h."""
+    _fields_ = [("in_", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("contig_off", ctypes.c_void_p), ("contig_len", ctypes.c_void_p),
+                ("recs", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("results", ctypes.c_void_p), ("vtab", ctypes.c_void_p),
+                ("in_bytes", ctypes.c_uint64), ("ref_bytes", ctypes.c_uint64), ("rec_cap", ctypes.c_uint64), ("seq_bytes", ctypes.c_uint64),
+                ("n_contigs", ctypes.c_uint32), ("cap_pos", ctypes.c_uint32), ("cap_name", ctypes.c_uint32),
+                ("seq_stride", ctypes.c_uint32), ("read_length", ctypes.c_uint32)]
+
+
+def emu_decode_stream(stream: bytes, ref, contigs, rec_cap, cap_pos=8192, cap_name=2048):
+    """The whole-file stream decoder body on the CPU wave emulation.  ref/contigs: the packer's reference layout
+    (pb.ref, pb.contigs).  Returns (recs, bases[n, stride], result)."""
+    L = emu_lib()
+    L.emu_decode_stream.restype = ctypes.c_int
+    L.emu_decode_stream.argtypes = [ctypes.POINTER(DStreamArgs)]
+    L0 = int.from_bytes(stream[:4], "big")
+    stride = 256
+    pay = np.concatenate([np.frombuffer(stream, dtype=np.uint8), np.zeros(16, dtype=np.uint8)])
+    co = np.ascontiguousarray(contigs["ref_off"], dtype=np.uint64); cl = np.ascontiguousarray(contigs["length"], dtype=np.uint64)
+    recs = np.zeros(rec_cap, dtype=host.REC_DTYPE)
+    seq = np.zeros(rec_cap * stride + 16, dtype=np.uint8)
+    res = np.zeros(1, dtype=host.RESULT_DTYPE)
+    vtab = np.zeros(65535 * 256, dtype=np.uint32)
+    a = DStreamArgs(pay.ctypes.data, ref.ctypes.data, co.ctypes.data, cl.ctypes.data, recs.ctypes.data, seq.ctypes.data,
+                    res.ctypes.data, vtab.ctypes.data, len(stream), len(ref), rec_cap, seq.size, len(co), cap_pos, cap_name, stride, L0)
+    if L.emu_decode_stream(ctypes.byref(a)) != 0:
+        raise RuntimeError("emulation reported an invariant violation")
+    n = int(res[0]["nbytes"])
+    return recs[:n], seq[:n * stride].reshape(n, stride), res[0]

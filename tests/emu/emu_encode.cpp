@@ -75,3 +75,13 @@ int emu_encode_stream(const cbc_stream_args *A)
     }
     return g_emu_errors ? -100 : 0;
 }
+
+extern "C" __attribute__((visibility("default")))
+int emu_decode_stream(const cbc_dstream_args *A)
+{
+    g_emu_errors = 0;
+    cbc_stream_caps caps = { A->cap_pos, A->cap_name };
+    std::vector<uint32_t> lds(cbc_stream_lds_bytes(&caps) / 4, 0xdeadbeefu);
+    cbc_decode_whole<WaveEmu>(*A, lds.data());
+    return g_emu_errors ? -100 : 0;
+}

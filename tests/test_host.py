@@ -36,7 +36,7 @@ def _one(fields, fa_seq="ACGT" * 100):
 
 def test_gpu_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(ROOT, "include", "cbc_gpu.h")).read()
-    declared = sorted(set(re.findall(r"\b(cbc_gpu_\w+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(cbc_(?:gpu|stream)_\w+)\s*\(", hdr)))
     assert len(declared) >= 12
     assert sorted(gpu.EXPORTS) == declared
     L = ctypes.CDLL(gpu.GPU_LIB)                         # loads without a GPU; no compute call made
