@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "../../include/cbc_host.h"
 
 static char *slurp2(const char *path, size_t *len)
@@ -59,8 +60,43 @@ static int decompress_stream(const uint8_t *blob, size_t blob_len, const char *f
     return 0;
 }
 
-int cbc_cli_decompress(const char *in, const char *out, const char *ref, int device)
+/* one device's share of the blocks: a contiguous range, decoded into its slice of the output arrays */
+typedef struct { const cbc_unpack_plan *u; int device; uint32_t b0, b1; cbc_read_rec *recs; uint8_t *seq; int rc; char err[512]; } dec_job;
+
+static void *dev_decode(void *arg)
 {
+    dec_job *J = (dec_job *)arg;
+    const cbc_unpack_plan *u = J->u;
+    if (J->b1 <= J->b0) return NULL;
+    cbc_gpu_ctx *ctx = NULL;
+    J->rc = cbc_gpu_init(J->device, &ctx);
+    if (J->rc) { snprintf(J->err, sizeof J->err, "no usable MI355X at ordinal %d (cbc_gpu_init = %d)", J->device, J->rc); return NULL; }
+    J->rc = cbc_gpu_upload_reference(ctx, u->ref, u->ref_bytes);
+    if (!J->rc) {
+        const uint32_t nb = J->b1 - J->b0;
+        cbc_dec_block_desc *bl = (cbc_dec_block_desc *)malloc((size_t)nb * sizeof(cbc_dec_block_desc));
+        if (!bl) J->rc = CBC_E_NOMEM;
+        else {
+            memcpy(bl, u->blocks + J->b0, (size_t)nb * sizeof(cbc_dec_block_desc));
+            const uint64_t in0 = bl[0].in_off, r0 = bl[0].rec_base;
+            uint64_t in1 = 0, nrec = 0;
+            for (uint32_t k = 0; k < nb; k++) {
+                if (bl[k].in_off + bl[k].in_bytes > in1) in1 = bl[k].in_off + bl[k].in_bytes;
+                bl[k].in_off -= in0; bl[k].rec_base -= r0; bl[k].seq_base = bl[k].rec_base * u->seq_stride; nrec += bl[k].n_reads;
+            }
+            J->rc = cbc_gpu_decode_blocks(ctx, u->payloads + in0, in1 - in0, bl, nb, &u->caps, J->recs + r0, nrec,
+                                          J->seq + r0 * u->seq_stride, nrec * u->seq_stride + 8, NULL);
+            free(bl);
+        }
+    }
+    if (J->rc) snprintf(J->err, sizeof J->err, "%s", cbc_gpu_last_error(ctx));
+    cbc_gpu_shutdown(ctx);
+    return NULL;
+}
+
+int cbc_cli_decompress(const char *in, const char *out, const char *ref, const int *devs, int ndev)
+{
+    const int device = devs[0];
     size_t blob_len = 0, fa_len = 0;
     char *blob = slurp2(in, &blob_len), *fa = slurp2(ref, &fa_len);
     if (!blob || !fa) return 1;
@@ -83,8 +119,25 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, int dev
     uint8_t *seq = (uint8_t *)calloc((size_t)seq_bytes, 1);
     char *text = (char *)malloc((size_t)(u->n_recs * (u->seq_stride + 1) + 16));
     if (!recs || !seq || !text) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
+    if (ndev > 1) {
+        /* contiguous block ranges balanced by record count, one host thread and one context per device */
+        dec_job jobs[16]; pthread_t th[16];
+        if (ndev > 16) ndev = 16;
+        uint32_t b = 0; uint64_t done = 0;
+        for (int d = 0; d < ndev; d++) {
+            memset(&jobs[d], 0, sizeof jobs[d]);
+            jobs[d].u = u; jobs[d].device = devs[d]; jobs[d].recs = recs; jobs[d].seq = seq; jobs[d].b0 = b;
+            uint64_t target = u->n_recs * (uint64_t)(d + 1) / (uint64_t)ndev;
+            while (b < u->n_blocks && (done < target || d == ndev - 1)) { done += u->blocks[b].n_reads; b++; }
+            jobs[d].b1 = b;
+            if (pthread_create(&th[d], NULL, dev_decode, &jobs[d]) != 0) { fprintf(stderr, "cbc: cannot start a device thread\n"); return 1; }
+        }
+        for (int d = 0; d < ndev; d++) { pthread_join(th[d], NULL); if (jobs[d].rc) { fprintf(stderr, "cbc: device %d: decode failed: %s\n", devs[d], jobs[d].err); rc = 1; } }
+        if (rc) return 1;
+    } else {
     rc = cbc_gpu_decode_blocks(ctx, u->payloads, u->payload_bytes, u->blocks, u->n_blocks, &u->caps, recs, u->n_recs, seq, seq_bytes, NULL);
     if (rc) { fprintf(stderr, "cbc: decode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
+    }
     int64_t n = cbc_unpack_write_text(u, recs, seq, text, u->n_recs * (u->seq_stride + 1) + 16);
     if (n < 0) { fprintf(stderr, "cbc: text assembly failed\n"); return 1; }
     FILE *fo = fopen(out, "wb");

@@ -81,7 +81,7 @@ struct CbcDec {
     uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, nev1, cap_var, L0;
     uint32_t prevPos, prevM, prevChar;
     uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
-    uint32_t vtag0, vtag1, vsum0, vsum1;
+    uint32_t np0, np1, p0over;
     uint64_t w0, w1, w2, w3;
 
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
@@ -514,45 +514,27 @@ struct CbcDec {
     {
         if (ctx >= CBC_NVARCTX) { fail(CBC_ST_ASSERT); return 0u; }
         if (GEN) return var_dec_dense(ctx);
-        {   /* hot contexts: dense table, same claim rule as CbcEnc::var_code */
-            const uint32_t slot = ctx & 1u;
-            uint32_t tag = slot ? vtag1 : vtag0;
-            if (tag == CBC_NOMEMO) { tag = ctx; if (slot) vtag1 = ctx; else vtag0 = ctx; }
-            if (tag == ctx) {
-                uint32_t *exc = tab(CBC_LDS_VSLOT) + 256u * slot;
-                uint32_t sum = slot ? vsum1 : vsum0, n = L0 + sum;
-                if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_CAP_VAR); return 0u; }
-                uint32_t tg = target(n), lo, cnt;
-                uint32_t x = dense_search(exc, L0, 1u, tg, lo, cnt);
-                if (status != CBC_ST_OK) return 0u;
-                step(lo, cnt, n);
-                W::write_uni(exc, x, cnt - 1u + 10u);
-                if (slot) vsum1 = sum + 10u; else vsum0 = sum + 10u;
-                return x;
-            }
-        }
+        /* the two context classes of CbcEnc::var_code: "p = 0" contexts (ctx = d << 8 | strand) keep their 16-bit
+         * events in an LDS array per strand, the others sit behind the Bloom filter in the global list; every
+         * event of the context adds 10 to its symbol's excess (4 symbols per lane), then one search */
         V32 ln = W::lane();
         uint32_t *bloom = tab(CBC_LDS_BLOOM), *ev = var_ev_p();
-        /* the encoder's filter: two hash functions, both words fetched by one LDS instruction */
-        const uint32_t h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2), h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
-        const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
-        const uint32_t bw1 = W::readlane(bwv, 0u), bw2 = W::readlane(bwv, 1u);
-        const uint32_t bb1 = 1u << (h1 & 31u), bb2 = 1u << (h2 & 31u);
-        /* per-symbol excess of this context, 4 symbols per lane, built from the event list */
+        const uint32_t strand1 = ctx & 1u;
+        const bool p0class = ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u;   /* 255 is the unused-half marker */
+        bool to_global = !p0class;
         V32 e0 = W::splat(0u), e1 = W::splat(0u), e2 = W::splat(0u), e3 = W::splat(0u);
         uint32_t m = 0;
-        if ((bw1 & bb1) && (bw2 & bb2)) {
-            W::list_fence();
-            /* two lists by the context's strand bit, one from each end of the area (cf. CbcEnc::var_code) */
-            const uint32_t strand1 = ctx & 1u;
-            const uint32_t cnt_s = strand1 ? nev1 : nev, base_s = strand1 ? cap_var - nev1 : 0u;
-            const uint32_t nb = W::uni(cnt_s);
-            for (uint32_t b = 0; b < nb; b += 512u) {             /* eight coalesced loads in flight per trip */
-                V32 ev4[8];
-                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev4[q] = W::load32_list(ev, i + base_s, i < cnt_s, 0xffffffffu); }
-                for (uint32_t q = 0; q < 8u; q++) {
-                    const V32 e = ev4[q];
-                    uint64_t bb = W::ballot((e >> 8) == ctx);     /* lanes past nev hold 0xffffffff: ctx 0xffffff never matches */
+        if (p0class) {
+            const uint32_t d = ctx >> 8;
+            const uint32_t *arr = tab(CBC_LDS_P0) + strand1 * CBC_P0_WORDS;
+            const uint32_t have = strand1 ? np1 : np0, nw = (have + 1u) >> 1;
+            const uint32_t nwb = W::uni(nw);
+            for (uint32_t b = 0; b < nwb; b += 64u) {
+                const V32 i = ln + b;
+                const V32 w = W::load32(arr, i, i < nw, 0xffffffffu);
+                for (uint32_t half = 0; half < 2u; half++) {
+                    const V32 e = half ? (w >> 16) : (w & 0xffffu);
+                    uint64_t bb = W::ballot((e >> 8) == d);
                     while (bb) {
                         uint32_t src = W::ctz64(bb); bb &= bb - 1u;
                         uint32_t kk = W::readlane(e, src) & 0xffu;
@@ -566,9 +548,40 @@ struct CbcDec {
                     }
                 }
             }
-        } else {
-            if ((h1 >> 5) == (h2 >> 5)) W::write_uni(bloom, h1 >> 5, bw1 | bb1 | bb2);
-            else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
+            if (have >= CBC_P0_CAP) to_global = true;
+        }
+        uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
+        if (to_global || ((p0over >> strand1) & 1u)) {
+            /* the encoder's filter: two hash functions, both words fetched by one LDS instruction */
+            h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
+            const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
+            bw1 = W::readlane(bwv, 0u); bw2 = W::readlane(bwv, 1u);
+            bb1 = 1u << (h1 & 31u); bb2 = 1u << (h2 & 31u);
+            if ((bw1 & bb1) && (bw2 & bb2)) {
+                W::list_fence();
+                /* two lists by the context's strand bit, one from each end of the area (cf. CbcEnc::var_code) */
+                const uint32_t cnt_s = strand1 ? nev1 : nev, base_s = strand1 ? cap_var - nev1 : 0u;
+                const uint32_t nb = W::uni(cnt_s);
+                for (uint32_t b = 0; b < nb; b += 512u) {             /* eight coalesced loads in flight per trip */
+                    V32 ev4[8];
+                    for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev4[q] = W::load32_list(ev, i + base_s, i < cnt_s, 0xffffffffu); }
+                    for (uint32_t q = 0; q < 8u; q++) {
+                        const V32 e = ev4[q];
+                        uint64_t bb = W::ballot((e >> 8) == ctx);     /* lanes past nev hold 0xffffffff: ctx 0xffffff never matches */
+                        while (bb) {
+                            uint32_t src = W::ctz64(bb); bb &= bb - 1u;
+                            uint32_t kk = W::readlane(e, src) & 0xffu;
+                            Mask hitl = ln == (kk >> 2);
+                            uint32_t sub = kk & 3u;
+                            e0 = W::select(hitl & (sub == 0u), e0 + 10u, e0);
+                            e1 = W::select(hitl & (sub == 1u), e1 + 10u, e1);
+                            e2 = W::select(hitl & (sub == 2u), e2 + 10u, e2);
+                            e3 = W::select(hitl & (sub == 3u), e3 + 10u, e3);
+                            m++;
+                        }
+                    }
+                }
+            }
         }
         uint32_t n = L0 + 10u * m;
         uint32_t tg = target(n), x, lo, cnt;
@@ -577,8 +590,21 @@ struct CbcDec {
         if (status != CBC_ST_OK) return 0u;
         if (x >= L0) { fail(CBC_ST_ASSERT); return 0u; }
         step(lo, cnt, n);
+        if (!to_global) {
+            uint32_t *arr = tab(CBC_LDS_P0) + strand1 * CBC_P0_WORDS;
+            const uint32_t have = strand1 ? np1 : np0, k16 = ((ctx >> 8) << 8) | x;
+            if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
+            else W::write_uni(arr, have >> 1, 0xffff0000u | k16);
+            if (strand1) np1 = have + 1u; else np0 = have + 1u;
+            return x;
+        }
         if (nev + nev1 >= cap_var) { fail(CBC_ST_CAP_VAR); return 0u; }
-        if (ctx & 1u) { nev1++; W::append_list(ev, cap_var - nev1, (ctx << 8) | x); }
+        if (p0class) p0over |= 1u << strand1;
+        if (!((bw1 & bb1) && (bw2 & bb2))) {
+            if ((h1 >> 5) == (h2 >> 5)) W::write_uni(bloom, h1 >> 5, bw1 | bb1 | bb2);
+            else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
+        }
+        if (strand1) { nev1++; W::append_list(ev, cap_var - nev1, (ctx << 8) | x); }
         else { W::append_list(ev, nev, (ctx << 8) | x); nev++; }
         return x;
     }
@@ -779,7 +805,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     }
     D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
     D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
-    D.vtag0 = D.vtag1 = CBC_NOMEMO; D.vsum0 = D.vsum1 = 0;
+    D.np0 = D.np1 = 0; D.p0over = 0;
 
     /* the tag: first 26 bits (alloc_arithmetic_stream, Arithmetic_stream.c:260-263) */
     if (D.status == CBC_ST_OK) D.t = D.take(26u);

@@ -43,7 +43,7 @@
 #define CBC_RESCALE   (1u << 20)
 #define CBC_NVARCTX   0xffffu
 #define CBC_NOMEMO    0xffffffffu
-#define CBC_BLOOM_LOG2 14u       /* log2(32 * CBC_BLOOM_WORDS) */
+#define CBC_BLOOM_LOG2 13u       /* log2(32 * CBC_BLOOM_WORDS) */
 #define CBC_ROLE_FUSED 0u      /* one wavefront does models and coder (CPU emulation)        */
 #define CBC_ROLE_MODEL 1u      /* wavefront 0 of the workgroup: models, produces symbol batches */
 #define CBC_ROLE_CODER 2u      /* wavefront 1: range coder, consumes them                        */
@@ -60,7 +60,7 @@
 #define CBC_LDS_RNKEY   768u                       /* CBC_CAP_NAME: (ctx<<8)|char       */
 #define CBC_LDS_RNEXC   (768u + CBC_CAP_NAME)      /* CBC_CAP_NAME                      */
 #define CBC_LDS_BLOOM   (768u + 2u * CBC_CAP_NAME) /* CBC_BLOOM_WORDS: Bloom filter on var ctx (two hashes) */
-#define CBC_LDS_VSLOT   (768u + 2u * CBC_CAP_NAME + CBC_BLOOM_WORDS) /* 2 x 256: dense excess of the two hot var contexts */
+#define CBC_LDS_P0      (768u + 2u * CBC_CAP_NAME + CBC_BLOOM_WORDS) /* 2 x CBC_P0_WORDS: var events of the p = 0 contexts, per strand */
 #define CBC_LDS_BATCH   CBC_PLAN_TABLE_WORDS       /* CBC_BATCH_SLOTS x CBC_BATCH_WORDS: model wave -> coder wave */
 #ifndef CBC_BATCH_MIN
 #define CBC_BATCH_MIN   40u    /* <= 64 - 12 (a record's fixed symbols) - 4 (edit counts) - slack: see the 56 checks */
@@ -157,13 +157,13 @@ struct CbcEnc {
     V32 small;                              /* match / same_ref / chars lane table            */
     V32 fkey, fexc; uint32_t fcount;        /* flag: sparse, one entry per lane                */
     V32 hkey, hexc; uint32_t hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;   /* codebook ctx 0..3: sparse, 8 lanes each */
-    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_occ, *pos_pre, *var_ev, *bloom;
+    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_occ, *pos_pre, *var_ev, *bloom, *p0ev;
     uint32_t snps_n, indels_n;
     uint32_t rn_count, rn_cap;               /* contig-name pairs in use / capacity (CBC_CAP_NAME in the block kernels) */
     uint32_t *vtab;                          /* GEN: var excess table in global memory, row = context, L0 words per row */
     uint32_t pos_card, cap_pos;              /* pos alphabet: value / occurrences / prefix by index, in LDS */
     uint32_t nev, nev1, cap_var;             /* var events of strand 0 (from the bottom of the area) / strand 1 (from the top) */
-    uint32_t vtag0, vtag1, vsum0, vsum1;     /* hot var contexts: tag (context) and total excess  */
+    uint32_t np0, np1, p0over;               /* p = 0 contexts: events held in LDS per strand; bit s of p0over = strand s spilled to the global list */
     uint32_t L0;
 
     /* ---- cross-read state (T7/T8 of SURVEY.md) ---- */
@@ -850,60 +850,85 @@ struct CbcEnc {
     {
         if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
         if (GEN) { var_code_dense(ctx, sym); return; }
-        /* Hot contexts.  The first SNP of a read with no known SNP ahead always has the same context
-         * (delta = L+2, prev = 0) per strand, so a block codes hundreds of symbols in it.  The first
-         * context seen on each strand claims a dense 256-entry excess table in LDS (exactly the
-         * snps/indels representation); only the other contexts go through the event list. */
-        {
-            const uint32_t slot = ctx & 1u;
-            uint32_t tag = slot ? vtag1 : vtag0;
-            if (tag == CBC_NOMEMO) { tag = ctx; if (slot) vtag1 = ctx; else vtag0 = ctx; }
-            if (tag == ctx) {
-                uint32_t *exc = bloom + CBC_BLOOM_WORDS + 256u * slot;   /* CBC_LDS_VSLOT follows the Bloom filter */
-                uint32_t lo, cnt, sum = slot ? vsum1 : vsum0;
-                dense_lookup(exc, sym, lo, cnt);
-                encode(lo, cnt, L0 + sum);
-                W::write_uni(exc, sym, cnt - 1u + 10u);
-                if (slot) vsum1 = sum + 10u; else vsum0 = sum + 10u;
-                if (L0 + sum + 10u >= CBC_RESCALE) fail(CBC_ST_CAP_VAR);     /* unreachable within cap_var */
-                return;
-            }
-        }
+        /* Two classes of contexts (the class is a function of the context number alone):
+         *  - "p = 0": (ctx >> 1) & 127 == 0 and ctx >> 8 < 255, i.e. ctx = d << 8 | strand -- the FIRST edit of a read, with the
+         *    distance d to the first known SNP ahead.  With a few percent of the reference positions marked by
+         *    earlier reads these are the contexts that repeat (a few hundred of them, each used several times per
+         *    block), and they carry most of a block's var symbols.  Their events are 16 bits (d << 8 | symbol)
+         *    in an LDS array per strand; a lookup is a scan of that array (128 events per LDS load, the three
+         *    tallies in one register, one wave sum) and never leaves the CU.
+         *  - all other contexts are mostly seen once per block: Bloom filter on the context, and only on a
+         *    filter hit a scan of the strand's event list in global memory.
+         * A strand whose LDS array is full spills its further p = 0 events to the global list (p0over). */
         V32 ln = W::lane();
-        uint32_t cn = 0, clo = 0, ceq = 0, key = (ctx << 8) | sym;
-        /* two hash functions, both words fetched by one LDS instruction (lanes 0 and 1) */
-        const uint32_t h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2), h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
-        const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
-        const uint32_t bw1 = W::readlane(bwv, 0u), bw2 = W::readlane(bwv, 1u);
-        const uint32_t bb1 = 1u << (h1 & 31u), bb2 = 1u << (h2 & 31u);
-        if ((bw1 & bb1) && (bw2 & bb2)) {
-            W::list_fence();
-            /* the context's strand bit picks the list: strand 0 grows up from the bottom of the event area,
-             * strand 1 down from its top, so a scan reads half of the block's events and the two share the
-             * capacity */
-            const uint32_t strand1 = ctx & 1u;
-            const uint32_t cnt_s = strand1 ? nev1 : nev, base_s = strand1 ? cap_var - nev1 : 0u;
-            const uint32_t nb = W::uni(cnt_s);
-            for (uint32_t b = 0; b < nb; b += 512u) {           /* eight coalesced loads in flight per trip */
-                V32 ev[8];
-                for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev[q] = W::load32_list(var_ev, i + base_s, i < cnt_s, 0xffffffffu); }
-                for (uint32_t q = 0; q < 8u; q++) {
-                    const V32 e = ev[q];
-                    const uint64_t bc = W::ballot((e >> 8) == ctx);    /* lanes past nev hold 0xffffffff: never a context */
-                    if (bc) {
-                        cn += W::popc64(bc);
-                        clo += W::popc64(W::ballot(((e >> 8) == ctx) & ((e & 0xffu) < sym)));
-                        ceq += W::popc64(W::ballot(e == key));
+        uint32_t cn = 0, clo = 0, ceq = 0;
+        const uint32_t key = (ctx << 8) | sym, strand1 = ctx & 1u;
+        const bool p0class = ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u;   /* 255 is the unused-half marker */
+        bool to_global = !p0class;
+        if (p0class) {
+            const uint32_t d = ctx >> 8, key16 = (d << 8) | sym;
+            const uint32_t *arr = p0ev + strand1 * CBC_P0_WORDS;
+            const uint32_t have = strand1 ? np1 : np0, nw = (have + 1u) >> 1;
+            V32 acc = W::splat(0u);
+            const uint32_t nwb = W::uni(nw);
+            for (uint32_t b = 0; b < nwb; b += 64u) {            /* an unused upper half holds 0xffff: d = 255 never occurs */
+                const V32 i = ln + b;
+                const V32 w = W::load32(arr, i, i < nw, 0xffffffffu);
+                const V32 e0 = w & 0xffffu, e1 = w >> 16;
+                acc = acc + W::select((e0 >> 8) == d, W::select((e0 & 0xffu) < sym, W::splat(1u + (1u << 10)), W::splat(1u)) +
+                                                       W::select(e0 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u));
+                acc = acc + W::select((e1 >> 8) == d, W::select((e1 & 0xffu) < sym, W::splat(1u + (1u << 10)), W::splat(1u)) +
+                                                       W::select(e1 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u));
+            }
+            const uint32_t tot = W::reduce_add(acc);
+            cn = tot & 1023u; clo = (tot >> 10) & 1023u; ceq = tot >> 20;
+            if (have >= CBC_P0_CAP) to_global = true;
+        }
+        uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
+        if (to_global || ((p0over >> strand1) & 1u)) {
+            /* two hash functions, both words fetched by one LDS instruction (lanes 0 and 1) */
+            h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
+            const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
+            bw1 = W::readlane(bwv, 0u); bw2 = W::readlane(bwv, 1u);
+            bb1 = 1u << (h1 & 31u); bb2 = 1u << (h2 & 31u);
+            if ((bw1 & bb1) && (bw2 & bb2)) {
+                W::list_fence();
+                /* the context's strand bit picks the list: strand 0 grows up from the bottom of the event area,
+                 * strand 1 down from its top, so a scan reads half of the block's events and the two share the
+                 * capacity */
+                const uint32_t cnt_s = strand1 ? nev1 : nev, base_s = strand1 ? cap_var - nev1 : 0u;
+                const uint32_t nb = W::uni(cnt_s);
+                for (uint32_t b = 0; b < nb; b += 512u) {           /* eight coalesced loads in flight per trip */
+                    V32 ev[8];
+                    for (uint32_t q = 0; q < 8u; q++) { V32 i = ln + (b + 64u * q); ev[q] = W::load32_list(var_ev, i + base_s, i < cnt_s, 0xffffffffu); }
+                    for (uint32_t q = 0; q < 8u; q++) {
+                        const V32 e = ev[q];
+                        const uint64_t bc = W::ballot((e >> 8) == ctx);    /* lanes past nev hold 0xffffffff: never a context */
+                        if (bc) {
+                            cn += W::popc64(bc);
+                            clo += W::popc64(W::ballot(((e >> 8) == ctx) & ((e & 0xffu) < sym)));
+                            ceq += W::popc64(W::ballot(e == key));
+                        }
                     }
                 }
             }
-        } else {
+        }
+        encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
+        if (!to_global) {                                        /* p = 0 context with room in its LDS array */
+            uint32_t *arr = p0ev + strand1 * CBC_P0_WORDS;
+            const uint32_t have = strand1 ? np1 : np0, k16 = ((ctx >> 8) << 8) | sym;
+            if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
+            else W::write_uni(arr, have >> 1, 0xffff0000u | k16);
+            if (strand1) np1 = have + 1u; else np0 = have + 1u;
+            return;
+        }
+        if (nev + nev1 >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
+        if (p0class) p0over |= 1u << strand1;
+        if (!((bw1 & bb1) && (bw2 & bb2))) {
             if ((h1 >> 5) == (h2 >> 5)) W::write_uni(bloom, h1 >> 5, bw1 | bb1 | bb2);
             else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
         }
-        encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
-        if (nev + nev1 >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
-        if (ctx & 1u) { nev1++; W::append_list(var_ev, cap_var - nev1, key); }
+        if (strand1) { nev1++; W::append_list(var_ev, cap_var - nev1, key); }
         else { W::append_list(var_ev, nev, key); nev++; }
     }
 
@@ -1119,7 +1144,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.L0 = L0;
     E.rlen_exc = lds + CBC_LDS_RLEN; E.snps_exc = lds + CBC_LDS_SNPS; E.indels_exc = lds + CBC_LDS_INDELS;
     E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
-    E.bloom = lds + CBC_LDS_BLOOM;
+    E.bloom = lds + CBC_LDS_BLOOM; E.p0ev = lds + CBC_LDS_P0;
     E.pos_val = lds + CBC_LDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = E.pos_occ + A.cap_pos;
     E.cap_pos = A.cap_pos;
     if (ROLE != CBC_ROLE_MODEL) {
@@ -1129,9 +1154,9 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     }
     if (ROLE != CBC_ROLE_CODER) {
         for (uint32_t b = 0; b < 512u; b += 64u) W::store32(E.snps_exc, ln + b, W::splat(0u), W::all());   /* snps + indels */
-        for (uint32_t b = 0; b < CBC_BLOOM_WORDS + 512u; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* Bloom + 2 slots */
+        for (uint32_t b = 0; b < CBC_BLOOM_WORDS; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* the p = 0 arrays need no clearing */
     }
-    E.vtag0 = E.vtag1 = CBC_NOMEMO; E.vsum0 = E.vsum1 = 0;
+    E.np0 = E.np1 = 0; E.p0over = 0;
     E.snps_n = L0; E.indels_n = L0;
     E.rn_count = 0; E.rn_cap = CBC_CAP_NAME; E.vtab = nullptr;
     E.pos_card = 1u;                                         /* initialize_stream_model_pos :132-162: the escape */

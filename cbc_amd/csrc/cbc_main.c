@@ -13,7 +13,9 @@
  * --threads N, --verbose, and --compat: write the reference's OWN file format (one arithmetic stream for the whole
  * file, compress() src/compression.c:112-170) instead of the block container -- byte-identical to what
  * `program -c 1` (-DDEBUG build) writes and readable by its `-x`; one wavefront codes it, so it is slow.
- * `cbc -d` recognises either format.
+ * `cbc -d` recognises either format.  --devices 0,1,...: one context and one host thread per listed device; whole
+ * contigs are dealt to them largest first (encode) / contiguous block ranges (decode); the output does not depend
+ * on the device count.
  * Exit status: 0 on success (the reference returns 1 on success, src/main.c:370 -- not reproduced).
  *
  * There is no CPU encoder or decoder in this program: without an MI355X it exits with an error.
@@ -27,6 +29,7 @@
 #include <unistd.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <pthread.h>
 #include "../../include/cbc_host.h"
 
 static void usage(const char *p)
@@ -36,7 +39,8 @@ static void usage(const char *p)
             "       %s -d|-x <in.cbc> <out.txt> <ref.fa>    reconstruct the reads, one per line\n"
             "options: -l (header read length = longest read)  --block-reads N (default 4096)  --device N (default 0)\n"
             "         --threads N (SAM parser threads, default one per CPU)  --verbose (stage times)\n"
-            "         --compat (write the reference's own single-stream format; slow: one stream = one wavefront)\n", p, p);
+            "         --compat (write the reference's own single-stream format; slow: one stream = one wavefront)\n"
+            "         --devices 0,1,... (shard the contigs / block ranges over several MI355X, one host thread each)\n", p, p);
 }
 
 /* Input files are mapped, not copied: the packer only ever reads [0, len). */
@@ -66,7 +70,118 @@ static int is_number(const char *s)
     return e && *e == 0;
 }
 
-static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose, int compat)
+/* ---- several devices: whole contigs are dealt to the devices (cbc_assign_contigs), one
+ * host thread and one context per device, no data exchanged between them; the container is assembled on the host in
+ * global block order, so it is byte-identical to the one-device container. ---- */
+#define CBC_MAX_DEVICES 16
+typedef struct {
+    const cbc_packed *p; int device; uint32_t part; const uint32_t *part_of_contig;
+    uint8_t **blk_payload; uint32_t *blk_bytes;        /* per block, filled by the owning thread (malloc'ed runs) */
+    uint8_t **runs; uint32_t n_runs;
+    int rc; char err[512]; double seconds; float kernel_ms; uint64_t n_reads;
+} dev_job;
+
+static void *dev_encode(void *arg)
+{
+    dev_job *J = (dev_job *)arg;
+    const cbc_packed *p = J->p;
+    double t0 = now_s();
+    cbc_gpu_ctx *ctx = NULL;
+    J->rc = cbc_gpu_init(J->device, &ctx);
+    if (J->rc) { snprintf(J->err, sizeof J->err, "no usable MI355X at ordinal %d (cbc_gpu_init = %d)", J->device, J->rc); return NULL; }
+    J->rc = cbc_gpu_upload_reference(ctx, p->ref, p->ref_bytes);
+    if (J->rc) { snprintf(J->err, sizeof J->err, "%s", cbc_gpu_last_error(ctx)); cbc_gpu_shutdown(ctx); return NULL; }
+    J->runs = (uint8_t **)calloc((size_t)p->n_blocks + 1, sizeof(uint8_t *));
+    for (uint32_t b0 = 0; b0 < p->n_blocks && !J->rc; ) {
+        if (J->part_of_contig[p->info[b0].contig] != J->part) { b0++; continue; }
+        uint32_t b1 = b0;                                    /* a maximal run of consecutive blocks of this part */
+        while (b1 < p->n_blocks && J->part_of_contig[p->info[b1].contig] == J->part) b1++;
+        const uint32_t nb = b1 - b0;
+        cbc_block_desc *bl = (cbc_block_desc *)malloc((size_t)nb * sizeof(cbc_block_desc));
+        uint64_t *offs = (uint64_t *)calloc((size_t)nb + 1, sizeof(uint64_t));
+        if (!bl || !offs) { J->rc = CBC_E_NOMEM; free(bl); free(offs); break; }
+        memcpy(bl, p->blocks + b0, (size_t)nb * sizeof(cbc_block_desc));
+        /* the run's records, bases and tokens are contiguous: hand over just that slice, bases rebased */
+        const uint64_t r0 = bl[0].rec_base, s0 = bl[0].seq_base, t0k = bl[0].tok_base;
+        const uint64_t r1 = bl[nb - 1].rec_base + bl[nb - 1].n_reads;
+        const uint64_t s1 = (b1 < p->n_blocks) ? p->blocks[b1].seq_base : p->seq_bytes - 8, t1k = (b1 < p->n_blocks) ? p->blocks[b1].tok_base : p->n_tok;
+        for (uint32_t k = 0; k < nb; k++) { bl[k].rec_base -= r0; bl[k].seq_base -= s0; bl[k].tok_base -= t0k; J->n_reads += bl[k].n_reads; }
+        cbc_host_batch hb;
+        memset(&hb, 0, sizeof hb);
+        hb.recs = p->recs + r0; hb.n_recs = r1 - r0; hb.seq = p->seq + s0; hb.seq_bytes = s1 - s0 + 8;   /* 8 readable pad bytes follow */
+        hb.tok = p->tok + t0k; hb.n_tok = t1k - t0k; hb.names = p->names; hb.names_bytes = p->names_bytes;
+        hb.blocks = bl; hb.n_blocks = nb; hb.caps = p->caps;
+        uint64_t cap = cbc_gpu_plan_output(bl, nb, hb.recs, hb.tok);
+        uint8_t *pay = (uint8_t *)malloc(cap ? cap : 1);
+        if (!pay) { J->rc = CBC_E_NOMEM; free(bl); free(offs); break; }
+        J->rc = cbc_gpu_encode_blocks(ctx, &hb, pay, cap, offs, NULL);
+        if (J->rc) snprintf(J->err, sizeof J->err, "%s", cbc_gpu_last_error(ctx));
+        else {
+            float ms = 0; if (!cbc_gpu_last_kernel_ms(ctx, &ms)) J->kernel_ms += ms;
+            for (uint32_t k = 0; k < nb; k++) { J->blk_payload[b0 + k] = pay + offs[k]; J->blk_bytes[b0 + k] = (uint32_t)(offs[k + 1] - offs[k]); }
+            J->runs[J->n_runs++] = pay; pay = NULL;
+        }
+        free(pay); free(bl); free(offs);
+        b0 = b1;
+    }
+    cbc_gpu_shutdown(ctx);
+    J->seconds = now_s() - t0;
+    return NULL;
+}
+
+static int parse_devices(const char *s, int *devs)
+{
+    int n = 0;
+    while (*s && n < CBC_MAX_DEVICES) {
+        char *e = NULL; long v = strtol(s, &e, 10);
+        if (e == s || v < 0) return -1;
+        devs[n++] = (int)v;
+        s = (*e == ',') ? e + 1 : e;
+        if (*e && *e != ',') return -1;
+    }
+    return n;
+}
+
+static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, const char *out, int verbose)
+{
+    uint32_t *part = (uint32_t *)calloc(p->n_contigs ? p->n_contigs : 1, sizeof(uint32_t));
+    uint8_t **blk_payload = (uint8_t **)calloc((size_t)p->n_blocks + 1, sizeof(uint8_t *));
+    uint32_t *blk_bytes = (uint32_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint32_t));
+    uint64_t *offs = (uint64_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint64_t));
+    dev_job jobs[CBC_MAX_DEVICES]; pthread_t th[CBC_MAX_DEVICES];
+    if (!part || !blk_payload || !blk_bytes || !offs || cbc_assign_contigs(p, (uint32_t)ndev, part)) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
+    double t0 = now_s();
+    for (int d = 0; d < ndev; d++) {
+        memset(&jobs[d], 0, sizeof jobs[d]);
+        jobs[d].p = p; jobs[d].device = devs[d]; jobs[d].part = (uint32_t)d; jobs[d].part_of_contig = part;
+        jobs[d].blk_payload = blk_payload; jobs[d].blk_bytes = blk_bytes;
+        if (pthread_create(&th[d], NULL, dev_encode, &jobs[d]) != 0) { fprintf(stderr, "cbc: cannot start a device thread\n"); return 1; }
+    }
+    int bad = 0;
+    for (int d = 0; d < ndev; d++) { pthread_join(th[d], NULL); if (jobs[d].rc) { fprintf(stderr, "cbc: device %d: %s\n", devs[d], jobs[d].err); bad = 1; } }
+    if (bad) return 1;
+    double t1 = now_s();
+    for (uint32_t b = 0; b < p->n_blocks; b++) offs[b + 1] = offs[b] + blk_bytes[b];
+    uint8_t *flat = (uint8_t *)malloc(offs[p->n_blocks] ? offs[p->n_blocks] : 1);
+    if (!flat) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
+    for (uint32_t b = 0; b < p->n_blocks; b++) memcpy(flat + offs[b], blk_payload[b], blk_bytes[b]);   /* global block order */
+    int64_t n = cbc_container_size(p, offs);
+    uint8_t *blob = (uint8_t *)malloc((size_t)n);
+    if (!blob || cbc_container_write(p, flat, offs, blob, (uint64_t)n) != n) { fprintf(stderr, "cbc: container write failed\n"); return 1; }
+    FILE *fo = fopen(out, "wb");
+    if (!fo || fwrite(blob, 1, (size_t)n, fo) != (size_t)n || fclose(fo) != 0) { fprintf(stderr, "cbc: cannot write %s\n", out); return 1; }
+    printf("Final Size: %lld\n", (long long)n);
+    printf("%llu reads in %u blocks, %llu bases, %d devices\n", (unsigned long long)p->n_recs, p->n_blocks, (unsigned long long)p->n_bases, ndev);
+    if (verbose) for (int d = 0; d < ndev; d++)
+        printf("device %d: %llu reads, %.3f s (init + reference upload + encode), kernels %.3f ms\n", devs[d], (unsigned long long)jobs[d].n_reads, jobs[d].seconds, (double)jobs[d].kernel_ms);
+    if (verbose) printf("time: all devices %.3f s, assemble + write %.3f s\n", t1 - t0, now_s() - t1);
+    for (int d = 0; d < ndev; d++) { for (uint32_t k = 0; k < jobs[d].n_runs; k++) free(jobs[d].runs[k]); free(jobs[d].runs); }
+    free(flat); free(blob); free(part); free(blk_payload); free(blk_bytes); free(offs);
+    return 0;
+}
+
+static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose, int compat,
+                       const int *devs, int ndev)
 {
     size_t sam_len = 0, fa_len = 0;
     double t0 = now_s();
@@ -84,6 +199,11 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     unmap_file(sam, sam_len); unmap_file(fa, fa_len);
     double t1 = now_s();
     if (rc) { fprintf(stderr, "cbc: %s\n", err); return 1; }
+    if (ndev > 1 && !compat) {
+        rc = compress_on_devices(p, devs, ndev, out, verbose);
+        cbc_packed_free(p);
+        return rc;
+    }
     cbc_gpu_ctx *ctx = NULL;
     rc = cbc_gpu_init(device, &ctx);
     if (rc) { fprintf(stderr, "cbc: no usable MI355X (cbc_gpu_init = %d); there is no CPU fallback\n", rc); cbc_packed_free(p); return 1; }
@@ -136,12 +256,13 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     return 0;
 }
 
-int cbc_cli_decompress(const char *in, const char *out, const char *ref, int device);   /* cbc_unpack.c */
+int cbc_cli_decompress(const char *in, const char *out, const char *ref, const int *devs, int ndev);   /* cbc_cli_unpack.c */
 
 int main(int argc, char **argv)
 {
     const char *files[3] = { 0, 0, 0 };
     int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0;
+    int devs[CBC_MAX_DEVICES] = { 0 }, ndev = 0;
     uint32_t block_reads = 0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -152,6 +273,12 @@ int main(int argc, char **argv)
         }
         if (!strcmp(a, "--block-reads") && i + 1 < argc) { block_reads = (uint32_t)strtoul(argv[++i], NULL, 10); continue; }
         if (!strcmp(a, "--device") && i + 1 < argc) { device = atoi(argv[++i]); continue; }
+        if (!strcmp(a, "--devices") && i + 1 < argc) {            /* e.g. 0,1,2,3: contigs are sharded over them */
+            ndev = parse_devices(argv[++i], devs);
+            if (ndev < 1) { fprintf(stderr, "cbc: --devices wants a comma-separated list of ordinals\n"); return 1; }
+            device = devs[0];
+            continue;
+        }
         if (!strcmp(a, "--threads") && i + 1 < argc) { threads = atoi(argv[++i]); if (threads < 0) threads = 0; continue; }
         if (!strcmp(a, "--verbose")) { verbose = 1; continue; }
         if (!strcmp(a, "--compat")) { compat = 1; continue; }
@@ -189,6 +316,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "cbc: user@host:file download mode (src/main.c:306-326) is out of scope\n");
         return 1;
     }
-    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat)
-                     : cbc_cli_decompress(files[0], files[1], files[2], device);
+    if (ndev == 0) { devs[0] = device; ndev = 1; }
+    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat, devs, ndev)
+                     : cbc_cli_decompress(files[0], files[1], files[2], devs, ndev);
 }

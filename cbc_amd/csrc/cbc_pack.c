@@ -1177,6 +1177,26 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
     return (int64_t)total;
 }
 
+/* ================================= sharding =============================================== */
+API int cbc_assign_contigs(const cbc_packed *p, uint32_t n_parts, uint32_t *part_of_contig)
+{
+    if (!p || !part_of_contig || n_parts == 0) return CBC_E_ARG;
+    uint32_t nc = p->n_contigs;
+    uint64_t *reads = (uint64_t *)calloc(nc ? nc : 1, sizeof(uint64_t)), *load = (uint64_t *)calloc(n_parts, sizeof(uint64_t));
+    uint8_t *done = (uint8_t *)calloc(nc ? nc : 1, 1);
+    if (!reads || !load || !done) { free(reads); free(load); free(done); return CBC_E_NOMEM; }
+    for (uint32_t b = 0; b < p->n_blocks; b++) reads[p->info[b].contig] += p->info[b].n_reads;
+    for (uint32_t k = 0; k < nc; k++) {                     /* largest remaining contig -> least loaded part */
+        uint32_t best = 0; int have = 0;
+        for (uint32_t c = 0; c < nc; c++) if (!done[c] && (!have || reads[c] > reads[best])) { best = c; have = 1; }
+        uint32_t part = 0;
+        for (uint32_t q = 1; q < n_parts; q++) if (load[q] < load[part]) part = q;
+        part_of_contig[best] = part; load[part] += reads[best]; done[best] = 1;
+    }
+    free(reads); free(load); free(done);
+    return 0;
+}
+
 /* ================================= reference alone ======================================== */
 API void cbc_reference_free(cbc_reference *r)
 {

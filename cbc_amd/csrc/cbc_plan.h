@@ -11,9 +11,12 @@
 
 /* LDS layout constants, in 32-bit words (the kernel bodies take them from here).
  * [0, CBC_PLAN_TABLE_WORDS): model tables shared by encoder and decoder bodies:
- *   256 rlength, 256 snps, 256 indels, 2 x CBC_CAP_NAME contig-name pairs, CBC_BLOOM_WORDS Bloom filter, 2 x 256 hot var slots */
-#define CBC_BLOOM_WORDS 512u                        /* 16384 bits, two hash functions (power of two) */
-#define CBC_PLAN_TABLE_WORDS (768u + 2u * CBC_CAP_NAME + CBC_BLOOM_WORDS + 512u)
+ *   256 rlength, 256 snps, 256 indels, 2 x CBC_CAP_NAME contig-name pairs, CBC_BLOOM_WORDS Bloom filter,
+ *   2 x CBC_P0_WORDS var events of the "p = 0" contexts (one array per strand, two 16-bit events per word) */
+#define CBC_BLOOM_WORDS 256u                        /* 8192 bits, two hash functions (power of two) */
+#define CBC_P0_WORDS    512u                        /* per strand: up to CBC_P0_CAP events of 16 bits */
+#define CBC_P0_CAP      1023u                       /* three 10-bit tallies share one register in the scan */
+#define CBC_PLAN_TABLE_WORDS (768u + 2u * CBC_CAP_NAME + CBC_BLOOM_WORDS + 2u * CBC_P0_WORDS)
 #ifndef CBC_BATCH_SLOTS
 #define CBC_BATCH_SLOTS 2u                         /* encoder hand-off ring depth (power of two; 2 measured as good as 4) */
 #endif

@@ -130,6 +130,8 @@ def lib():
         L.cbc_container_write.restype = ctypes.c_int64
         L.cbc_container_write.argtypes = [ctypes.POINTER(Packed), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
                                           ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_assign_contigs.restype = ctypes.c_int
+        L.cbc_assign_contigs.argtypes = [ctypes.POINTER(Packed), ctypes.c_uint32, ctypes.c_void_p]
         L.cbc_unpack_plan_create.restype = ctypes.c_int
         L.cbc_unpack_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t,
                                              ctypes.POINTER(ctypes.POINTER(UnpackPlanC)), ctypes.c_char_p, ctypes.c_size_t]
@@ -213,6 +215,18 @@ class PackedBatch:
         off = int(self.contigs[ci]["name_off"])
         raw = self.names[off:].tobytes()
         return raw[:raw.index(b"\0")]
+
+    def assign_contigs(self, n_parts):
+        """Whole contigs dealt to n_parts, largest first to the least loaded part (cbc_assign_contigs).  Returns the
+        part of every contig; blocks_of_part() turns it into block index lists."""
+        out = np.zeros(max(len(self.contigs), 1), dtype=np.uint32)
+        rc = lib().cbc_assign_contigs(self._ptr, n_parts, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("cbc_assign_contigs failed: %d" % rc)
+        return out[:len(self.contigs)]
+
+    def blocks_of_part(self, part_of_contig, part):
+        return [b for b in range(self.n_blocks) if int(part_of_contig[int(self.info[b]["contig"])]) == part]
 
     def container(self, payloads: np.ndarray, out_offsets: np.ndarray) -> bytes:
         offs = np.ascontiguousarray(out_offsets, dtype=np.uint64)

@@ -76,3 +76,30 @@ def encode_sharded(dist, block_reads, encode_range, device, dst=0):
     local, sizes = encode_range(b0, b1)
     payload, allsizes = gather_bitstreams(dist, local, sizes, device, dst=dst)
     return (b0, b1), payload, allsizes
+
+
+def encode_sharded_by_contig(dist, pb, encode_blocks, device, dst=0):
+    """cfg4's partitioning: whole contigs are dealt to the ranks, largest first to the least
+    loaded (PackedBatch.assign_contigs -> cbc_assign_contigs, the rule the C host's `cbc --devices` uses), every
+    rank codes the blocks of its contigs, and rank `dst` puts the gathered bitstreams back into global block
+    order.  encode_blocks(list of block indices) -> (uint8 tensor of their payloads in that order, int64 tensor
+    of sizes), both on `device`.  Returns (my block indices, payload, sizes): the last two in global block order
+    on `dst`, None elsewhere."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    part = pb.assign_contigs(world)
+    mine = pb.blocks_of_part(part, rank)
+    local, sizes = encode_blocks(mine)
+    payload, allsizes = gather_bitstreams(dist, local, sizes, device, dst=dst)
+    if rank != dst:
+        return mine, None, None
+    # rank order -> block order: every rank's list is known from the (deterministic) assignment
+    order = [b for r in range(world) for b in pb.blocks_of_part(part, r)]
+    sz = allsizes.tolist()
+    starts = [0]
+    for v in sz:
+        starts.append(starts[-1] + int(v))
+    where = {b: i for i, b in enumerate(order)}
+    pieces = [payload[starts[where[b]]:starts[where[b] + 1]] for b in range(pb.n_blocks)]
+    out_sizes = torch.tensor([int(sz[where[b]]) for b in range(pb.n_blocks)], dtype=torch.int64)
+    return mine, (torch.cat(pieces) if pieces else payload[:0]), out_sizes

@@ -103,6 +103,12 @@ int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets);
 int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
                             uint8_t *dst, uint64_t dst_cap);
 
+/* ---- sharding over devices ---------------------------------------------------------
+ * Blocks are independent streams; a contig's blocks share its reference, so whole contigs are dealt to the parts,
+ * largest first, each to the part with the least records so far (cfg4: chromosome-sharded).  part_of_contig[c]
+ * receives the part of contig c.  Deterministic: ties go to the lower part index. */
+int  cbc_assign_contigs(const cbc_packed *p, uint32_t n_parts, uint32_t *part_of_contig /* n_contigs */);
+
 /* ---- the reference alone (whole-file stream decode: the stream names contigs only by "next one") ----
  * FASTA text -> upper-cased contig bases, each + CBC_REF_PAD zero bytes, and the contig table in file order
  * (store_reference_in_memory, src/read_decompression.c:17-53).  Free with cbc_reference_free. */

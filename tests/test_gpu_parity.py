@@ -450,3 +450,27 @@ def test_bench_launched_bare_with_two_ranks(built, scaling):
     assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["value"] > 0
     if scaling == "strong":
         assert j["config"]["gathered_equals_single_gpu"] is True
+
+
+def test_cli_several_devices(built, tmp_path):
+    """`cbc --devices a,b`: one host thread and one context per listed device, contigs dealt largest-first (encode),
+    contiguous block ranges (decode).  This box has one GPU, so both contexts live on device 0; the container and
+    the decoded text must not depend on the device count."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cbc_amd", "csrc", "cbc")
+    fa, sam, _, _ = synth.dataset(18, [60000, 200000, 90000], [900, 3000, 1400], 100, sub_rate=0.01, indel_frac=0.2)
+    (tmp_path / "in.sam").write_bytes(sam); (tmp_path / "ref.fa").write_bytes(fa)
+    outs = []
+    for tag, extra in (("one", []), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0,0,0"])):
+        o = tmp_path / ("out_%s.cbc" % tag)
+        r = subprocess.run([exe, "-c", "1", str(tmp_path / "in.sam"), str(o), str(tmp_path / "ref.fa"), "--block-reads", "256", "--verbose"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(o.read_bytes())
+    assert outs[0] == outs[1] == outs[2]
+    expect = b"".join(ln.split(b"\t")[9] + b"\n" for ln in sam.splitlines() if not ln.startswith(b"@"))
+    for extra in ([], ["--devices", "0,0"]):
+        r = subprocess.run([exe, "-d", str(tmp_path / "out_two.cbc"), str(tmp_path / "reads.txt"), str(tmp_path / "ref.fa")] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / "reads.txt").read_bytes() == expect

@@ -54,6 +54,68 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_contigs(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import blockref
+    import synth
+    from cbc_amd import host, shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a 3-contig miniature of cfg4: the middle contig is the largest, so the ranks' blocks interleave
+    fa, sam, _, _ = synth.dataset(23, [60000, 200000, 90000], [900, 3000, 1400], 100, sub_rate=0.01, indel_frac=0.1)
+    pb = host.pack_sam(sam, fa, block_reads=256)
+
+    def encode_blocks(which):
+        mine = [p for _, p, _ in blockref.emu_encode_blocks(pb, which)]
+        local = torch.from_numpy(np.frombuffer(b"".join(mine), dtype=np.uint8).copy()) if mine else torch.zeros(0, dtype=torch.uint8)
+        return local, torch.tensor([len(p) for p in mine], dtype=torch.int64)
+
+    mine, allp, alls = shard.encode_sharded_by_contig(dist, pb, encode_blocks, torch.device("cpu"), dst=0)
+    part = pb.assign_contigs(world)
+    if rank == 0:
+        payloads, _ = blockref.emu_encode(pb)                     # the single-rank result
+        offs = np.concatenate([[0], np.cumsum(alls.numpy())]).astype(np.uint64)
+        same = pb.container(allp.numpy(), offs) == blockref.container_from_payloads(pb, payloads)
+        q.put((same, [int(x) for x in part], len(mine), pb.n_blocks))
+    dist.destroy_process_group()
+
+
+def test_contig_sharding_two_ranks(built):
+    """Chromosome sharding (cfg4): contigs dealt largest-first over 2 ranks, each codes its contigs' blocks, rank 0
+    reassembles global block order: the container equals the single-rank container."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_contigs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, part, n_mine, nb = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same
+    assert part == [1, 0, 1]                  # 3000 reads -> rank 0; then 1400 -> rank 1; then 900 -> rank 1 (least loaded)
+    assert 0 < n_mine < nb
+
+
+def test_assign_contigs_rule(built):
+    import synth
+    from cbc_amd import host
+    fa, sam, _, _ = synth.dataset(24, [50000] * 5, [500, 100, 400, 300, 200], 100)
+    pb = host.pack_sam(sam, fa, block_reads=128)
+    assert list(pb.assign_contigs(1)) == [0] * 5
+    part = list(pb.assign_contigs(2))          # 500->0, 400->1, 300->1 (400<500), 200->0 (500<700), 100->0 (700==700: lower index)
+    assert part == [0, 0, 1, 1, 0]
+    loads = [sum(int(pb.info[b]["n_reads"]) for b in pb.blocks_of_part(part, r)) for r in range(2)]
+    assert sorted(loads) == [700, 800]
+    assert len(set(pb.assign_contigs(8))) == 5
+
+
 def test_gather_two_ranks(built):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
