@@ -81,7 +81,7 @@ struct CbcDec {
     uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, nev1, cap_var, L0;
     uint32_t prevPos, prevM, prevChar;
     uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
-    uint32_t np0, np1, p0over;
+    V32 p0cnt; uint32_t p0over;
     uint64_t w0, w1, w2, w3;
 
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
@@ -524,34 +524,33 @@ struct CbcDec {
         bool to_global = !p0class;
         V32 e0 = W::splat(0u), e1 = W::splat(0u), e2 = W::splat(0u), e3 = W::splat(0u);
         uint32_t m = 0;
+        const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);
+        uint32_t have = 0;
         if (p0class) {
             const uint32_t d = ctx >> 8;
-            const uint32_t *arr = tab(CBC_LDS_P0) + strand1 * CBC_P0_WORDS;
-            const uint32_t have = strand1 ? np1 : np0, nw = (have + 1u) >> 1;
-            const uint32_t nwb = W::uni(nw);
-            for (uint32_t b = 0; b < nwb; b += 64u) {
-                const V32 i = ln + b;
-                const V32 w = W::load32(arr, i, i < nw, 0xffffffffu);
-                for (uint32_t half = 0; half < 2u; half++) {
-                    const V32 e = half ? (w >> 16) : (w & 0xffffu);
-                    uint64_t bb = W::ballot((e >> 8) == d);
-                    while (bb) {
-                        uint32_t src = W::ctz64(bb); bb &= bb - 1u;
-                        uint32_t kk = W::readlane(e, src) & 0xffu;
-                        Mask hitl = ln == (kk >> 2);
-                        uint32_t sub = kk & 3u;
-                        e0 = W::select(hitl & (sub == 0u), e0 + 10u, e0);
-                        e1 = W::select(hitl & (sub == 1u), e1 + 10u, e1);
-                        e2 = W::select(hitl & (sub == 2u), e2 + 10u, e2);
-                        e3 = W::select(hitl & (sub == 3u), e3 + 10u, e3);
-                        m++;
-                    }
+            const uint32_t *arr = tab(CBC_LDS_P0) + bkt * CBC_P0_BUCKET_WORDS;
+            have = W::readlane(p0cnt, bkt);
+            const uint32_t nw = (have + 1u) >> 1;
+            const V32 w = W::load32(arr, ln, ln < nw, 0xffffffffu);       /* the whole bucket in one load */
+            for (uint32_t half = 0; half < 2u; half++) {
+                const V32 e = half ? (w >> 16) : (w & 0xffffu);
+                uint64_t bb = W::ballot((e >> 8) == d);
+                while (bb) {
+                    uint32_t src = W::ctz64(bb); bb &= bb - 1u;
+                    uint32_t kk = W::readlane(e, src) & 0xffu;
+                    Mask hitl = ln == (kk >> 2);
+                    uint32_t sub = kk & 3u;
+                    e0 = W::select(hitl & (sub == 0u), e0 + 10u, e0);
+                    e1 = W::select(hitl & (sub == 1u), e1 + 10u, e1);
+                    e2 = W::select(hitl & (sub == 2u), e2 + 10u, e2);
+                    e3 = W::select(hitl & (sub == 3u), e3 + 10u, e3);
+                    m++;
                 }
             }
             if (have >= CBC_P0_CAP) to_global = true;
         }
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
-        if (to_global || ((p0over >> strand1) & 1u)) {
+        if (to_global || ((p0over >> bkt) & 1u)) {
             /* the encoder's filter: two hash functions, both words fetched by one LDS instruction */
             h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
             const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
@@ -591,15 +590,15 @@ struct CbcDec {
         if (x >= L0) { fail(CBC_ST_ASSERT); return 0u; }
         step(lo, cnt, n);
         if (!to_global) {
-            uint32_t *arr = tab(CBC_LDS_P0) + strand1 * CBC_P0_WORDS;
-            const uint32_t have = strand1 ? np1 : np0, k16 = ((ctx >> 8) << 8) | x;
+            uint32_t *arr = tab(CBC_LDS_P0) + bkt * CBC_P0_BUCKET_WORDS;
+            const uint32_t k16 = ((ctx >> 8) << 8) | x;
             if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
             else W::write_uni(arr, have >> 1, 0xffff0000u | k16);
-            if (strand1) np1 = have + 1u; else np0 = have + 1u;
+            p0cnt = W::select(ln == bkt, p0cnt + 1u, p0cnt);
             return x;
         }
         if (nev + nev1 >= cap_var) { fail(CBC_ST_CAP_VAR); return 0u; }
-        if (p0class) p0over |= 1u << strand1;
+        if (p0class) p0over |= 1u << bkt;
         if (!((bw1 & bb1) && (bw2 & bb2))) {
             if ((h1 >> 5) == (h2 >> 5)) W::write_uni(bloom, h1 >> 5, bw1 | bb1 | bb2);
             else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
@@ -805,7 +804,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     }
     D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
     D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
-    D.np0 = D.np1 = 0; D.p0over = 0;
+    D.p0cnt = W::splat(0u); D.p0over = 0;
 
     /* the tag: first 26 bits (alloc_arithmetic_stream, Arithmetic_stream.c:260-263) */
     if (D.status == CBC_ST_OK) D.t = D.take(26u);

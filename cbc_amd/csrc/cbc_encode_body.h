@@ -163,7 +163,7 @@ struct CbcEnc {
     uint32_t *vtab;                          /* GEN: var excess table in global memory, row = context, L0 words per row */
     uint32_t pos_card, cap_pos;              /* pos alphabet: value / occurrences / prefix by index, in LDS */
     uint32_t nev, nev1, cap_var;             /* var events of strand 0 (from the bottom of the area) / strand 1 (from the top) */
-    uint32_t np0, np1, p0over;               /* p = 0 contexts: events held in LDS per strand; bit s of p0over = strand s spilled to the global list */
+    V32 p0cnt; uint32_t p0over;              /* p = 0 contexts: events held per (strand, d & 7) bucket, lane = strand * 8 + bucket; bit = that bucket spilled to the global list */
     uint32_t L0;
 
     /* ---- cross-read state (T7/T8 of SURVEY.md) ---- */
@@ -855,37 +855,36 @@ struct CbcEnc {
          *    distance d to the first known SNP ahead.  With a few percent of the reference positions marked by
          *    earlier reads these are the contexts that repeat (a few hundred of them, each used several times per
          *    block), and they carry most of a block's var symbols.  Their events are 16 bits (d << 8 | symbol)
-         *    in an LDS array per strand; a lookup is a scan of that array (128 events per LDS load, the three
-         *    tallies in one register, one wave sum) and never leaves the CU.
+         *    in LDS, bucketed by (strand, d & 7), 128 events per bucket: a lookup is ONE LDS load per lane over the
+         *    context's bucket, the three tallies in one register, one wave sum, and never leaves the CU.
          *  - all other contexts are mostly seen once per block: Bloom filter on the context, and only on a
          *    filter hit a scan of the strand's event list in global memory.
-         * A strand whose LDS array is full spills its further p = 0 events to the global list (p0over). */
+         * A bucket that is full spills its further events to the global list (p0over). */
         V32 ln = W::lane();
         uint32_t cn = 0, clo = 0, ceq = 0;
         const uint32_t key = (ctx << 8) | sym, strand1 = ctx & 1u;
         const bool p0class = ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u;   /* 255 is the unused-half marker */
         bool to_global = !p0class;
+        const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);   /* the context's bucket: strand, d & 7 */
+        uint32_t have = 0;
         if (p0class) {
             const uint32_t d = ctx >> 8, key16 = (d << 8) | sym;
-            const uint32_t *arr = p0ev + strand1 * CBC_P0_WORDS;
-            const uint32_t have = strand1 ? np1 : np0, nw = (have + 1u) >> 1;
-            V32 acc = W::splat(0u);
-            const uint32_t nwb = W::uni(nw);
-            for (uint32_t b = 0; b < nwb; b += 64u) {            /* an unused upper half holds 0xffff: d = 255 never occurs */
-                const V32 i = ln + b;
-                const V32 w = W::load32(arr, i, i < nw, 0xffffffffu);
-                const V32 e0 = w & 0xffffu, e1 = w >> 16;
-                acc = acc + W::select((e0 >> 8) == d, W::select((e0 & 0xffu) < sym, W::splat(1u + (1u << 10)), W::splat(1u)) +
-                                                       W::select(e0 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u));
-                acc = acc + W::select((e1 >> 8) == d, W::select((e1 & 0xffu) < sym, W::splat(1u + (1u << 10)), W::splat(1u)) +
+            const uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
+            have = W::readlane(p0cnt, bkt);
+            const uint32_t nw = (have + 1u) >> 1;
+            /* the whole bucket in one load; an unused upper half holds 0xffff (d = 255 is not in the class) */
+            const V32 w = W::load32(arr, ln, ln < nw, 0xffffffffu);
+            const V32 e0 = w & 0xffffu, e1 = w >> 16;
+            const V32 acc = W::select((e0 >> 8) == d, W::select((e0 & 0xffu) < sym, W::splat(1u + (1u << 10)), W::splat(1u)) +
+                                                       W::select(e0 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u)) +
+                            W::select((e1 >> 8) == d, W::select((e1 & 0xffu) < sym, W::splat(1u + (1u << 10)), W::splat(1u)) +
                                                        W::select(e1 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u));
-            }
             const uint32_t tot = W::reduce_add(acc);
             cn = tot & 1023u; clo = (tot >> 10) & 1023u; ceq = tot >> 20;
             if (have >= CBC_P0_CAP) to_global = true;
         }
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
-        if (to_global || ((p0over >> strand1) & 1u)) {
+        if (to_global || ((p0over >> bkt) & 1u)) {
             /* two hash functions, both words fetched by one LDS instruction (lanes 0 and 1) */
             h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
             const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
@@ -914,16 +913,16 @@ struct CbcEnc {
             }
         }
         encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
-        if (!to_global) {                                        /* p = 0 context with room in its LDS array */
-            uint32_t *arr = p0ev + strand1 * CBC_P0_WORDS;
-            const uint32_t have = strand1 ? np1 : np0, k16 = ((ctx >> 8) << 8) | sym;
+        if (!to_global) {                                        /* p = 0 context with room in its bucket */
+            uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
+            const uint32_t k16 = ((ctx >> 8) << 8) | sym;
             if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
             else W::write_uni(arr, have >> 1, 0xffff0000u | k16);
-            if (strand1) np1 = have + 1u; else np0 = have + 1u;
+            p0cnt = W::select(ln == bkt, p0cnt + 1u, p0cnt);
             return;
         }
         if (nev + nev1 >= cap_var) { fail(CBC_ST_CAP_VAR); return; }
-        if (p0class) p0over |= 1u << strand1;
+        if (p0class) p0over |= 1u << bkt;
         if (!((bw1 & bb1) && (bw2 & bb2))) {
             if ((h1 >> 5) == (h2 >> 5)) W::write_uni(bloom, h1 >> 5, bw1 | bb1 | bb2);
             else { W::write_uni(bloom, h1 >> 5, bw1 | bb1); W::write_uni(bloom, h2 >> 5, bw2 | bb2); }
@@ -1156,7 +1155,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         for (uint32_t b = 0; b < 512u; b += 64u) W::store32(E.snps_exc, ln + b, W::splat(0u), W::all());   /* snps + indels */
         for (uint32_t b = 0; b < CBC_BLOOM_WORDS; b += 64u) W::store32(E.bloom, ln + b, W::splat(0u), W::all());   /* the p = 0 arrays need no clearing */
     }
-    E.np0 = E.np1 = 0; E.p0over = 0;
+    E.p0cnt = W::splat(0u); E.p0over = 0;
     E.snps_n = L0; E.indels_n = L0;
     E.rn_count = 0; E.rn_cap = CBC_CAP_NAME; E.vtab = nullptr;
     E.pos_card = 1u;                                         /* initialize_stream_model_pos :132-162: the escape */

@@ -523,7 +523,8 @@ static int place_record(packer_t *S, uint32_t pos, uint32_t flag, size_t rl, uin
         for (uint32_t i = 0; i < S->blk_nflags; i++) if (S->blk_flags[i] == (uint16_t)flag) { newflag = 0; break; }
         int newdelta = !delta_seen(S, x, 0);
         if (S->blk_reads >= S->o.block_reads) need_new = 1;
-        else if (x >= 5000000u) need_new = 1;                                   /* MAX_ALPHA sam_block.h:54 */
+        else if (S->o.long_reads && S->blk_bases + rl > CBC_LONG_BLOCK_BASES) need_new = 1;
+        else if (x >= 5000000u && !S->o.long_reads) need_new = 1;              /* MAX_ALPHA sam_block.h:54 */
         else if (newdelta && S->blk_ndelta + 3 > S->o.max_cap_pos) need_new = 1;
         else if (S->blk_var + ev + 1 > S->o.max_cap_var) need_new = 1;
         else if (newflag && S->blk_nflags >= CBC_CAP_FLAG) need_new = 1;
@@ -583,6 +584,92 @@ static int add_record(packer_t *S, const char *rname, uint32_t flag, int32_t pos
     return 0;
 }
 
+
+/* ================================= long-read format ====================== */
+/* One mapped record of a long-read SAM: fields by pointer and length (lines are not copied: a 10 kb read's line
+ * is ~20 kB).  Tokens: word 0 = n_cigar, word 1 = 0, then (len << 4) | op per CIGAR op; MD is not used -- the
+ * kernels derive the edits from read vs reference.  SEQ must be over {A,C,G,T,N} so that the round trip is exact
+ * (the base models code basepair classes, sam_models.c:11-33). */
+static int add_record_long(packer_t *S, const char *rname, size_t nl, uint32_t flag, int64_t pos_i, const char *cigar, size_t cl,
+                           const char *seq, size_t rl)
+{
+    cbc_packed *P = S->P;
+    if (!S->have_contig || nl != strlen(S->prev_name) || memcmp(rname, S->prev_name, nl) != 0) {
+        if (nl >= LINE_BUF) return fail(S, CBC_E_INPUT, "RNAME longer than %s%lld characters", "", (long long)LINE_BUF - 1);
+        int rc = contig_open(S, rname, nl);
+        if (rc) return rc;
+        memcpy(S->prev_name, rname, nl); S->prev_name[nl] = 0;
+    }
+    const cbc_contig_info *ctg = &P->contigs[S->contig];
+    const char *nm = (const char *)P->names + ctg->name_off;
+    if (rl == 0 || rl > CBC_LONG_MAX_READ_LEN) return fail(S, CBC_E_INPUT, "read length %s%lld outside 1..65535", "", (long long)rl);
+    if (pos_i < 1 || pos_i > 0x7fffffff) return fail(S, CBC_E_INPUT, "POS %s%lld outside 1..2^31-1", "", (long long)pos_i);
+    for (size_t i = 0; i < rl; i++) {
+        char c = seq[i];
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N'))
+            return fail(S, CBC_E_INPUT, "SEQ at %s:%lld holds a character outside ACGTN (long-read format)", nm, (long long)pos_i);
+    }
+    /* CIGAR -> tokens, and what it consumes */
+    uint64_t to = P->n_tok, nt = 2, in_read = 0, in_ref = 0; uint32_t n_cig = 0;
+    {
+        size_t i = 0;
+        while (i < cl) {
+            uint64_t v = 0; size_t d0 = i;
+            while (i < cl && cigar[i] >= '0' && cigar[i] <= '9') { v = v * 10 + (uint64_t)(cigar[i] - '0'); if (v > 0x0fffffff) break; i++; }
+            if (i >= cl || i == d0 || v == 0 || v > 0x0fffffff) return fail(S, CBC_E_INPUT, "malformed CIGAR at %s:%lld", nm, (long long)pos_i);
+            char c = cigar[i++];
+            uint32_t op;
+            if (c == 'M' || c == '=' || c == 'X') { op = CBC_OP_M; in_read += v; in_ref += v; }
+            else if (c == 'I' || c == 'S') { op = (c == 'I') ? CBC_OP_I : CBC_OP_S; in_read += v; }
+            else if (c == 'D' || c == 'N') { op = CBC_OP_D; in_ref += v; }
+            else if (c == 'H' || c == 'P') continue;                      /* consume nothing, code nothing */
+            else return fail(S, CBC_E_INPUT, "CIGAR operation not understood at %s:%lld", nm, (long long)pos_i);
+            if (grow((void **)&P->tok, &P->cap_tok, to + nt + 1, sizeof(uint32_t))) return CBC_E_NOMEM;
+            P->tok[to + nt++] = ((uint32_t)v << 4) | op; n_cig++;
+            if (n_cig > 0xffff) return fail(S, CBC_E_INPUT, "more than 65535 CIGAR operations at %s:%lld", nm, (long long)pos_i);
+        }
+    }
+    if (in_read != rl) return fail(S, CBC_E_INPUT, "CIGAR and SEQ lengths differ at %s:%lld", nm, (long long)pos_i);
+    if ((uint64_t)pos_i - 1 + in_ref > ctg->length + CBC_REF_PAD - 8) return fail(S, CBC_E_INPUT, "record at %s POS %lld runs past the contig end + pad", nm, (long long)pos_i);
+    if (grow((void **)&P->tok, &P->cap_tok, to + 2, sizeof(uint32_t))) return CBC_E_NOMEM;
+    P->tok[to] = n_cig; P->tok[to + 1] = 0;
+    uint64_t so = P->seq_bytes;
+    if (grow((void **)&P->seq, &P->cap_seq, so + rl + 8, 1)) return CBC_E_NOMEM;
+    int rc = place_record(S, (uint32_t)pos_i, flag, rl, 0, (uint32_t)nt);
+    if (rc) return rc;
+    memcpy(P->seq + so, seq, rl);
+    return 0;
+}
+
+/* the body of a long-read SAM: lines of any length, the 11 compulsory columns by tab */
+static int pack_body_long(packer_t *S, const char *sam, size_t off, size_t sam_len)
+{
+    while (off < sam_len) {
+        const char *nlp = (const char *)memchr(sam + off, '\n', sam_len - off);
+        size_t e = nlp ? (size_t)(nlp - sam) : sam_len;
+        const char *f[11]; size_t fl[11]; int nf = 0;
+        size_t p = off;
+        while (nf < 11 && p <= e) {
+            const char *t = (const char *)memchr(sam + p, '\t', e - p);
+            size_t q = t ? (size_t)(t - sam) : e;
+            f[nf] = sam + p; fl[nf] = q - p; nf++;
+            if (!t) break;
+            p = q + 1;
+        }
+        size_t line_off = off;
+        off = e + 1;
+        if (nf == 0 || (nf == 1 && fl[0] == 0)) continue;
+        if (nf < 11) return fail(S, CBC_E_INPUT, "SAM record with fewer than 11 columns near offset %s%lld", "", (long long)line_off);
+        char num[24]; size_t l = fl[1] < 23 ? fl[1] : 23; memcpy(num, f[1], l); num[l] = 0;
+        uint32_t flag = (uint16_t)atoi(num);
+        if ((flag & 4) == 4) { S->P->n_skipped_unmapped++; continue; }
+        l = fl[3] < 23 ? fl[3] : 23; memcpy(num, f[3], l); num[l] = 0;
+        int rc = add_record_long(S, f[2], fl[2], flag, atoll(num), f[5], fl[5], f[9], fl[9]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int finish_pack(packer_t *S)
 {
     cbc_packed *P = S->P;
@@ -594,7 +681,7 @@ static int finish_pack(packer_t *S)
     P->caps.cap_pos = (P->caps.cap_pos + 63u) & ~63u;
     P->caps.cap_var = (P->caps.cap_var + 63u) & ~63u;
     if (P->n_tok == 0) { if (grow((void **)&P->tok, &P->cap_tok, 1, sizeof(uint32_t))) return CBC_E_NOMEM; P->tok[0] = 0; }
-    P->whole_file = S->o.whole_file ? 1u : 0u;
+    P->whole_file = S->o.long_reads ? 2u : S->o.whole_file ? 1u : 0u;
     return 0;
 }
 
@@ -602,6 +689,10 @@ static int packer_init(packer_t *S, const cbc_pack_opts *opts, char *errbuf, siz
 {
     memset(S, 0, sizeof *S);
     if (opts) S->o = *opts; else cbc_pack_default_opts(&S->o);
+    if (S->o.long_reads) {                                  /* blocks are cut by bases: 64 reads of 10 kb fill one */
+        S->o.whole_file = 0;
+        if (S->o.block_reads == 0 || S->o.block_reads > 1024) S->o.block_reads = 64;
+    }
     if (S->o.block_reads == 0) S->o.block_reads = 4096;
     if (S->o.block_reads > CBC_MAX_BLOCK_READS) S->o.block_reads = CBC_MAX_BLOCK_READS;
     if (S->o.max_cap_pos < 64) S->o.max_cap_pos = 2048;
@@ -625,7 +716,7 @@ static void packer_release(packer_t *S) { free(S->dset); free(S->dstamp); }
 
 API void cbc_pack_default_opts(cbc_pack_opts *o)
 {
-    o->block_reads = 4096; o->max_cap_pos = 2048; o->max_cap_var = 8192; o->var_length = 0; o->n_threads = 0; o->whole_file = 0;
+    o->block_reads = 4096; o->max_cap_pos = 2048; o->max_cap_var = 8192; o->var_length = 0; o->n_threads = 0; o->whole_file = 0; o->long_reads = 0;
 }
 
 API void cbc_packed_free(cbc_packed *p)
@@ -958,6 +1049,12 @@ API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t 
     if (rc) goto done;
     size_t off = 0;
     S->P->read_length = header_read_length(sam, sam_len, &off, (int)S->o.var_length);
+    if (S->o.long_reads) {
+        if (S->P->read_length < 1) S->P->read_length = 1;       /* not part of the long-read stream */
+        rc = pack_body_long(S, sam, off, sam_len);
+        if (!rc) rc = finish_pack(S);
+        goto done;
+    }
     if (S->P->read_length < 1 || S->P->read_length > 256) {
         rc = fail(S, CBC_E_INPUT, "header read length %s%lld outside 1..256", "", S->P->read_length); goto done;
     }
@@ -1135,6 +1232,167 @@ done:
     return rc;
 }
 
+
+/* ================================= cfg5: synthetic long reads ============================== */
+typedef struct {
+    const cbc_synth_opts *so; const uint8_t *ref; const uint32_t *starts;
+    uint64_t r0, r1;                       /* reads [r0, r1) */
+    uint8_t *seq;                          /* final array: read r at r * read_len */
+    uint32_t *tok; uint64_t n_tok, cap_tok; uint32_t *tok_of; uint16_t *flags;
+    char *sam; size_t samn, samcap; int want_sam; const char *name;
+    int rc;
+} long_job;
+
+static void *long_gen(void *arg)
+{
+    long_job *J = (long_job *)arg;
+    static const char ACGT[4] = { 'A', 'C', 'G', 'T' };
+    const uint32_t L = J->so->read_len;
+    char *cig = (char *)malloc(16 * (size_t)L + 64);
+    if (!cig) { J->rc = CBC_E_NOMEM; return NULL; }
+    for (uint64_t r = J->r0; r < J->r1 && !J->rc; r++) {
+        rng_t R; uint64_t sd = J->so->seed ^ (0x9e3779b97f4a7c15ull * (r + 1));
+        for (int i = 0; i < 4; i++) R.s[i] = splitmix64(&sd);
+        const uint8_t *ref = J->ref + J->starts[r];
+        uint8_t *out = J->seq + r * (uint64_t)L;
+        if (grow((void **)&J->tok, &J->cap_tok, J->n_tok + 2 + 2 * (uint64_t)L + 8, sizeof(uint32_t))) { J->rc = CBC_E_NOMEM; break; }
+        uint32_t *t = J->tok + J->n_tok; uint32_t nt = 2, n_cig = 0;
+        J->tok_of[r - J->r0] = (uint32_t)J->n_tok;          /* relative to the job's pool; rebased when placed */
+        J->flags[r - J->r0] = (rng_next(&R) & 1) ? 16 : 0;
+        uint32_t i = 0, j = 0, run = 0;
+#define EMIT(op_, n_) do { if ((n_)) { if (n_cig && (t[nt - 1] & 15u) == (op_)) t[nt - 1] += (uint32_t)(n_) << 4; else { t[nt++] = ((uint32_t)(n_) << 4) | (op_); n_cig++; } } } while (0)
+        while (i < L) {
+            double u = rng_unit(&R);
+            if (u >= J->so->sub_rate || i == 0 || i + 1 >= L) { out[i++] = ref[j++]; run++; continue; }
+            uint32_t kind = (uint32_t)(rng_next(&R) % 3);
+            if (kind == 0) { char alt; do { alt = ACGT[rng_next(&R) & 3]; } while ((uint8_t)alt == ref[j]); out[i++] = (uint8_t)alt; j++; run++; }
+            else if (kind == 1) { EMIT(CBC_OP_M, run); run = 0; out[i++] = (uint8_t)ACGT[rng_next(&R) & 3]; EMIT(CBC_OP_I, 1u); }
+            else { EMIT(CBC_OP_M, run); run = 0; j++; EMIT(CBC_OP_D, 1u); }
+        }
+        EMIT(CBC_OP_M, run);
+#undef EMIT
+        t[0] = n_cig; t[1] = 0;
+        J->n_tok += nt;
+        if (J->want_sam) {
+            size_t cl = 0;
+            for (uint32_t k = 0; k < n_cig; k++) cl += (size_t)sprintf(cig + cl, "%u%c", t[2 + k] >> 4, "MIDS"[t[2 + k] & 15u]);
+            size_t need = J->samn + 2 * (size_t)L + cl + 256;
+            if (need > J->samcap) { size_t nc = J->samcap ? J->samcap * 2 : (1u << 20); while (nc < need) nc *= 2;
+                                    char *ns = (char *)realloc(J->sam, nc); if (!ns) { J->rc = CBC_E_NOMEM; break; } J->sam = ns; J->samcap = nc; }
+            J->samn += (size_t)sprintf(J->sam + J->samn, "r%llu\t%u\t%s\t%u\t60\t%s\t*\t0\t0\t", (unsigned long long)r, J->flags[r - J->r0], J->name, J->starts[r] + 1, cig);
+            memcpy(J->sam + J->samn, out, L); J->samn += L; J->sam[J->samn++] = '\t';
+            memset(J->sam + J->samn, 'I', L); J->samn += L; J->sam[J->samn++] = '\n';
+        }
+    }
+    free(cig);
+    return NULL;
+}
+
+API int cbc_synth_long(const cbc_synth_opts *so, const cbc_pack_opts *po, cbc_packed **out,
+                       char **sam_out, size_t *sam_len, char **fasta_out, size_t *fasta_len, char *errbuf, size_t errlen)
+{
+    if (!so || !out || so->read_len < 64 || so->read_len > CBC_LONG_MAX_READ_LEN || so->contig_len < 2ull * so->read_len + 64 ||
+        so->contig_len > 0xf0000000ull || so->sub_rate < 0 || so->sub_rate > 0.5) return CBC_E_ARG;
+    static const char ACGT[4] = { 'A', 'C', 'G', 'T' };
+    const char *name = so->name ? so->name : "chrL";
+    const uint32_t L = so->read_len;
+    cbc_pack_opts o; if (po) o = *po; else cbc_pack_default_opts(&o);
+    o.long_reads = 1;
+    packer_t *S = (packer_t *)malloc(sizeof(packer_t));
+    if (!S) return CBC_E_NOMEM;
+    uint32_t *starts = NULL; long_job *jobs = NULL; pthread_t *th = NULL;
+    int nt = o.n_threads ? (int)o.n_threads : online_cpus();
+    if (nt > 64) nt = 64;
+    if ((uint64_t)nt > so->n_reads) nt = so->n_reads ? (int)so->n_reads : 1;
+    int rc = packer_init(S, &o, errbuf, errlen);
+    if (rc) goto done;
+    cbc_packed *P = S->P;
+    rng_t R; uint64_t sd = so->seed;
+    for (int i = 0; i < 4; i++) R.s[i] = splitmix64(&sd);
+    if (grow((void **)&P->ref, &P->cap_ref, so->contig_len + CBC_REF_PAD, 1)) { rc = CBC_E_NOMEM; goto done; }
+    for (uint64_t i = 0; i < so->contig_len; i += 32) {
+        uint64_t w = rng_next(&R);
+        for (int k = 0; k < 32 && i + k < so->contig_len; k++) { P->ref[i + k] = (uint8_t)ACGT[w & 3]; w >>= 2; }
+    }
+    memset(P->ref + so->contig_len, 0, CBC_REF_PAD);
+    P->ref_bytes = so->contig_len + CBC_REF_PAD;
+    if (grow32((void **)&P->contigs, &P->cap_contigs, 1, sizeof(cbc_contig_info))) { rc = CBC_E_NOMEM; goto done; }
+    P->contigs[0].ref_off = 0; P->contigs[0].length = so->contig_len; P->contigs[0].name_off = 0; P->contigs[0].reserved = 0;
+    S->n_fasta = 1; P->read_length = L > 256 ? 256 : L;
+    starts = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(so->n_reads ? so->n_reads : 1));
+    jobs = (long_job *)calloc((size_t)nt, sizeof(long_job)); th = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+    if (!starts || !jobs || !th) { rc = CBC_E_NOMEM; goto done; }
+    {   /* every read may consume up to 2 L reference bases (deletions) */
+        uint64_t span = so->contig_len - 2ull * L - 8;
+        for (uint64_t i = 0; i < so->n_reads; i++) starts[i] = (uint32_t)rng_below(&R, span);
+        qsort(starts, (size_t)so->n_reads, sizeof(uint32_t), cmp_u32);
+    }
+    if (grow((void **)&P->seq, &P->cap_seq, so->n_reads * (uint64_t)L + 8, 1)) { rc = CBC_E_NOMEM; goto done; }
+    for (int t = 0; t < nt; t++) {
+        long_job *J = &jobs[t];
+        J->so = so; J->ref = P->ref; J->starts = starts; J->seq = P->seq; J->name = name; J->want_sam = sam_out != NULL;
+        J->r0 = so->n_reads * (uint64_t)t / (uint64_t)nt; J->r1 = so->n_reads * (uint64_t)(t + 1) / (uint64_t)nt;
+        J->tok_of = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(J->r1 - J->r0 + 1));
+        J->flags = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(J->r1 - J->r0 + 1));
+        if (!J->tok_of || !J->flags) { rc = CBC_E_NOMEM; goto done; }
+    }
+    {
+        int started = 0;
+        for (int t = 0; t < nt; t++) { if (pthread_create(&th[t], NULL, long_gen, &jobs[t]) != 0) break; started++; }
+        for (int t = started; t < nt; t++) long_gen(&jobs[t]);
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    }
+    for (int t = 0; t < nt; t++) if (jobs[t].rc) { rc = jobs[t].rc; goto done; }
+    {   /* block cutting over the reads in order; the SEQ bytes are already in place, the tokens are copied per read */
+        rc = contig_open(S, name, strlen(name));
+        if (rc) goto done;
+        uint64_t ntok = 0;
+        for (int t = 0; t < nt; t++) ntok += jobs[t].n_tok;
+        if (grow((void **)&P->tok, &P->cap_tok, ntok + 1, sizeof(uint32_t))) { rc = CBC_E_NOMEM; goto done; }
+        for (int t = 0; t < nt && !rc; t++) {
+            long_job *J = &jobs[t];
+            for (uint64_t r = J->r0; r < J->r1; r++) {
+                const uint32_t *tk = J->tok + J->tok_of[r - J->r0];
+                uint32_t n = 2 + (tk[0] & 0xffffu);
+                uint64_t to = P->n_tok;
+                rc = place_record(S, starts[r] + 1, J->flags[r - J->r0], L, 0, n);
+                if (rc) break;
+                memcpy(P->tok + to, tk, sizeof(uint32_t) * n);
+            }
+        }
+        if (rc) goto done;
+    }
+    rc = finish_pack(S);
+    if (rc) goto done;
+    if (sam_out) {
+        size_t total = 0;
+        for (int t = 0; t < nt; t++) total += jobs[t].samn;
+        char *sam = (char *)malloc(total + 1);
+        if (!sam) { rc = CBC_E_NOMEM; goto done; }
+        size_t n = 0;
+        for (int t = 0; t < nt; t++) { memcpy(sam + n, jobs[t].sam, jobs[t].samn); n += jobs[t].samn; }
+        *sam_out = sam; *sam_len = n;
+    }
+    if (fasta_out) {
+        uint64_t nlines = (so->contig_len + 59) / 60;
+        size_t cap = (size_t)(so->contig_len + nlines + strlen(name) + 8);
+        char *fa = (char *)malloc(cap); if (!fa) { rc = CBC_E_NOMEM; goto done; }
+        size_t n = (size_t)sprintf(fa, ">%s\n", name);
+        for (uint64_t i = 0; i < so->contig_len; i += 60) {
+            uint64_t c = so->contig_len - i < 60 ? so->contig_len - i : 60;
+            memcpy(fa + n, P->ref + i, (size_t)c); n += (size_t)c; fa[n++] = '\n';
+        }
+        *fasta_out = fa; *fasta_len = n;
+    }
+done:
+    if (jobs) for (int t = 0; t < nt; t++) { free(jobs[t].tok); free(jobs[t].tok_of); free(jobs[t].flags); free(jobs[t].sam); }
+    free(jobs); free(th); free(starts);
+    packer_release(S);
+    if (rc) { cbc_packed_free(S->P); *out = NULL; } else *out = S->P;
+    free(S);
+    return rc;
+}
+
 /* ================================= block container ======================================== */
 /* layout (little-endian), version 2:
  *   u32 magic "CBCB", u32 version, u32 read_length, u32 n_contigs, u32 n_blocks, u32 names_bytes,
@@ -1163,7 +1421,7 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
     uint64_t hb = container_header_bytes(p), total = hb + out_offsets[p->n_blocks];
     if (dst_cap < total) return CBC_E_ARG;
     uint8_t *d = dst;
-    w32(&d, CBC_CONTAINER_MAGIC); w32(&d, CBC_CONTAINER_VERSION); w32(&d, p->read_length);
+    w32(&d, CBC_CONTAINER_MAGIC); w32(&d, p->whole_file == 2 ? CBC_CONTAINER_VERSION_LONG : CBC_CONTAINER_VERSION); w32(&d, p->read_length);
     w32(&d, p->n_contigs); w32(&d, p->n_blocks); w32(&d, p->names_bytes);
     w32(&d, p->caps.cap_pos); w32(&d, p->caps.cap_var); w32(&d, p->max_read_len);
     uint32_t nb = (p->names_bytes + 3u) & ~3u;
@@ -1171,7 +1429,8 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
     for (uint32_t i = 0; i < p->n_contigs; i++) { w32(&d, p->contigs[i].name_off); w32(&d, 0); w64(&d, p->contigs[i].length); }
     for (uint32_t b = 0; b < p->n_blocks; b++) {
         w32(&d, p->info[b].contig); w32(&d, p->info[b].n_reads); w64(&d, p->info[b].window_start);
-        w64(&d, out_offsets[b]); w32(&d, (uint32_t)(out_offsets[b + 1] - out_offsets[b])); w32(&d, 0);
+        w64(&d, out_offsets[b]); w32(&d, (uint32_t)(out_offsets[b + 1] - out_offsets[b]));
+        w32(&d, p->whole_file == 2 ? (uint32_t)p->info[b].n_bases : 0u);     /* version 3: the decoder writes the bases compactly */
     }
     memcpy(d, payloads, (size_t)out_offsets[p->n_blocks]);
     return (int64_t)total;
@@ -1257,13 +1516,14 @@ API int cbc_unpack_plan_create(const uint8_t *blob, uint64_t len, const char *fa
     S->P = (cbc_packed *)calloc(1, sizeof(cbc_packed));
     if (!S->P) { rc = CBC_E_NOMEM; goto fail; }
     if (len < CBC_CONTAINER_HDR || r32(blob) != CBC_CONTAINER_MAGIC) { rc = fail(S, CBC_E_INPUT, "not a cbc block container%s%lld", "", 0); goto fail; }
-    if (r32(blob + 4) != CBC_CONTAINER_VERSION) { rc = fail(S, CBC_E_INPUT, "unsupported container version %s%lld", "", r32(blob + 4)); goto fail; }
+    const int is_long = r32(blob + 4) == CBC_CONTAINER_VERSION_LONG;
+    if (r32(blob + 4) != CBC_CONTAINER_VERSION && !is_long) { rc = fail(S, CBC_E_INPUT, "unsupported container version %s%lld", "", r32(blob + 4)); goto fail; }
     {
         uint32_t L0 = r32(blob + 8), nc = r32(blob + 12), nb = r32(blob + 16), nbytes = r32(blob + 20);
         uint32_t cap_pos = r32(blob + 24), cap_var = r32(blob + 28), max_rl = r32(blob + 32);
         uint64_t names_pad = ((uint64_t)nbytes + 3u) & ~3ull;
         uint64_t hdr = CBC_CONTAINER_HDR + names_pad + 16ull * nc + 32ull * nb;
-        if (hdr > len || L0 < 1 || L0 > 256 || max_rl < 1 || max_rl > CBC_MAX_READ_LEN || cap_pos < 2 || cap_pos > 8192 ||
+        if (hdr > len || L0 < 1 || (L0 > 256 && !is_long) || max_rl < 1 || max_rl > (is_long ? CBC_LONG_MAX_READ_LEN : CBC_MAX_READ_LEN) || cap_pos < 2 || cap_pos > 8192 ||
             cap_var < 1 || cap_var > 32768) { rc = fail(S, CBC_E_INPUT, "corrupt container header%s%lld", "", 0); goto fail; }
         const uint8_t *ctab = blob + CBC_CONTAINER_HDR + names_pad, *btab = ctab + 16ull * nc, *pay = btab + 32ull * nb;
         uint64_t pay_bytes = len - hdr;
@@ -1276,24 +1536,26 @@ API int cbc_unpack_plan_create(const uint8_t *blob, uint64_t len, const char *fa
         u->blocks = (cbc_dec_block_desc *)calloc(nb ? nb : 1, sizeof(cbc_dec_block_desc));
         u->window_start = (uint64_t *)calloc(nb ? nb : 1, sizeof(uint64_t));
         if (!u->blocks || !u->window_start) { rc = CBC_E_NOMEM; goto fail; }
-        uint32_t stride = (max_rl + 3u) & ~3u;
-        uint64_t nrec = 0;
+        uint32_t stride = is_long ? 0u : ((max_rl + 3u) & ~3u);
+        uint64_t nrec = 0, nbases = 0;
         for (uint32_t b = 0; b < nb; b++) {
             const uint8_t *e = btab + 32ull * b;
-            uint32_t contig = r32(e), nreads = r32(e + 4), pbytes = r32(e + 24);
+            uint32_t contig = r32(e), nreads = r32(e + 4), pbytes = r32(e + 24), blk_bases = r32(e + 28);
             uint64_t w0 = r64(e + 8), poff = r64(e + 16);
             /* no sums of file-supplied values: poff + pbytes could wrap */
             if (contig >= nc || poff > pay_bytes || pbytes > pay_bytes - poff || w0 >= S->P->contigs[contig].length + 1 ||
-                nreads > CBC_MAX_BLOCK_READS) {
+                nreads > CBC_MAX_BLOCK_READS || (is_long && (uint64_t)blk_bases > (uint64_t)nreads * CBC_LONG_MAX_READ_LEN)) {
                 rc = fail(S, CBC_E_INPUT, "corrupt block index entry %s%lld", "", b); goto fail; }
             cbc_dec_block_desc *d = &u->blocks[b];
             d->in_off = poff; d->in_bytes = pbytes; d->ref_off = S->P->contigs[contig].ref_off + w0;
-            d->rec_base = nrec; d->seq_base = nrec * stride; d->n_reads = nreads; d->read_length = L0; d->seq_stride = stride;
+            d->rec_base = nrec; d->seq_base = is_long ? nbases : nrec * stride; d->n_reads = nreads; d->read_length = L0; d->seq_stride = stride;
+            d->reserved[0] = is_long ? blk_bases : 0u;
             u->window_start[b] = w0;
-            nrec += nreads;
+            nrec += nreads; nbases += ((uint64_t)blk_bases + 7u) & ~7ull;
         }
         u->n_blocks = nb; u->payloads = pay; u->payload_bytes = pay_bytes; u->caps.cap_pos = cap_pos; u->caps.cap_var = cap_var;
         u->read_length = L0; u->seq_stride = stride; u->n_recs = nrec;
+        u->long_reads = is_long ? 1u : 0u; u->max_read_len = max_rl; u->seq_total = is_long ? nbases + 8 : nrec * stride + 8;
         u->ref = S->P->ref; u->ref_bytes = S->P->ref_bytes; S->P->ref = NULL;
     }
     cbc_packed_free(S->P); free(S);
@@ -1311,6 +1573,18 @@ API int64_t cbc_unpack_write_text(const cbc_unpack_plan *u, const cbc_read_rec *
 {
     if (!u || !recs || !seq || !dst) return CBC_E_ARG;
     uint64_t n = 0;
+    if (u->long_reads) {                                 /* bases are compact: block base + the record's offset */
+        for (uint32_t b = 0; b < u->n_blocks; b++) {
+            const cbc_dec_block_desc *d = &u->blocks[b];
+            for (uint32_t k = 0; k < d->n_reads; k++) {
+                const cbc_read_rec *r = &recs[d->rec_base + k];
+                if ((uint64_t)r->seq_off + r->rlen > d->reserved[0] || n + r->rlen + 1 > cap) return CBC_E_ARG;
+                memcpy(dst + n, seq + d->seq_base + r->seq_off, r->rlen); n += r->rlen;
+                dst[n++] = '\n';
+            }
+        }
+        return (int64_t)n;
+    }
     for (uint64_t r = 0; r < u->n_recs; r++) {
         uint32_t rl = recs[r].rlen;
         if (rl > u->seq_stride || n + rl + 1 > cap) return CBC_E_ARG;

@@ -14,8 +14,9 @@
  *   256 rlength, 256 snps, 256 indels, 2 x CBC_CAP_NAME contig-name pairs, CBC_BLOOM_WORDS Bloom filter,
  *   2 x CBC_P0_WORDS var events of the "p = 0" contexts (one array per strand, two 16-bit events per word) */
 #define CBC_BLOOM_WORDS 256u                        /* 8192 bits, two hash functions (power of two) */
-#define CBC_P0_WORDS    512u                        /* per strand: up to CBC_P0_CAP events of 16 bits */
-#define CBC_P0_CAP      1023u                       /* three 10-bit tallies share one register in the scan */
+#define CBC_P0_WORDS    512u                        /* per strand: 8 buckets (d & 7) of 64 words = 128 events of 16 bits each */
+#define CBC_P0_BUCKET_WORDS 64u                     /* one LDS load per lane scans a whole bucket */
+#define CBC_P0_CAP      128u                        /* events per bucket */
 #define CBC_PLAN_TABLE_WORDS (768u + 2u * CBC_CAP_NAME + CBC_BLOOM_WORDS + 2u * CBC_P0_WORDS)
 #ifndef CBC_BATCH_SLOTS
 #define CBC_BATCH_SLOTS 2u                         /* encoder hand-off ring depth (power of two; 2 measured as good as 4) */

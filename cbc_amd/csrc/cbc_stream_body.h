@@ -99,7 +99,7 @@ CBC_FN void cbc_encode_whole(const cbc_stream_args &A, uint32_t stream, uint32_t
     E.vtab = A.vtab + (uint64_t)slot * CBC_VTAB_WORDS;
     for (uint32_t b = 0; b < CBC_SLDS_RING + CBC_RING_WORDS; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
     W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);      /* the escape: counts[0] = 1 (sam_models.c:132-162) */
-    E.np0 = E.np1 = 0; E.p0over = 0; E.p0ev = nullptr;
+    E.p0cnt = W::splat(0u); E.p0over = 0; E.p0ev = nullptr;
     E.snps_n = L0; E.indels_n = L0;
     E.pos_card = 1u;
     E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
@@ -347,7 +347,7 @@ CBC_FN void cbc_decode_whole(const cbc_dstream_args &A, uint32_t *lds)
     }
     D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
     D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
-    D.np0 = D.np1 = 0; D.p0over = 0;
+    D.p0cnt = W::splat(0u); D.p0over = 0;
 
     if (D.status == CBC_ST_OK) D.t = D.take(26u);                 /* the tag (alloc_arithmetic_stream :260-263) */
     for (uint32_t k = 0; k < 34u && D.status == CBC_ST_OK; k++) {  /* header: int(L0), 32 x int(WELL), int(8) */

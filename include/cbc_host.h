@@ -46,7 +46,7 @@ typedef struct cbc_packed {
     uint64_t         n_bases;
     uint64_t         n_skipped_unmapped;
     uint32_t         max_read_len;                    /* longest SEQ packed                        */
-    uint32_t         whole_file;                      /* 1: packed for the whole-file stream (cbc_pack_opts.whole_file) */
+    uint32_t         whole_file;                      /* 1: packed for the whole-file stream (cbc_pack_opts.whole_file); 2: long-read format */
     /* allocation bookkeeping (private) */
     uint64_t cap_recs, cap_seq, cap_tok, cap_ref; uint32_t cap_names, cap_blocks, cap_contigs;
 } cbc_packed;
@@ -63,7 +63,14 @@ typedef struct cbc_pack_opts {
                              * 32-bit offset would overflow), caps.cap_pos counts the distinct POS steps of the whole
                              * file.  Inputs the reference cannot represent are refused: a POS step of 5 000 000 or
                              * more (MAX_ALPHA, sam_block.h:54), more than CBC_CAP_FLAG distinct FLAG values. */
+    uint32_t long_reads;    /* 1 = the long-read format extension (stream version 3):
+                             * SEQ up to CBC_LONG_MAX_READ_LEN bases and SAM lines of any length (the reference's limits
+                             * are 252 bases / 1023 bytes), tokens = the CIGAR only (MD is ignored: edits are derived from
+                             * read vs reference), blocks cut at block_reads (default 64) or CBC_LONG_BLOCK_BASES bases. */
 } cbc_pack_opts;
+
+#define CBC_LONG_MAX_READ_LEN 65535u
+#define CBC_LONG_BLOCK_BASES  (1u << 20)
 
 void cbc_pack_default_opts(cbc_pack_opts *o);
 
@@ -91,6 +98,14 @@ typedef struct cbc_synth_opts {
 int  cbc_synth_packed(const cbc_synth_opts *so, const cbc_pack_opts *po, cbc_packed **out,
                       char **sam_out, size_t *sam_len, char **fasta_out, size_t *fasta_len,
                       char *errbuf, size_t errlen);
+
+/* cfg5 workload: long reads of `read_len` bases at sorted uniform positions on one uniform-ACGT
+ * contig, FLAG in {0,16}; every aligned base is, with probability `edit_rate`, the site of one edit: substitution,
+ * 1-base insertion or 1-base deletion (one third each).  Packed for the long-read format (long_reads = 1); the
+ * generator runs on `po->n_threads` threads.  sam_out / fasta_out as in cbc_synth_packed (small cases only). */
+int  cbc_synth_long(const cbc_synth_opts *so, const cbc_pack_opts *po, cbc_packed **out,
+                    char **sam_out, size_t *sam_len, char **fasta_out, size_t *fasta_len,
+                    char *errbuf, size_t errlen);
 void cbc_free(void *p);
 
 /* ---- block container (block mode of the CLI) ----------------------------------------------
@@ -98,6 +113,7 @@ void cbc_free(void *p);
  * Every payload follows the reference's stream grammar byte for byte. */
 #define CBC_CONTAINER_MAGIC 0x42434243u   /* "CBCB" little-endian */
 #define CBC_CONTAINER_VERSION 2u
+#define CBC_CONTAINER_VERSION_LONG 3u     /* long-read format: same layout, per-block base counts in the index */
 
 int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets);
 int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
@@ -128,6 +144,9 @@ typedef struct cbc_unpack_plan {
     cbc_lds_caps        caps;
     uint32_t            read_length, seq_stride;
     uint64_t            n_recs;
+    uint32_t            long_reads;                          /* container version 3: blocks[b].reserved[0] = bases of block b, */
+    uint32_t            max_read_len;                        /* blocks[b].seq_base = where they start in the output (compact)  */
+    uint64_t            seq_total;                           /* bytes of bases the decode writes (+ 8 spare)                   */
 } cbc_unpack_plan;
 
 int     cbc_unpack_plan_create(const uint8_t *blob, uint64_t len, const char *fasta, size_t fasta_len,
