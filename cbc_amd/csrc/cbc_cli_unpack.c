@@ -114,12 +114,16 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, const i
     rc = cbc_gpu_init(device, &ctx);
     if (rc) { fprintf(stderr, "cbc: no usable MI355X (cbc_gpu_init = %d); there is no CPU fallback\n", rc); return 1; }
     if (cbc_gpu_upload_reference(ctx, u->ref, u->ref_bytes)) { fprintf(stderr, "cbc: %s\n", cbc_gpu_last_error(ctx)); return 1; }
-    uint64_t seq_bytes = u->n_recs * u->seq_stride + 8;
+    uint64_t seq_bytes = u->long_reads ? u->seq_total : u->n_recs * u->seq_stride + 8;
+    const uint64_t text_cap = (u->long_reads ? u->seq_total : u->n_recs * u->seq_stride) + u->n_recs + 16;
     cbc_read_rec *recs = (cbc_read_rec *)calloc((size_t)(u->n_recs ? u->n_recs : 1), sizeof(cbc_read_rec));
     uint8_t *seq = (uint8_t *)calloc((size_t)seq_bytes, 1);
-    char *text = (char *)malloc((size_t)(u->n_recs * (u->seq_stride + 1) + 16));
+    char *text = (char *)malloc((size_t)text_cap);
     if (!recs || !seq || !text) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
-    if (ndev > 1) {
+    if (u->long_reads) {
+        rc = cbc_gpu_long_decode_blocks(ctx, u->payloads, u->payload_bytes, u->blocks, u->n_blocks, &u->caps, recs, u->n_recs, seq, seq_bytes, NULL);
+        if (rc) { fprintf(stderr, "cbc: decode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
+    } else if (ndev > 1) {
         /* contiguous block ranges balanced by record count, one host thread and one context per device */
         dec_job jobs[16]; pthread_t th[16];
         if (ndev > 16) ndev = 16;
@@ -138,7 +142,7 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, const i
     rc = cbc_gpu_decode_blocks(ctx, u->payloads, u->payload_bytes, u->blocks, u->n_blocks, &u->caps, recs, u->n_recs, seq, seq_bytes, NULL);
     if (rc) { fprintf(stderr, "cbc: decode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
     }
-    int64_t n = cbc_unpack_write_text(u, recs, seq, text, u->n_recs * (u->seq_stride + 1) + 16);
+    int64_t n = cbc_unpack_write_text(u, recs, seq, text, text_cap);
     if (n < 0) { fprintf(stderr, "cbc: text assembly failed\n"); return 1; }
     FILE *fo = fopen(out, "wb");
     if (!fo || fwrite(text, 1, (size_t)n, fo) != (size_t)n || fclose(fo) != 0) { fprintf(stderr, "cbc: cannot write %s\n", out); return 1; }

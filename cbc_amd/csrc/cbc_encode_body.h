@@ -629,6 +629,56 @@ struct CbcEnc {
         encode(b0 + 10u * lt0, 1u + 10u * eq0, n);
     }
 
+
+    /* ---- pos model in its general form (compress_pos read_compression.c:113-159; used by the whole-file stream and
+     * the long-read format): the alphabet in order of appearance in pos_val[], LITERAL counts in pos_occ[] (entry 0
+     * = the escape, count 1), step 10, rescale at 2^20; the four pos_alpha byte models are derived from the
+     * registered values (pos_alpha()).  pos_n = the model's total. ---- */
+    CBC_MFN void pos_lit_update(uint32_t idx, uint32_t &pos_n)
+    {
+        const V32 ln = W::lane();
+        W::write_uni(pos_occ, idx, W::read_uni(pos_occ, idx) + 10u);
+        pos_n += 10u;
+        if (pos_n >= CBC_RESCALE) {
+            V32 a = W::splat(0u);
+            const uint32_t cb = W::uni(pos_card);
+            for (uint32_t b = 0; b < cb; b += 64u) {
+                V32 i = ln + b; Mask m = i < pos_card;
+                V32 c = (W::load32(pos_occ, i, m, 0u) >> 1) + 1u;
+                W::store32(pos_occ, i, c, m);
+                a = a + W::select(m, c, W::splat(0u));
+            }
+            pos_n = W::reduce_add(a);
+        }
+    }
+    CBC_MFN void pos_lit_code(uint32_t x, uint32_t &pos_n)
+    {
+        const V32 ln = W::lane();
+        uint32_t idx = 0;
+        const uint32_t cb = W::uni(pos_card);
+        for (uint32_t b = 0; b < cb; b += 64u) {
+            V32 i = ln + b;
+            V32 v = W::load32(pos_val, i, (i != 0u) & (i < pos_card), 0xffffffffu);
+            uint64_t hit = W::ballot(v == x);
+            if (hit) { idx = b + W::ctz64(hit); break; }
+        }
+        if (idx) {
+            V32 a = W::splat(0u);
+            const uint32_t ib = W::uni(idx);
+            for (uint32_t b = 0; b < ib; b += 64u) { V32 i = ln + b; a = a + W::load32(pos_occ, i, i < idx, 0u); }
+            encode(W::reduce_add(a), W::read_uni(pos_occ, idx), pos_n);
+            pos_lit_update(idx, pos_n);
+            return;
+        }
+        if (pos_card >= cap_pos) { fail(CBC_ST_CAP_POS); return; }
+        encode(0u, W::read_uni(pos_occ, 0u), pos_n);
+        pos_lit_update(0u, pos_n);
+        pos_alpha(x, pos_card);                                /* the four byte models, derived from the registered values */
+        W::write_uni(pos_val, pos_card, x); W::write_uni(pos_occ, pos_card, 0u);
+        pos_card++;
+        pos_lit_update(pos_card - 1u, pos_n);                  /* update_model(P, alphabetCard++) without a send (:153) */
+    }
+
     /* ---- the fixed symbols of 64 records at once, one lane per record ------------------------------
      * A block never holds more than CBC_MAX_BLOCK_READS records, so none of the per-record models
      * (rlength, pos, flag, match, same_ref) reaches its 2^20 rescale point inside a block and each

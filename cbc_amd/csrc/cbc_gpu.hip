@@ -18,6 +18,7 @@
 #include "cbc_decode_body.h"
 #include "cbc_plan.h"
 #include "cbc_stream_body.h"
+#include "cbc_long_body.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 /* internal marker: "use the context's own stream" (host-buffer entry points only) */
@@ -80,6 +81,12 @@ cbc_encode_whole_kernel(cbc_stream_args A)
 
 __global__ void __launch_bounds__(64)
 cbc_decode_whole_kernel(cbc_dstream_args A) { cbc_decode_whole<WaveGPU>(A, cbc_lds); }
+
+/* long-read format (cbc_long_body.h): one wavefront per block */
+__global__ void __launch_bounds__(64)
+cbc_long_encode_kernel(cbc_long_args A) { if (blockIdx.x < A.n_blocks) cbc_long_encode<WaveGPU>(A, blockIdx.x, cbc_lds); }
+__global__ void __launch_bounds__(64)
+cbc_long_decode_kernel(cbc_dec_args A) { if (blockIdx.x < A.n_blocks) cbc_long_decode<WaveGPU>(A, blockIdx.x, cbc_lds); }
 
 /* exclusive scan of the per-block payload sizes -> offsets[n_blocks+1]; one workgroup */
 __global__ void __launch_bounds__(1024)
@@ -172,6 +179,8 @@ API int cbc_gpu_init(int device_ordinal, cbc_gpu_ctx **out)
     (void)hipFuncSetAttribute((const void *)cbc_encode_blocks_kernel_w6, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)cbc_decode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)cbc_encode_whole_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)cbc_long_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)cbc_long_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)cbc_decode_whole_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return CBC_OK;
@@ -604,5 +613,198 @@ done:
 #undef GO
     if (d_in) (void)hipFree(d_in); if (d_co) (void)hipFree(d_co); if (d_cl) (void)hipFree(d_cl); if (d_recs) (void)hipFree(d_recs);
     if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vtab) (void)hipFree(d_vtab);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * long-read format extension
+ * ---------------------------------------------------------------------------------------------- */
+API uint32_t cbc_gpu_long_lds_bytes(const cbc_lds_caps *caps) { return caps ? cbc_long_lds_bytes(caps->cap_pos) : 0; }
+
+/* payload areas: 4096 + 64 per read + bytes_per_16_bases / 16 per base (typical streams need < 1 bit per base; the
+ * worst case, every base an edit with an escaped gap, is 5 symbols of < 20 bits = 12.5 bytes per base = 200) */
+API uint64_t cbc_gpu_long_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_read_rec *recs, uint32_t bytes_per_16_bases)
+{
+    uint64_t off = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        uint64_t bases = 0;
+        for (uint32_t r = 0; r < blocks[b].n_reads; r++) bases += recs[blocks[b].rec_base + r].rlen;
+        uint64_t cap = (4096 + 64ull * blocks[b].n_reads + bases * bytes_per_16_bases / 16 + 255) & ~255ull;
+        if (cap > 0xffffff00ull) cap = 0xffffff00ull;
+        blocks[b].out_off = off; blocks[b].out_cap = (uint32_t)cap; blocks[b].reserved = (uint32_t)cap;
+        off += cap;
+    }
+    return off;
+}
+
+API int cbc_gpu_long_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b, void *hip_stream)
+{
+    if (!ctx || !b) return CBC_E_ARG;
+    if (b->n_blocks == 0) return CBC_OK;
+    if (!b->d_recs || !b->d_seq || !b->d_tok || !b->d_names || !b->d_blocks || !b->d_ref || !b->d_out || !b->d_results)
+        return set_err(ctx, CBC_E_ARG, "null device pointer in cbc_device_batch", hipSuccess);
+    if (b->caps.cap_pos < 2 || b->caps.cap_pos > 8192) return set_err(ctx, CBC_E_ARG, "lds caps out of range", hipSuccess);
+    const uint32_t lds = cbc_long_lds_bytes(b->caps.cap_pos);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t s = hip_stream == CBC_CTX_STREAM ? ctx->stream : (hipStream_t)hip_stream;
+    cbc_long_args A;
+    A.recs = b->d_recs; A.seq = b->d_seq; A.tok = b->d_tok; A.names = b->d_names; A.blocks = b->d_blocks;
+    A.ref = b->d_ref; A.out = b->d_out; A.results = b->d_results;
+    A.ref_bytes = b->ref_bytes; A.out_bytes = b->out_bytes; A.seq_bytes = b->seq_bytes; A.n_tok = b->n_tok;
+    A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.names_bytes = 0x7fffffffu;
+    HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
+    hipLaunchKernelGGL(cbc_long_encode_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
+    HIPCHK(hipGetLastError(), "launch cbc_long_encode_kernel");
+    HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
+    ctx->have_timing = 1; ctx->last_variant = 0;
+    return CBC_OK;
+}
+
+API int cbc_gpu_long_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batch *b, void *hip_stream)
+{
+    if (!ctx || !b) return CBC_E_ARG;
+    if (b->n_blocks == 0) return CBC_OK;
+    if (!b->d_in || !b->d_blocks || !b->d_ref || !b->d_recs || !b->d_seq || !b->d_results)
+        return set_err(ctx, CBC_E_ARG, "null device pointer in cbc_dec_device_batch", hipSuccess);
+    if (b->caps.cap_pos < 2 || b->caps.cap_pos > 8192) return set_err(ctx, CBC_E_ARG, "lds caps out of range", hipSuccess);
+    const uint32_t lds = cbc_long_lds_bytes(b->caps.cap_pos);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t s = hip_stream == CBC_CTX_STREAM ? ctx->stream : (hipStream_t)hip_stream;
+    cbc_dec_args A;
+    memset(&A, 0, sizeof A);
+    A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
+    A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
+    A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = 0;
+    HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
+    hipLaunchKernelGGL(cbc_long_decode_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
+    HIPCHK(hipGetLastError(), "launch cbc_long_decode_kernel");
+    HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
+    ctx->have_timing = 1;
+    return CBC_OK;
+}
+
+/* host buffers in, compacted payloads out; a block whose area was too small (CBC_ST_OUT_FULL) makes the whole batch
+ * run once more with the worst-case areas */
+API int cbc_gpu_long_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_t *out, uint64_t out_cap,
+                                   uint64_t *out_offsets, cbc_block_result *results)
+{
+    if (!ctx || !hb || !out || !out_offsets) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    const uint32_t nb = hb->n_blocks;
+    out_offsets[0] = 0;
+    if (nb == 0) return CBC_OK;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_blocks = NULL, *d_out = NULL, *d_res = NULL, *d_off = NULL, *d_packed = NULL;
+    cbc_block_result *res = NULL;
+    int rc = CBC_OK;
+    uint64_t total = 0, scratch = 0;
+    const uint64_t ntok = hb->n_tok ? hb->n_tok : 1;
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_recs, hb->n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
+    GO(hipMalloc(&d_seq, hb->seq_bytes + 16), "hipMalloc seq");
+    GO(hipMalloc(&d_tok, ntok * 4 + 16), "hipMalloc tok");
+    GO(hipMalloc(&d_names, hb->names_bytes + 16), "hipMalloc names");
+    GO(hipMalloc(&d_blocks, (uint64_t)nb * sizeof(cbc_block_desc)), "hipMalloc blocks");
+    GO(hipMalloc(&d_res, (uint64_t)nb * sizeof(cbc_block_result)), "hipMalloc results");
+    GO(hipMalloc(&d_off, ((uint64_t)nb + 1) * 8), "hipMalloc offsets");
+    GO(hipMemcpyAsync(d_recs, hb->recs, hb->n_recs * sizeof(cbc_read_rec), hipMemcpyHostToDevice, ctx->stream), "H2D recs");
+    GO(hipMemcpyAsync(d_seq, hb->seq, hb->seq_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D seq");
+    GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
+    GO(hipMemcpyAsync(d_names, hb->names, hb->names_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D names");
+    res = results ? results : (cbc_block_result *)malloc((size_t)nb * sizeof(cbc_block_result));
+    if (!res) { rc = CBC_E_NOMEM; goto done; }
+    for (uint32_t attempt = 0; attempt < 2; attempt++) {
+        scratch = cbc_gpu_long_plan_output(hb->blocks, nb, hb->recs, attempt == 0 ? 8u : 200u);     /* 0.5, then 12.5 bytes per base */
+        if (d_out) { (void)hipFree(d_out); d_out = NULL; }
+        GO(hipMalloc(&d_out, scratch), "hipMalloc out scratch");
+        GO(hipMemcpyAsync(d_blocks, hb->blocks, (uint64_t)nb * sizeof(cbc_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
+        GO(hipMemsetAsync(d_res, 0xff, (uint64_t)nb * sizeof(cbc_block_result), ctx->stream), "memset results");
+        cbc_device_batch db;
+        memset(&db, 0, sizeof db);
+        db.d_recs = (const cbc_read_rec *)d_recs; db.d_seq = (const uint8_t *)d_seq; db.d_tok = (const uint32_t *)d_tok;
+        db.d_names = (const uint8_t *)d_names; db.d_blocks = (const cbc_block_desc *)d_blocks; db.n_blocks = nb;
+        db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_out = (uint8_t *)d_out; db.out_bytes = scratch;
+        db.d_results = (cbc_block_result *)d_res; db.seq_bytes = hb->seq_bytes; db.n_tok = ntok; db.n_recs = hb->n_recs; db.caps = hb->caps;
+        rc = cbc_gpu_long_encode_blocks_device(ctx, &db, CBC_CTX_STREAM);
+        if (rc) goto done;
+        GO(hipMemcpyAsync(res, d_res, (uint64_t)nb * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
+        GO(hipStreamSynchronize(ctx->stream), "long encode kernel");
+        int full = 0;
+        for (uint32_t b = 0; b < nb; b++) if (res[b].status == CBC_ST_OUT_FULL) full = 1;
+        if (!full) break;
+    }
+    GO(hipMalloc(&d_packed, scratch), "hipMalloc packed");
+    rc = cbc_gpu_compact_device(ctx, (const uint8_t *)d_out, (const cbc_block_desc *)d_blocks, (const cbc_block_result *)d_res,
+                                nb, (uint64_t *)d_off, (uint8_t *)d_packed, scratch, CBC_CTX_STREAM);
+    if (rc) goto done;
+    GO(hipMemcpyAsync(out_offsets, d_off, ((uint64_t)nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H offsets");
+    GO(hipStreamSynchronize(ctx->stream), "compaction");
+    for (uint32_t b = 0; b < nb; b++)
+        if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
+            snprintf(ctx->err, sizeof ctx->err, "block %u failed with status %u at record %u", b, res[b].status, res[b].fail_read);
+            rc = CBC_E_BLOCK;
+        }
+    total = out_offsets[nb];
+    if (total > out_cap) { rc = set_err(ctx, CBC_E_ARG, "out_cap too small for the compacted payloads", hipSuccess); goto done; }
+    if (total) {
+        GO(hipMemcpyAsync(out, d_packed, total, hipMemcpyDeviceToHost, ctx->stream), "D2H payloads");
+        GO(hipStreamSynchronize(ctx->stream), "D2H payloads");
+    }
+done:
+#undef GO
+    if (res && res != results) free(res);
+    if (d_recs) (void)hipFree(d_recs); if (d_seq) (void)hipFree(d_seq); if (d_tok) (void)hipFree(d_tok);
+    if (d_names) (void)hipFree(d_names); if (d_blocks) (void)hipFree(d_blocks); if (d_out) (void)hipFree(d_out);
+    if (d_res) (void)hipFree(d_res); if (d_off) (void)hipFree(d_off); if (d_packed) (void)hipFree(d_packed);
+    return rc;
+}
+
+API int cbc_gpu_long_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
+                                   uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
+                                   uint8_t *seq, uint64_t seq_bytes, cbc_block_result *results)
+{
+    if (!ctx || !in || !blocks || !caps || !recs || !seq) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    if (n_blocks == 0) return CBC_OK;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    void *d_in = NULL, *d_blocks = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL;
+    cbc_block_result *res = NULL;
+    int rc = CBC_OK;
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_in, in_bytes + 16), "hipMalloc in");
+    GO(hipMalloc(&d_blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc)), "hipMalloc blocks");
+    GO(hipMalloc(&d_recs, n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
+    GO(hipMalloc(&d_seq, seq_bytes + 16), "hipMalloc seq");
+    GO(hipMalloc(&d_res, (uint64_t)n_blocks * sizeof(cbc_block_result)), "hipMalloc results");
+    GO(hipMemsetAsync((uint8_t *)d_in + in_bytes, 0, 16, ctx->stream), "memset pad");
+    GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D payloads");
+    GO(hipMemcpyAsync(d_blocks, blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
+    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)n_blocks * sizeof(cbc_block_result), ctx->stream), "memset results");
+    {
+        cbc_dec_device_batch db;
+        memset(&db, 0, sizeof db);
+        db.d_in = (const uint8_t *)d_in; db.in_bytes = in_bytes + 16; db.d_blocks = (const cbc_dec_block_desc *)d_blocks;
+        db.n_blocks = n_blocks; db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = (cbc_read_rec *)d_recs;
+        db.n_recs = n_recs; db.d_seq = (uint8_t *)d_seq; db.seq_bytes = seq_bytes + 16; db.d_results = (cbc_block_result *)d_res;
+        db.caps = *caps;
+        rc = cbc_gpu_long_decode_blocks_device(ctx, &db, CBC_CTX_STREAM);
+        if (rc) goto done;
+    }
+    res = results ? results : (cbc_block_result *)malloc((size_t)n_blocks * sizeof(cbc_block_result));
+    if (!res) { rc = CBC_E_NOMEM; goto done; }
+    GO(hipMemcpyAsync(res, d_res, (uint64_t)n_blocks * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
+    GO(hipMemcpyAsync(recs, d_recs, n_recs * sizeof(cbc_read_rec), hipMemcpyDeviceToHost, ctx->stream), "D2H recs");
+    GO(hipMemcpyAsync(seq, d_seq, seq_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H seq");
+    GO(hipStreamSynchronize(ctx->stream), "long decode kernel");
+    for (uint32_t b = 0; b < n_blocks; b++)
+        if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
+            snprintf(ctx->err, sizeof ctx->err, "block %u failed to decode with status %u at record %u", b, res[b].status, res[b].fail_read);
+            rc = CBC_E_BLOCK;
+        }
+done:
+#undef GO
+    if (res && res != results) free(res);
+    if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
+    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res);
     return rc;
 }

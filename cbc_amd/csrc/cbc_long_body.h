@@ -1,0 +1,396 @@
+/*
+ * cbc_long_body.h -- the LONG-READ FORMAT EXTENSION (stream version 3).
+ *
+ * The reference cannot code a read longer than 252 bases (var contexts < 65535: sam_models.c:317; MAX_READ_LENGTH
+ * 1024: sam_block.h:38; pos steps < 5e6: :54), so this is a format of its own under its own version number -- no
+ * reference parity exists for it; oracle/cbc_long.c is its independent CPU statement and the tests hold GPU ==
+ * that file byte for byte, and decode(encode(x)) == x.  What is kept from the reference: the range coder, the
+ * adaptive model rule (stream_model.c:31-51), compress_int, the contig-name, pos, FLAG and chars models.
+ *
+ *   stream  := int(0x43424C03) int(8)  record*  same_ref(1) '\n' NUL  flush
+ *   record  := same_ref | name ...        len x 4 (real bytes, MSB first)    pos_sym [esc b3 b2 b1 b0]    flag
+ *              ne_hi ne_lo                { gap [gx_hi gx_lo] kind [base] } x ne
+ *   gap: matched bases since the previous edit, min(g, 255) in context 2 * prev_kind + strand (prev_kind 3 = first
+ *   edit), g >= 255 followed by g - 255 as two bytes; kind: 0 sub, 1 ins / soft clip, 2 del, context prev_kind;
+ *   base: chars[reference base] for a sub, chars[O] for an ins.  Edits are found HERE, from read vs reference along
+ *   the CIGAR (64 bases per compare + ballot); MD is not used.
+ *
+ * One block = one stream = one wavefront (blocks are cut at 64 reads / 1 Mbase, so a 1 M x 10 kb input is ~15 600
+ * streams).  Every model is in its general (rescaling) form: a 10 kb read carries ~500 edits, a block ~100 k
+ * symbols per model.  Dense excess tables in LDS (16 x 256 words), pos alphabet with literal counts.
+ */
+#ifndef CBC_LONG_BODY_H
+#define CBC_LONG_BODY_H
+
+#include "cbc_encode_body.h"
+#include "cbc_decode_body.h"
+
+#define CBC_LONG_MAGIC 0x43424C03u
+/* LDS words: 16 dense tables, the bit ring (encode) / nothing (decode), contig-name pairs, then pos value / count */
+#define CBC_LLDS_LEN    0u         /* 4 x 256 */
+#define CBC_LLDS_NE     1024u      /* 2 x 256 */
+#define CBC_LLDS_GAP    1536u      /* 8 x 256 */
+#define CBC_LLDS_GX     3584u      /* 2 x 256 */
+#define CBC_LLDS_RING   4096u      /* CBC_RING_WORDS (encode); decode: 512 pos_alpha histograms start here */
+#define CBC_LLDS_HIST   4096u
+#define CBC_LLDS_RNKEY  4608u      /* CBC_CAP_NAME */
+#define CBC_LLDS_RNEXC  (4608u + CBC_CAP_NAME)
+#define CBC_LLDS_FIXED  (4608u + 2u * CBC_CAP_NAME)
+static inline uint32_t cbc_long_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_LLDS_FIXED + 2u * cap_pos); }
+
+/* lanes of the "totals" register: the n of each dense table */
+#define CBC_LN_LEN 0u
+#define CBC_LN_NE  4u
+#define CBC_LN_GAP 6u
+#define CBC_LN_GX  14u
+/* kind model (4 contexts x 3, init 1, step 8) in the free lanes of the small lane table: 0-2, 3-5, 10-12, 13-15 */
+CBC_FN uint32_t cbc_long_kind_base(uint32_t pk) { return pk < 2u ? pk * 3u : 10u + (pk - 2u) * 3u; }
+
+struct cbc_long_args {
+    const cbc_read_rec   *recs;
+    const uint8_t        *seq;
+    const uint32_t       *tok;
+    const uint8_t        *names;
+    const cbc_block_desc *blocks;
+    const uint8_t        *ref;
+    uint8_t              *out;
+    cbc_block_result     *results;
+    uint64_t ref_bytes, out_bytes, seq_bytes, n_tok, n_recs;
+    uint32_t n_blocks, cap_pos, names_bytes;
+};
+
+template <class W>
+CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
+{
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+    typedef CbcEnc<W, true> Enc;
+    const V32 ln = W::lane();
+    const cbc_block_desc *bd = A.blocks + blk;
+    Enc E;
+    const uint64_t rec_base = bd->rec_base, seq_base = bd->seq_base, tok_base = bd->tok_base, ref_off = bd->ref_off, out_off = bd->out_off;
+    const uint32_t out_cap = bd->out_cap, n_reads = bd->n_reads, name_off = bd->name_off, n_tok_blk = bd->n_tok;
+
+    E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
+    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
+    E.ring = lds + CBC_LLDS_RING;
+    E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
+    E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
+    E.role = CBC_ROLE_FUSED; E.batch_i = 0; E.batch = nullptr; E.ctl = nullptr;
+    E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
+    E.out32 = (uint32_t *)(A.out + out_off);
+    E.cap_words = out_cap >> 2;
+    bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0u) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
+                   cbc_fits64(tok_base, n_tok_blk, A.n_tok) && (name_off < A.names_bytes) && A.cap_pos >= 2u;
+    if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
+
+    E.L0 = 256u;                                              /* alphabet of the dense tables (var is not used) */
+    E.rlen_exc = lds + CBC_LLDS_LEN; E.snps_exc = nullptr; E.indels_exc = nullptr;
+    E.rname_key = lds + CBC_LLDS_RNKEY; E.rname_exc = lds + CBC_LLDS_RNEXC; E.rn_cap = CBC_CAP_NAME; E.rn_count = 0;
+    E.pos_val = lds + CBC_LLDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = nullptr; E.cap_pos = A.cap_pos;
+    E.bloom = nullptr; E.var_ev = nullptr; E.nev = E.nev1 = 0; E.cap_var = 0; E.vtab = nullptr; E.p0ev = nullptr;
+    E.p0cnt = W::splat(0u); E.p0over = 0;
+    for (uint32_t b = 0; b < CBC_LLDS_RING + CBC_RING_WORDS; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
+    W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);
+    E.snps_n = 0; E.indels_n = 0; E.pos_card = 1u;
+    E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
+    E.hkey = W::splat(0u); E.hexc = W::splat(0u);
+    E.hc0 = E.hc1 = E.hc2 = E.hc3 = 0; E.hn0 = E.hn1 = E.hn2 = E.hn3 = 256u;
+    {   /* lane table: kind contexts (lanes 0-5, 10-15) 1,1,1; same_ref 1,1 (lanes 8, 9); chars rows (16..63) */
+        V32 sm = W::select(ln < 16u, W::splat(1u), W::splat(0u));
+        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
+        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
+        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
+        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
+                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
+        cv = W::select(bump, cv + 8u, cv);
+        E.small = W::select(inch, cv, sm);
+    }
+    E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0; E.win_clear();
+    V32 ntab = W::splat(256u);                                /* totals of the 16 dense tables, lane = table */
+    uint32_t flag_n = 65536u, pos_n = 1u;
+
+    auto tab_code = [&](uint32_t table, uint32_t x) {          /* table: 0-3 len, 4-5 ne, 6-13 gap, 14-15 gx */
+        uint32_t n = W::readlane(ntab, table);
+        E.dense_code(lds + 256u * table, 256u, 10u, x, n);
+        ntab = W::select(ln == table, W::splat(n), ntab);
+    };
+    auto code_int = [&](uint32_t v) {
+        E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 8u, 8u, E.hc1, E.hn1, 256u, 1u, (v >> 16) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
+        E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
+    };
+    if (E.status == CBC_ST_OK) { code_int(CBC_LONG_MAGIC); code_int(8u); E.drain_q(); }
+
+    const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
+    const uint8_t *seqb = A.seq + seq_base;
+    const uint32_t *tokb = A.tok + tok_base;
+    const uint8_t *refb = A.ref + ref_off;
+    const uint64_t seq_avail = cbc_le64(seq_base, A.seq_bytes) ? A.seq_bytes - seq_base : 0;
+    const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
+    const uint32_t seq_lim = cbc_avail32(seq_avail, 0u), ref_lim = cbc_avail32(ref_avail, 0u);
+
+    for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
+        V32 r_pos, r_fl, r_seq, r_tok;
+        const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
+        W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
+        {
+            V32 vrl = r_fl >> 16;
+            Mask live = (ln + c0) < n_reads;
+            Mask bad = live & ((vrl == 0u) | (r_pos == 0u) | (r_seq > seq_lim) | ((seq_lim - r_seq) < vrl) | (r_pos > ref_lim) | (r_tok >= n_tok_blk));
+            uint64_t bb = W::ballot(bad);
+            if (bb) { E.cur_read = c0 + W::ctz64(bb); E.fail(CBC_ST_ASSERT); break; }
+        }
+        for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
+            const uint32_t r = c0 + j;
+            E.cur_read = r;
+            if (E.q_len >= 32u) E.drain_q();
+            if (r == 0u) {
+                E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+                for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
+                    uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
+                    E.rname_code(E.prevChar, ch);
+                    if ((q & 31u) == 31u) E.drain_q();
+                    if (ch == 0u) break;
+                    E.prevChar = ch;
+                }
+                E.drain_q();
+            } else E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
+            const uint32_t pos = W::readlane(r_pos, j), flw = W::readlane(r_fl, j), rl = flw >> 16, strand = (flw >> 4) & 1u;
+            const uint32_t so = W::readlane(r_seq, j), to = W::readlane(r_tok, j);
+            for (uint32_t k = 0; k < 4u; k++) tab_code(CBC_LN_LEN + k, (rl >> (8u * (3u - k))) & 0xffu);
+            /* -- pos: the reference's model (compress_pos read_compression.c:113-159), any 31-bit step -- */
+            if (pos < E.prevPos) { E.fail(CBC_ST_ASSERT); break; }
+            E.pos_lit_code(pos - E.prevPos + 1u, pos_n);
+            E.prevPos = pos;
+            E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);
+            if (E.status != CBC_ST_OK) break;
+
+            /* -- the edits, in read order: pass 0 counts them, pass 1 codes them -- */
+            const uint32_t hdr = W::read_uni(tokb, to), n_cig = hdr & 0xffffu;
+            if (to + 2u + n_cig > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
+            uint32_t ne = 0;
+            for (uint32_t pass = 0; pass < 2u && E.status == CBC_ST_OK; pass++) {
+                const bool emit = pass == 1u;
+                if (emit) {
+                    if (ne > 0xffffu) { E.fail(CBC_ST_ASSERT); break; }
+                    tab_code(CBC_LN_NE, ne >> 8); tab_code(CBC_LN_NE + 1u, ne & 0xffu);
+                }
+                uint32_t i = 0, since = 0, n = 0, pk = 3u; uint32_t jr = pos - 1u;       /* read index, matched run, edits, previous kind, reference index */
+                V32 tokv = W::splat(0u);
+                auto edit = [&](uint32_t kind, uint32_t row, uint32_t base) {
+                    if (++n > 0xffffu) { E.fail(CBC_ST_ASSERT); return; }      /* the edit count is a u16 in the stream */
+                    if (emit) {
+                        if (E.q_len >= 56u) E.drain_q();
+                        const uint32_t g = since;
+                        tab_code(CBC_LN_GAP + 2u * pk + strand, g < 255u ? g : 255u);
+                        if (g >= 255u) { tab_code(CBC_LN_GX, ((g - 255u) >> 8) & 0xffu); tab_code(CBC_LN_GX + 1u, (g - 255u) & 0xffu); }
+                        E.small_code(cbc_long_kind_base(pk), 3u, 8u, kind);
+                        if (kind != 2u) E.small_code(CBC_LT_CHARS + row * 8u, 5u, 8u, base);
+                        pk = kind;
+                    }
+                    since = 0;
+                };
+                for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
+                    if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
+                    const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
+                    if (op == CBC_OP_M) {
+                        if (len > rl - i || jr > ref_lim || len > ref_lim - jr) { E.fail(CBC_ST_ASSERT); break; }
+                        const uint32_t lb = W::uni(len);
+                        for (uint32_t b = 0; b < lb; b += 64u) {
+                            const uint32_t c = len - b < 64u ? len - b : 64u;
+                            const V32 rd = W::load8(seqb + so, ln + (i + b), ln < c), rf = W::load8(refb, ln + (jr + b), ln < c);
+                            uint64_t mm = W::ballot((rd != rf) & (ln < c));
+                            uint32_t next = 0;                              /* first base of the chunk not yet accounted for */
+                            while (mm && E.status == CBC_ST_OK) {
+                                const uint32_t k = W::ctz64(mm); mm &= mm - 1ull;
+                                since += k - next; next = k + 1u;
+                                edit(0u, cbc_basepair(W::readlane(rf, k)), cbc_basepair(W::readlane(rd, k)));
+                            }
+                            since += c - next;
+                        }
+                        i += len; jr += len;
+                    } else if (op == CBC_OP_I || op == CBC_OP_S) {
+                        if (len > rl - i) { E.fail(CBC_ST_ASSERT); break; }
+                        for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) edit(1u, 5u, cbc_basepair(W::read_uni8(seqb + so, i + c)));
+                        i += len;
+                    } else if (op == CBC_OP_D) {
+                        if (jr > ref_lim || len > ref_lim - jr) { E.fail(CBC_ST_ASSERT); break; }
+                        for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) edit(2u, 0u, 0u);
+                        jr += len;
+                    } else { E.fail(CBC_ST_UNSUPPORTED); break; }
+                }
+                if (E.status == CBC_ST_OK && i != rl) E.fail(CBC_ST_ASSERT);   /* the CIGAR must consume the read exactly */
+                if (!emit) ne = n;
+            }
+        }
+    }
+    uint32_t nbytes = 0;
+    if (E.status == CBC_ST_OK) {
+        E.cur_read = n_reads;
+        if (E.q_len >= 32u) E.drain_q();
+        E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+        E.rname_code(E.prevChar, (uint32_t)'\n');
+        E.rname_code((uint32_t)'\n', 0u);
+        E.drain_q();
+    }
+    if (E.status == CBC_ST_OK) { E.flush_recs(); nbytes = E.finish(); }
+    if (E.status != CBC_ST_OK) nbytes = 0;
+    V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),
+               W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
+    W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * decode: records into recs[] (pos block-local, flag, length, offset of the bases inside the block), bases compact
+ * at seq + seq_base.  cbc_dec_block_desc.reserved[0] = bases the block holds (from the container index).
+ * ------------------------------------------------------------------------------------------------------------- */
+template <class W>
+CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
+{
+    typedef typename W::V32 V32;
+    typedef typename W::Mask Mask;
+    const V32 ln = W::lane();
+    const cbc_dec_block_desc *bd = A.blocks + blk;
+    CbcDec<W, true> D;
+    const uint64_t in_off = bd->in_off, ref_off = bd->ref_off, rec_base = bd->rec_base, seq_base = bd->seq_base;
+    const uint32_t in_bytes = bd->in_bytes, n_reads = bd->n_reads, blk_bases = bd->reserved[0];
+
+    D.status = CBC_ST_OK; D.nsym = 0; D.fail_read = 0; D.cur_read = 0;
+    D.l = 0; D.u = CBC_M26; D.t = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
+    D.inb = A.in + in_off;
+    D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = 0; D.L0 = 256u; D.evp = nullptr; D.vtab = nullptr;
+    D.rname_key = lds + CBC_LLDS_RNKEY; D.rname_exc = lds + CBC_LLDS_RNEXC; D.rn_cap = CBC_CAP_NAME; D.histp = lds + CBC_LLDS_HIST;
+    D.pos_valp = lds + CBC_LLDS_FIXED; D.pos_cntp = D.pos_valp + A.cap_pos;
+    bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
+                   cbc_fits64(seq_base, (uint64_t)blk_bases + 8u, A.seq_bytes) && cbc_le64(ref_off, A.ref_bytes) && A.cap_pos >= 2u;
+    D.nwords_in = (in_bytes + 3u) >> 2;
+    D.tail_valid = in_bytes & 3u;
+    if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
+    for (uint32_t b = 0; b < CBC_LLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_LLDS_FIXED);
+    D.rlen_n = 0; D.rl123_c0 = 0; D.rl123_n = 0; D.snps_n = 0; D.indels_n = 0; D.rn_count = 0;
+    D.pos_card = 1u; D.pos_n = 1u; D.nev = 0; D.nev1 = 0;
+    D.pval = W::splat(0xffffffffu); D.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
+    D.fkey = W::splat(0u); D.fexc = W::splat(0u); D.fcount = 0; D.fn = 65536u;
+    D.hkey = W::splat(0u); D.hexc = W::splat(0u);
+    D.hc0 = D.hc1 = D.hc2 = D.hc3 = 0; D.hn0 = D.hn1 = D.hn2 = D.hn3 = 256u;
+    {
+        V32 s = W::select(ln < 16u, W::splat(1u), W::splat(0u));
+        V32 r = (ln - CBC_LT_CHARS) >> 3, c = (ln - CBC_LT_CHARS) & 7u;
+        Mask inch = (ln >= CBC_LT_CHARS) & (r < 6u) & (c < 5u);
+        V32 cv = W::select(c == 4u, W::splat(1u), W::select(c == r, W::splat(0u), W::splat(8u)));
+        Mask bump = ((r == 0u) & ((c == 1u) | (c == 2u))) | ((r == 1u) & ((c == 0u) | (c == 3u))) |
+                    ((r == 2u) & ((c == 0u) | (c == 3u))) | ((r == 3u) & ((c == 1u) | (c == 2u)));
+        cv = W::select(bump, cv + 8u, cv);
+        D.small = W::select(inch, cv, s);
+    }
+    D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
+    D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
+    D.p0cnt = W::splat(0u); D.p0over = 0;
+    V32 ntab = W::splat(256u);
+    auto tab_dec = [&](uint32_t table) -> uint32_t {
+        uint32_t n = W::readlane(ntab, table);
+        uint32_t x = D.dense_dec(lds + 256u * table, 256u, 10u, n);
+        ntab = W::select(ln == table, W::splat(n), ntab);
+        return x;
+    };
+    auto dec_int = [&]() -> uint32_t {
+        uint32_t v = D.regsparse_dec(D.hkey, D.hexc, 0u, 8u, D.hc0, D.hn0, 256u, 1u, CBC_ST_ASSERT) << 24;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 8u, 8u, D.hc1, D.hn1, 256u, 1u, CBC_ST_ASSERT) << 16;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 16u, 8u, D.hc2, D.hn2, 256u, 1u, CBC_ST_ASSERT) << 8;
+        v |= D.regsparse_dec(D.hkey, D.hexc, 24u, 8u, D.hc3, D.hn3, 256u, 1u, CBC_ST_ASSERT);
+        return v;
+    };
+    if (D.status == CBC_ST_OK) D.t = D.take(26u);
+    if (D.status == CBC_ST_OK && dec_int() != CBC_LONG_MAGIC) D.fail(CBC_ST_UNSUPPORTED);
+    if (D.status == CBC_ST_OK && dec_int() != 8u) D.fail(CBC_ST_UNSUPPORTED);
+
+    uint4 *recs4 = (uint4 *)(A.recs + rec_base);
+    uint8_t *seqo = A.seq + seq_base;
+    const uint8_t *refb = A.ref + ref_off;
+    const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
+    const uint32_t ref_lim = cbc_avail32(ref_avail, 0u);
+    uint32_t so = 0;                                             /* bases written so far in this block */
+    /* a run of matched bases is the reference itself: g bytes from refb + jr to seqo + at, 64 per step */
+    auto copy_run = [&](uint32_t at, uint32_t jr, uint32_t g) {
+        const uint32_t gb = W::uni(g);
+        for (uint32_t b = 0; b < gb; b += 64u) {
+            const V32 v = W::load8(refb, ln + (jr + b), (ln + b) < g);
+            W::store8(seqo, ln + (at + b), v, (ln + b) < g);
+        }
+    };
+    for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) {
+        D.cur_read = r;
+        uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
+        if (D.status != CBC_ST_OK) break;
+        if (sr != (r == 0u ? 1u : 0u)) { D.fail(CBC_ST_ASSERT); break; }
+        if (r == 0u) {
+            for (uint32_t q = 0; q < CBC_CAP_NAME && D.status == CBC_ST_OK; q++) {
+                uint32_t ch = D.rname_dec(D.prevChar);
+                if (ch == 0u) break;
+                if (ch == (uint32_t)'\n' && q == 0u) { D.fail(CBC_ST_ASSERT); break; }
+                D.prevChar = ch;
+            }
+            if (D.status != CBC_ST_OK) break;
+        }
+        uint32_t rl = 0;
+        for (uint32_t k = 0; k < 4u && D.status == CBC_ST_OK; k++) rl = (rl << 8) | tab_dec(CBC_LN_LEN + k);
+        if (D.status != CBC_ST_OK) break;
+        if (rl == 0u || rl > 65535u || rl > blk_bases - so) { D.fail(CBC_ST_ASSERT); break; }
+        uint32_t x = D.pos_dec();
+        if (D.status != CBC_ST_OK) break;
+        if (x < 1u) { D.fail(CBC_ST_ASSERT); break; }
+        uint32_t pos = D.prevPos + x - 1u;
+        if (pos < D.prevPos || pos == 0u || pos > ref_lim) { D.fail(CBC_ST_ASSERT); break; }
+        D.prevPos = pos;
+        uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
+        const uint32_t strand = (flag >> 4) & 1u;
+        uint32_t ne = tab_dec(CBC_LN_NE) << 8; ne |= tab_dec(CBC_LN_NE + 1u);
+        if (D.status != CBC_ST_OK) break;
+        uint32_t i = 0, jr = pos - 1u, pk = 3u;
+        for (uint32_t k = 0; k < ne && D.status == CBC_ST_OK; k++) {
+            uint32_t g = tab_dec(CBC_LN_GAP + 2u * pk + strand);
+            if (g == 255u) { uint32_t hi = tab_dec(CBC_LN_GX); g = 255u + ((hi << 8) | tab_dec(CBC_LN_GX + 1u)); }
+            uint32_t kind = D.small_dec(cbc_long_kind_base(pk), 3u, 8u);
+            if (D.status != CBC_ST_OK) break;
+            if (g > rl - i || jr > ref_lim || g > ref_lim - jr) { D.fail(CBC_ST_ASSERT); break; }
+            copy_run(so + i, jr, g);
+            i += g; jr += g;
+            if (kind == 0u) {
+                if (i >= rl || jr >= ref_lim) { D.fail(CBC_ST_ASSERT); break; }
+                uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(W::read_uni8(refb, jr)) * 8u, 5u, 8u);
+                W::store8(seqo, W::splat(so + i), W::splat(cbc_basechar(alt)), ln == 0u);
+                i++; jr++;
+            } else if (kind == 1u) {
+                if (i >= rl) { D.fail(CBC_ST_ASSERT); break; }
+                uint32_t alt = D.small_dec(CBC_LT_CHARS + 5u * 8u, 5u, 8u);
+                W::store8(seqo, W::splat(so + i), W::splat(cbc_basechar(alt)), ln == 0u);
+                i++;
+            } else jr++;
+            pk = kind;
+        }
+        if (D.status != CBC_ST_OK) break;
+        if (jr > ref_lim || rl - i > ref_lim - jr) { D.fail(CBC_ST_ASSERT); break; }
+        copy_run(so + i, jr, rl - i);
+        V32 rv0 = W::splat(pos), rv1 = W::splat(flag | (rl << 16)), rv2 = W::splat(so), rv3 = W::splat(0u);
+        W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
+        so += rl;
+    }
+    if (D.status == CBC_ST_OK) {                                  /* sentinel */
+        D.cur_read = n_reads;
+        uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
+        if (D.status == CBC_ST_OK && sr != 1u) D.fail(CBC_ST_ASSERT);
+        if (D.status == CBC_ST_OK) {
+            uint32_t ch = D.rname_dec(D.prevChar);
+            if (D.status == CBC_ST_OK && ch != (uint32_t)'\n') D.fail(CBC_ST_ASSERT);
+            if (D.status == CBC_ST_OK && D.rname_dec((uint32_t)'\n') != 0u) D.fail(CBC_ST_ASSERT);
+        }
+        if (D.status == CBC_ST_OK && so != blk_bases) D.fail(CBC_ST_ASSERT);      /* container index and stream disagree */
+    }
+    V32 resv = W::select(ln == 0u, W::splat(D.status == CBC_ST_OK ? n_reads : D.cur_read), W::select(ln == 1u, W::splat(D.status),
+               W::select(ln == 2u, W::splat(D.nsym), W::splat(D.fail_read))));
+    W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);
+}
+
+#endif /* CBC_LONG_BODY_H */

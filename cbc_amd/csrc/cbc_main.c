@@ -15,7 +15,8 @@
  * `program -c 1` (-DDEBUG build) writes and readable by its `-x`; one wavefront codes it, so it is slow.
  * `cbc -d` recognises either format.  --devices 0,1,...: one context and one host thread per listed device; whole
  * contigs are dealt to them largest first (encode) / contiguous block ranges (decode); the output does not depend
- * on the device count.
+ * on the device count.  --long: the long-read format extension (stream version 3) -- reads up
+ * to 65535 bases, which the reference cannot code at all; `cbc -d` recognises it by the container version.
  * Exit status: 0 on success (the reference returns 1 on success, src/main.c:370 -- not reproduced).
  *
  * There is no CPU encoder or decoder in this program: without an MI355X it exits with an error.
@@ -40,7 +41,8 @@ static void usage(const char *p)
             "options: -l (header read length = longest read)  --block-reads N (default 4096)  --device N (default 0)\n"
             "         --threads N (SAM parser threads, default one per CPU)  --verbose (stage times)\n"
             "         --compat (write the reference's own single-stream format; slow: one stream = one wavefront)\n"
-            "         --devices 0,1,... (shard the contigs / block ranges over several MI355X, one host thread each)\n", p, p);
+            "         --devices 0,1,... (shard the contigs / block ranges over several MI355X, one host thread each)\n"
+            "         --long (long-read format extension: reads up to 65535 bases, any SAM line length; not a reference format)\n", p, p);
 }
 
 /* Input files are mapped, not copied: the packer only ever reads [0, len). */
@@ -181,7 +183,7 @@ static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, c
 }
 
 static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose, int compat,
-                       const int *devs, int ndev)
+                       const int *devs, int ndev, int long_reads)
 {
     size_t sam_len = 0, fa_len = 0;
     double t0 = now_s();
@@ -194,12 +196,14 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     po.var_length = (uint32_t)var_length;
     po.n_threads = (uint32_t)threads;
     po.whole_file = compat ? 1u : 0u;
+    po.long_reads = long_reads ? 1u : 0u;
+    if (long_reads && !block_reads) po.block_reads = 64;
     cbc_packed *p = NULL;
     int rc = cbc_pack_sam(sam, sam_len, fa, fa_len, &po, &p, err, sizeof err);
     unmap_file(sam, sam_len); unmap_file(fa, fa_len);
     double t1 = now_s();
     if (rc) { fprintf(stderr, "cbc: %s\n", err); return 1; }
-    if (ndev > 1 && !compat) {
+    if (ndev > 1 && !compat && !long_reads) {
         rc = compress_on_devices(p, devs, ndev, out, verbose);
         cbc_packed_free(p);
         return rc;
@@ -236,6 +240,14 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     uint64_t *offs = (uint64_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint64_t));
     if (!payloads || !offs) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
     double t2 = now_s();
+    if (long_reads) {                                             /* stream version 3: reads up to 65535 bases */
+        free(payloads);
+        cap = 8192ull * p->n_blocks + 64ull * p->n_recs + 13ull * p->n_bases;
+        if (p->n_bases > (1ull << 28)) cap = 8192ull * p->n_blocks + 64ull * p->n_recs + 2ull * p->n_bases;
+        payloads = (uint8_t *)malloc(cap);
+        if (!payloads) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
+        rc = cbc_gpu_long_encode_blocks(ctx, &hb, payloads, cap, offs, NULL);
+    } else
     rc = cbc_gpu_encode_blocks(ctx, &hb, payloads, cap, offs, NULL);
     if (rc) { fprintf(stderr, "cbc: encode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
     double t3 = now_s();
@@ -261,7 +273,7 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, const i
 int main(int argc, char **argv)
 {
     const char *files[3] = { 0, 0, 0 };
-    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0;
+    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0, long_reads = 0;
     int devs[CBC_MAX_DEVICES] = { 0 }, ndev = 0;
     uint32_t block_reads = 0;
     for (int i = 1; i < argc; i++) {
@@ -282,6 +294,7 @@ int main(int argc, char **argv)
         if (!strcmp(a, "--threads") && i + 1 < argc) { threads = atoi(argv[++i]); if (threads < 0) threads = 0; continue; }
         if (!strcmp(a, "--verbose")) { verbose = 1; continue; }
         if (!strcmp(a, "--compat")) { compat = 1; continue; }
+        if (!strcmp(a, "--long")) { long_reads = 1; continue; }
         if (!strcmp(a, "-h") || !strcmp(a, "--help")) { usage(argv[0]); return 0; }
         switch (a[1]) {
         case 'c':
@@ -317,6 +330,6 @@ int main(int argc, char **argv)
         return 1;
     }
     if (ndev == 0) { devs[0] = device; ndev = 1; }
-    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat, devs, ndev)
+    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat, devs, ndev, long_reads)
                      : cbc_cli_decompress(files[0], files[1], files[2], devs, ndev);
 }

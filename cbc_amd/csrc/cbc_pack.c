@@ -1051,6 +1051,7 @@ API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t 
     S->P->read_length = header_read_length(sam, sam_len, &off, (int)S->o.var_length);
     if (S->o.long_reads) {
         if (S->P->read_length < 1) S->P->read_length = 1;       /* not part of the long-read stream */
+        if (S->P->read_length > 256) S->P->read_length = 256;
         rc = pack_body_long(S, sam, off, sam_len);
         if (!rc) rc = finish_pack(S);
         goto done;

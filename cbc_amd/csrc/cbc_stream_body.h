@@ -130,48 +130,6 @@ CBC_FN void cbc_encode_whole(const cbc_stream_args &A, uint32_t stream, uint32_t
     }
     E.drain_q();
 
-    /* pos model, general form (compress_pos read_compression.c:113-159): literal counts, step 10 */
-    auto pos_update = [&](uint32_t idx) {
-        W::write_uni(E.pos_occ, idx, W::read_uni(E.pos_occ, idx) + 10u);
-        pos_n += 10u;
-        if (pos_n >= CBC_RESCALE) {
-            V32 a = W::splat(0u);
-            const uint32_t cb = W::uni(E.pos_card);
-            for (uint32_t b = 0; b < cb; b += 64u) {
-                V32 i = ln + b; Mask m = i < E.pos_card;
-                V32 c = (W::load32(E.pos_occ, i, m, 0u) >> 1) + 1u;
-                W::store32(E.pos_occ, i, c, m);
-                a = a + W::select(m, c, W::splat(0u));
-            }
-            pos_n = W::reduce_add(a);
-        }
-    };
-    auto pos_code = [&](uint32_t x) {
-        uint32_t idx = 0;
-        const uint32_t cb = W::uni(E.pos_card);
-        for (uint32_t b = 0; b < cb; b += 64u) {
-            V32 i = ln + b;
-            V32 v = W::load32(E.pos_val, i, (i != 0u) & (i < E.pos_card), 0xffffffffu);
-            uint64_t hit = W::ballot(v == x);
-            if (hit) { idx = b + W::ctz64(hit); break; }
-        }
-        if (idx) {
-            V32 a = W::splat(0u);
-            const uint32_t ib = W::uni(idx);
-            for (uint32_t b = 0; b < ib; b += 64u) { V32 i = ln + b; a = a + W::load32(E.pos_occ, i, i < idx, 0u); }
-            E.encode(W::reduce_add(a), W::read_uni(E.pos_occ, idx), pos_n);
-            pos_update(idx);
-            return;
-        }
-        if (E.pos_card >= E.cap_pos) { E.fail(CBC_ST_CAP_POS); return; }
-        E.encode(0u, W::read_uni(E.pos_occ, 0u), pos_n);
-        pos_update(0u);
-        E.pos_alpha(x, E.pos_card);                            /* the four byte models, derived from the registered values */
-        W::write_uni(E.pos_val, E.pos_card, x); W::write_uni(E.pos_occ, E.pos_card, 0u);
-        E.pos_card++;
-        pos_update(E.pos_card - 1u);                           /* update_model(P, alphabetCard++) without a send (:153) */
-    };
-
     uint32_t prev_name = 0xffffffffu;
     uint64_t rec_index = 0;
     for (uint32_t sg = seg0; sg < seg1 && E.status == CBC_ST_OK; sg++) {
@@ -254,7 +212,7 @@ CBC_FN void cbc_encode_whole(const cbc_stream_args &A, uint32_t stream, uint32_t
                 if (pos < E.prevPos) { E.fail(CBC_ST_ASSERT); break; }                  /* unsorted: x <= 0 aborts there */
                 const uint32_t x = pos - E.prevPos + 1u;
                 if (x >= 5000000u) { E.fail(CBC_ST_ASSERT); break; }                     /* MAX_ALPHA, sam_block.h:54 */
-                pos_code(x);
+                E.pos_lit_code(x, pos_n);
                 E.prevPos = pos;
                 /* -- compress_flag, compress_match -- */
                 E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);

@@ -118,6 +118,18 @@ def lib():
                                             ctypes.c_uint32, ctypes.POINTER(StreamResult)]
         L.cbc_stream_read_length.restype = ctypes.c_uint32
         L.cbc_stream_read_length.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_gpu_long_plan_output.restype = ctypes.c_uint64
+        L.cbc_gpu_long_plan_output.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+        L.cbc_gpu_long_lds_bytes.restype = ctypes.c_uint32
+        L.cbc_gpu_long_lds_bytes.argtypes = [ctypes.POINTER(host.LdsCaps)]
+        L.cbc_gpu_long_encode_blocks_device.restype = ctypes.c_int
+        L.cbc_gpu_long_encode_blocks_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeviceBatch), ctypes.c_void_p]
+        L.cbc_gpu_long_decode_blocks_device.restype = ctypes.c_int
+        L.cbc_gpu_long_decode_blocks_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(DecDeviceBatch), ctypes.c_void_p]
+        L.cbc_gpu_long_encode_blocks.restype = ctypes.c_int
+        L.cbc_gpu_long_encode_blocks.argtypes = L.cbc_gpu_encode_blocks.argtypes
+        L.cbc_gpu_long_decode_blocks.restype = ctypes.c_int
+        L.cbc_gpu_long_decode_blocks.argtypes = L.cbc_gpu_decode_blocks.argtypes
         L.cbc_gpu_last_kernel_variant.restype = ctypes.c_int
         L.cbc_gpu_last_kernel_variant.argtypes = [ctypes.c_void_p]
         L.cbc_gpu_synchronize.restype = ctypes.c_int
@@ -132,7 +144,9 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_upload_reference", "cbc_gpu_encode_blocks", "cbc_gpu_encode_blocks_device", "cbc_gpu_compact_device",
            "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_decode_blocks_device", "cbc_gpu_decode_blocks",
            "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_last_kernel_variant", "cbc_gpu_synchronize",
-           "cbc_gpu_encode_stream", "cbc_gpu_encode_stream_blocks", "cbc_gpu_decode_stream", "cbc_stream_read_length"]
+           "cbc_gpu_encode_stream", "cbc_gpu_encode_stream_blocks", "cbc_gpu_decode_stream", "cbc_stream_read_length",
+           "cbc_gpu_long_plan_output", "cbc_gpu_long_lds_bytes", "cbc_gpu_long_encode_blocks_device",
+           "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks"]
 
 
 class Encoder:
@@ -242,6 +256,41 @@ class Encoder:
                 self._check(rc, "cbc_gpu_decode_stream")
             n = int(sr.nbytes) if sr.status == 0 else 0
             return recs[:n], seq[:n * 256].reshape(n, 256), sr
+
+    def encode_long_blocks(self, pb: "host.PackedBatch"):
+        """Long-read format (pb packed with long_reads=True).  Returns (payload list, results, offsets, flat)."""
+        hb, blocks = self._host_batch(pb)
+        nb = pb.n_blocks
+        cap = int(8192 * nb + 13 * pb.n_bases + 64 * pb.n_recs)
+        cap = min(cap, int(8192 * nb + 2 * pb.n_bases + 64 * pb.n_recs) if pb.n_bases > (1 << 28) else cap)
+        out = np.zeros(cap, dtype=np.uint8)
+        offs = np.zeros(nb + 1, dtype=np.uint64)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        rc = lib().cbc_gpu_long_encode_blocks(self._ctx, ctypes.byref(hb), out.ctypes.data, cap, offs.ctypes.data, res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_long_encode_blocks")
+        return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res, offs, out[:int(offs[nb])]
+
+    def decode_long_blocks(self, plan: "host.UnpackPlan"):
+        """Long-read format: returns (recs, flat bases, results); plan.text(recs, seq) gives the reads."""
+        nb = plan.n_blocks
+        blocks = plan.blocks.copy()
+        recs = np.zeros(plan.n_recs, dtype=host.REC_DTYPE)
+        seq = np.zeros(plan.seq_total + 16, dtype=np.uint8)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        caps = host.LdsCaps(plan.cap_pos, plan.cap_var)
+        pay = np.ascontiguousarray(plan.payloads)
+        rc = lib().cbc_gpu_long_decode_blocks(self._ctx, pay.ctypes.data, pay.size, blocks.ctypes.data, nb, ctypes.byref(caps),
+                                              recs.ctypes.data, plan.n_recs, seq.ctypes.data, plan.seq_total, res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_long_decode_blocks")
+        return recs, seq, res
+
+    def encode_long_device(self, db: DeviceBatch, stream=None):
+        self._check(lib().cbc_gpu_long_encode_blocks_device(self._ctx, ctypes.byref(db), stream), "cbc_gpu_long_encode_blocks_device")
+
+    def decode_long_device(self, db: DecDeviceBatch, stream=None):
+        self._check(lib().cbc_gpu_long_decode_blocks_device(self._ctx, ctypes.byref(db), stream), "cbc_gpu_long_decode_blocks_device")
 
     def decode_device(self, db: DecDeviceBatch, stream=None):
         self._check(lib().cbc_gpu_decode_blocks_device(self._ctx, ctypes.byref(db), stream), "cbc_gpu_decode_blocks_device")

@@ -83,13 +83,14 @@ class UnpackPlanC(ctypes.Structure):
                 ("ref", ctypes.POINTER(ctypes.c_uint8)), ("ref_bytes", ctypes.c_uint64),
                 ("window_start", ctypes.POINTER(ctypes.c_uint64)),
                 ("caps", LdsCaps), ("read_length", ctypes.c_uint32), ("seq_stride", ctypes.c_uint32),
-                ("n_recs", ctypes.c_uint64)]
+                ("n_recs", ctypes.c_uint64), ("long_reads", ctypes.c_uint32), ("max_read_len", ctypes.c_uint32),
+                ("seq_total", ctypes.c_uint64)]
 
 
 class PackOpts(ctypes.Structure):
     _fields_ = [("block_reads", ctypes.c_uint32), ("max_cap_pos", ctypes.c_uint32),
                 ("max_cap_var", ctypes.c_uint32), ("var_length", ctypes.c_uint32),
-                ("n_threads", ctypes.c_uint32), ("whole_file", ctypes.c_uint32)]
+                ("n_threads", ctypes.c_uint32), ("whole_file", ctypes.c_uint32), ("long_reads", ctypes.c_uint32)]
 
 
 class SynthOpts(ctypes.Structure):
@@ -124,6 +125,8 @@ def lib():
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
                                        ctypes.c_char_p, ctypes.c_size_t]
+        L.cbc_synth_long.restype = ctypes.c_int
+        L.cbc_synth_long.argtypes = L.cbc_synth_packed.argtypes
         L.cbc_free.argtypes = [ctypes.c_void_p]
         L.cbc_container_size.restype = ctypes.c_int64
         L.cbc_container_size.argtypes = [ctypes.POINTER(Packed), ctypes.POINTER(ctypes.c_uint64)]
@@ -143,7 +146,8 @@ def lib():
     return _lib
 
 
-def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False, threads=None, whole_file=False):
+def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False, threads=None, whole_file=False,
+          long_reads=False):
     o = PackOpts()
     lib().cbc_pack_default_opts(ctypes.byref(o))
     if block_reads is not None:
@@ -156,6 +160,9 @@ def _opts(block_reads=None, max_cap_pos=None, max_cap_var=None, var_length=False
     if threads is not None:
         o.n_threads = threads                  # 0 = one per online CPU, 1 = serial text path
     o.whole_file = 1 if whole_file else 0      # "compat": one stream per file, the reference's own format
+    o.long_reads = 1 if long_reads else 0      # the long-read format extension (stream version 3)
+    if long_reads and block_reads is None:
+        o.block_reads = 64
     return o
 
 
@@ -204,7 +211,8 @@ class PackedBatch:
         self.n_tok = int(p.n_tok)
         self.n_blocks = int(p.n_blocks)
         self.n_skipped_unmapped = int(p.n_skipped_unmapped)
-        self.whole_file = bool(p.whole_file)
+        self.whole_file = int(p.whole_file) == 1
+        self.long_reads = int(p.whole_file) == 2
         self.max_read_len = int(p.max_read_len)
 
     @property
@@ -267,16 +275,22 @@ def pack_sam(sam: bytes, fasta: bytes, **kw) -> PackedBatch:
     return PackedBatch(out)
 
 
+def synth_long(seed, contig_len, n_reads, read_len=10_000, edit_rate=0.05, name=b"chrL", want_text=False, **kw):
+    """cfg5 workload: long reads with an indel + substitution mix, packed for the long-read format."""
+    return synth(seed, contig_len, n_reads, read_len, edit_rate, 0.0, name, want_text, _long=True, **kw)
+
+
 def synth(seed, contig_len, n_reads, read_len=150, sub_rate=0.003, indel_frac=0.02, name=b"chr1",
-          want_text=False, **kw):
+          want_text=False, _long=False, **kw):
     """Seeded synthetic workload.  Returns PackedBatch, or (PackedBatch, sam, fasta)."""
     so = SynthOpts(seed, contig_len, n_reads, read_len, sub_rate, indel_frac, name)
-    o = _opts(**kw)
+    o = _opts(long_reads=_long, **kw)
     out = ctypes.POINTER(Packed)()
     err = ctypes.create_string_buffer(512)
     sam_p, fa_p = ctypes.c_void_p(), ctypes.c_void_p()
     sam_n, fa_n = ctypes.c_size_t(), ctypes.c_size_t()
-    rc = lib().cbc_synth_packed(ctypes.byref(so), ctypes.byref(o), ctypes.byref(out),
+    fn = lib().cbc_synth_long if _long else lib().cbc_synth_packed
+    rc = fn(ctypes.byref(so), ctypes.byref(o), ctypes.byref(out),
                                 ctypes.byref(sam_p) if want_text else None, ctypes.byref(sam_n),
                                 ctypes.byref(fa_p) if want_text else None, ctypes.byref(fa_n), err, 512)
     if rc != 0:
@@ -314,10 +328,13 @@ class UnpackPlan:
         self.payloads = _np_view(p.payloads, p.payload_bytes, np.uint8)
         self.ref = _np_view(p.ref, p.ref_bytes, np.uint8)
         self.window_start = _np_view(p.window_start, p.n_blocks, np.uint64)
+        self.long_reads = bool(p.long_reads)
+        self.max_read_len = int(p.max_read_len)
+        self.seq_total = int(p.seq_total)
 
     def text(self, recs: np.ndarray, seq: np.ndarray) -> bytes:
         """One reconstructed read per line (what `cbc -d` writes)."""
-        cap = int(self.n_recs) * (self.seq_stride + 1) + 16
+        cap = (int(self.seq_total) + int(self.n_recs) + 16) if self.long_reads else int(self.n_recs) * (self.seq_stride + 1) + 16
         dst = np.zeros(cap, dtype=np.uint8)
         recs = np.ascontiguousarray(recs)
         seq = np.ascontiguousarray(seq)

@@ -260,6 +260,23 @@ int  cbc_gpu_decode_stream(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_byte
 /* header read length of a whole-file stream (its first four bytes come out verbatim), 0 if too short */
 uint32_t cbc_stream_read_length(const uint8_t *in, uint64_t in_bytes);
 
+/* ---- long-read format extension (stream version 3) ------------
+ * Reads up to 65535 bases, POS steps up to 2^31, edits derived from read vs reference along the CIGAR -- everything
+ * the reference's limits (include/sam_block.h:38,54, src/sam_models.c:317) exclude, so this is a format of its own:
+ * no reference parity exists for it (oracle/cbc_long.c is its CPU statement).  Batches come from cbc_pack_sam /
+ * cbc_synth_long with cbc_pack_opts.long_reads = 1; cbc_device_batch / cbc_dec_device_batch are used as in block
+ * mode (caps.cap_var is ignored).  cbc_dec_block_desc.reserved[0] = bases of the block, seq_base = where they go
+ * (the decoder writes the bases compactly; cbc_read_rec.seq_off = offset inside the block). */
+uint64_t cbc_gpu_long_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_read_rec *recs, uint32_t bytes_per_16_bases);
+uint32_t cbc_gpu_long_lds_bytes(const cbc_lds_caps *caps);
+int  cbc_gpu_long_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *batch, void *hip_stream);
+int  cbc_gpu_long_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batch *batch, void *hip_stream);
+int  cbc_gpu_long_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *batch, uint8_t *out, uint64_t out_cap,
+                                uint64_t *out_offsets /* n_blocks+1 */, cbc_block_result *results /* or NULL */);
+int  cbc_gpu_long_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
+                                uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
+                                uint8_t *seq, uint64_t seq_bytes, cbc_block_result *results /* or NULL */);
+
 /* Timing of the most recent encode launch made through this context, measured with HIP events
  * recorded on the launch stream around the kernel (valid after the stream has been synchronised). */
 int  cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms);

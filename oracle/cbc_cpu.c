@@ -188,3 +188,6 @@ ORACLE_API int cbc_cpu_encode_blocks(cbc_cpu_ctx *C, const cbc_host_batch *hb, u
     }
     return rc;
 }
+
+/* the long-read format extension (stream version 3): its CPU statement lives in its own file */
+#include "cbc_long.c"

@@ -23,7 +23,7 @@ class OracleStats(ctypes.Structure):
 
 def build(force=False):
     """Compile the restatement with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, "cbc_oracle.c"), os.path.join(_HERE, "cbc_cpu.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("cbc_oracle.c", "cbc_cpu.c", "cbc_long.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libcbc_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -54,6 +54,11 @@ def lib():
         L.cbc_cpu_encode_blocks.restype = ctypes.c_int
         L.cbc_cpu_encode_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_cpu_long_encode_blocks.restype = ctypes.c_int
+        L.cbc_cpu_long_encode_blocks.argtypes = L.cbc_cpu_encode_blocks.argtypes
+        L.cbc_cpu_long_decode_block.restype = ctypes.c_int64
+        L.cbc_cpu_long_decode_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                                ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
         _lib = L
     return _lib
 
@@ -91,7 +96,7 @@ def decode(stream: bytes, fasta: bytes, max_out: int = None):
     return out.raw[:n], nr.value
 
 
-def cpu_encode_blocks(pb, blocks=None, return_payloads=False):
+def cpu_encode_blocks(pb, blocks=None, return_payloads=False, long_reads=False):
     """The cbc_cpu_* entry points (oracle/cbc_cpu.c): the SAME packed batch the HIP library takes, coded block
     by block on one core.  `blocks` = optional list of block indices (default: all).  Returns the total payload
     bytes, or (list of payload bytes, results array) with return_payloads."""
@@ -108,14 +113,37 @@ def cpu_encode_blocks(pb, blocks=None, return_payloads=False):
         hb = gpu.HostBatch(pb.recs.ctypes.data, pb.n_recs, pb.seq.ctypes.data, len(pb.seq), pb.tok.ctypes.data, pb.n_tok,
                            pb.names.ctypes.data, len(pb.names), bl.ctypes.data, nb, host.LdsCaps(pb.cap_pos, pb.cap_var))
         cap = int(4096 * nb + 48 * int(bl["n_reads"].sum()) + 8 * int(bl["n_tok"].sum())) + 4096
+        if long_reads:
+            cap = int(8192 * nb + 9 * pb.n_bases + 64 * pb.n_recs)
         out = np.zeros(cap, dtype=np.uint8)
         offs = np.zeros(nb + 1, dtype=np.uint64)
         res = np.zeros(nb, dtype=host.RESULT_DTYPE)
-        rc = L.cbc_cpu_encode_blocks(ctx, ctypes.byref(hb), out.ctypes.data, cap, offs.ctypes.data, res.ctypes.data)
+        fn = L.cbc_cpu_long_encode_blocks if long_reads else L.cbc_cpu_encode_blocks
+        rc = fn(ctx, ctypes.byref(hb), out.ctypes.data, cap, offs.ctypes.data, res.ctypes.data)
         if rc not in (0, -4):
             raise OracleError("cbc_cpu_encode_blocks failed: %d" % rc)
         if not return_payloads:
             return int(offs[nb])
         return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res
+    finally:
+        L.cbc_cpu_shutdown(ctx)
+
+
+def cpu_long_decode_block(payload: bytes, ref, ref_off, max_recs, max_bases):
+    """Decode one long-read-format block on the CPU (oracle/cbc_long.c).  Returns (recs, flat bases)."""
+    import numpy as np
+    from cbc_amd import host
+    L = lib()
+    ctx = ctypes.c_void_p()
+    L.cbc_cpu_init(0, ctypes.byref(ctx))
+    try:
+        L.cbc_cpu_upload_reference(ctx, ref.ctypes.data, ref.size)
+        recs = np.zeros(max_recs, dtype=host.REC_DTYPE)
+        seq = np.zeros(max_bases + 16, dtype=np.uint8)
+        buf = np.frombuffer(payload, dtype=np.uint8)
+        n = L.cbc_cpu_long_decode_block(ctx, buf.ctypes.data, buf.size, int(ref_off), recs.ctypes.data, max_recs, seq.ctypes.data, seq.size)
+        if n < 0:
+            raise OracleError("cbc_cpu_long_decode_block failed: %d" % n)
+        return recs[:n], seq
     finally:
         L.cbc_cpu_shutdown(ctx)

@@ -227,3 +227,51 @@ def emu_decode_stream(stream: bytes, ref, contigs, rec_cap, cap_pos=8192, cap_na
         raise RuntimeError("emulation reported an invariant violation")
     n = int(res[0]["nbytes"])
     return recs[:n], seq[:n * stride].reshape(n, stride), res[0]
+
+
+class LongArgs(ctypes.Structure):
+    """cbc_long_args of cbc_amd/csrc/cbc_long_body.h."""
+    _fields_ = [("recs", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("tok", ctypes.c_void_p), ("names", ctypes.c_void_p),
+                ("blocks", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("out", ctypes.c_void_p), ("results", ctypes.c_void_p),
+                ("ref_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64), ("seq_bytes", ctypes.c_uint64),
+                ("n_tok", ctypes.c_uint64), ("n_recs", ctypes.c_uint64),
+                ("n_blocks", ctypes.c_uint32), ("cap_pos", ctypes.c_uint32), ("names_bytes", ctypes.c_uint32)]
+
+
+def emu_long_encode(pb, out_cap_per_base=2.0):
+    """The long-read encoder body on the CPU wave emulation.  Returns (payload list, results)."""
+    L = emu_lib()
+    L.emu_long_encode_blocks.restype = ctypes.c_int
+    L.emu_long_encode_blocks.argtypes = [ctypes.POINTER(LongArgs)]
+    blocks = pb.blocks.copy()
+    off = 0
+    for b in range(pb.n_blocks):
+        cap = (4096 + 64 * int(blocks[b]["n_reads"]) + int(out_cap_per_base * int(pb.info[b]["n_bases"])) + 255) & ~255
+        blocks[b]["out_off"] = off; blocks[b]["out_cap"] = cap
+        off += cap
+    out = np.full(off, 0xAA, dtype=np.uint8)
+    res = np.zeros(pb.n_blocks, dtype=host.RESULT_DTYPE)
+    a = LongArgs(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data, blocks.ctypes.data,
+                 pb.ref.ctypes.data, out.ctypes.data, res.ctypes.data, len(pb.ref), off, len(pb.seq), pb.n_tok, pb.n_recs,
+                 pb.n_blocks, pb.cap_pos, len(pb.names))
+    if L.emu_long_encode_blocks(ctypes.byref(a)) != 0:
+        raise RuntimeError("emulation reported an invariant violation")
+    return [out[int(blocks[b]["out_off"]):int(blocks[b]["out_off"]) + int(res[b]["nbytes"])].tobytes() for b in range(pb.n_blocks)], res
+
+
+def emu_long_decode(plan):
+    """The long-read decoder body on the CPU wave emulation.  Returns (recs, flat bases, results)."""
+    L = emu_lib()
+    L.emu_long_decode_blocks.restype = ctypes.c_int
+    L.emu_long_decode_blocks.argtypes = [ctypes.POINTER(DecDeviceBatch)]
+    blocks = plan.blocks.copy()
+    pay = np.concatenate([np.ascontiguousarray(plan.payloads), np.zeros(16, dtype=np.uint8)])
+    recs = np.zeros(plan.n_recs, dtype=host.REC_DTYPE)
+    seq = np.zeros(plan.seq_total + 16, dtype=np.uint8)
+    res = np.zeros(plan.n_blocks, dtype=host.RESULT_DTYPE)
+    db = DecDeviceBatch(pay.ctypes.data, pay.size, blocks.ctypes.data, plan.n_blocks, plan.ref.ctypes.data, len(plan.ref),
+                        recs.ctypes.data, plan.n_recs, seq.ctypes.data, seq.size, res.ctypes.data, None, 0,
+                        host.LdsCaps(plan.cap_pos, plan.cap_var))
+    if L.emu_long_decode_blocks(ctypes.byref(db)) != 0:
+        raise RuntimeError("emulation reported an invariant violation")
+    return recs, seq, res

@@ -10,6 +10,7 @@
 #include "../../cbc_amd/csrc/cbc_decode_body.h"
 #include "../../cbc_amd/csrc/cbc_plan.h"
 #include "../../cbc_amd/csrc/cbc_stream_body.h"
+#include "../../cbc_amd/csrc/cbc_long_body.h"
 
 static int g_emu_errors = 0;
 #ifdef CBC_EMU_TRACE
@@ -83,5 +84,32 @@ int emu_decode_stream(const cbc_dstream_args *A)
     cbc_stream_caps caps = { A->cap_pos, A->cap_name };
     std::vector<uint32_t> lds(cbc_stream_lds_bytes(&caps) / 4, 0xdeadbeefu);
     cbc_decode_whole<WaveEmu>(*A, lds.data());
+    return g_emu_errors ? -100 : 0;
+}
+
+/* long-read format (cbc_long_body.h) */
+extern "C" __attribute__((visibility("default")))
+int emu_long_encode_blocks(const cbc_long_args *A)
+{
+    g_emu_errors = 0;
+    for (uint32_t blk = 0; blk < A->n_blocks; blk++) {
+        std::vector<uint32_t> lds(cbc_long_lds_bytes(A->cap_pos) / 4, 0xdeadbeefu);
+        cbc_long_encode<WaveEmu>(*A, blk, lds.data());
+    }
+    return g_emu_errors ? -100 : 0;
+}
+extern "C" __attribute__((visibility("default")))
+int emu_long_decode_blocks(const cbc_dec_device_batch *b)
+{
+    cbc_dec_args A;
+    memset(&A, 0, sizeof A);
+    A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
+    A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
+    A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    g_emu_errors = 0;
+    for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
+        std::vector<uint32_t> lds(cbc_long_lds_bytes(A.cap_pos) / 4, 0xdeadbeefu);
+        cbc_long_decode<WaveEmu>(A, blk, lds.data());
+    }
     return g_emu_errors ? -100 : 0;
 }
