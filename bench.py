@@ -51,6 +51,10 @@ def parse_args(argv=None):
     ap.add_argument("--contig-len", type=int, default=CHR1_LEN)
     ap.add_argument("--block-reads", type=int, default=4096)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5"],
+                    help="cfg2 = BASELINE.json's headline (150 bp reads, the reference's format, default); cfg5 = 1 M x 10 kb long "
+                         "reads with a 5 %% indel + substitution mix through the long-read format extension (no reference parity "
+                         "exists for it: the reference cannot code such reads)")
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000,
                     help="records of the same workload timed on one host core by the CPU legs (10 M ~ 11 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -60,7 +64,19 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real path); gloo = rehearsal of the N>1 host logic when "
                          "several ranks must share one GPU (payloads take a detour through host memory)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.workload == "cfg5":                                  # one 100 Mb contig, 1 M x 10 kb, 5 % edits
+        if a.reads == 10_000_000:
+            a.reads = 1_000_000
+        if a.read_len == 150:
+            a.read_len = 10_000
+        if a.contig_len == CHR1_LEN:
+            a.contig_len = 100_000_000
+        if a.block_reads == 4096:
+            a.block_reads = 64
+        if a.cpu_sample_reads == 10_000_000:
+            a.cpu_sample_reads = 100_000                      # 1 Gbase: ~10 s of CPU
+    return a
 
 
 def spawn_ranks(args):
@@ -155,13 +171,20 @@ def run_rank(args):
 
     # ---- workload (cfg2 shape), packed on the host, then made resident ----
     t0 = time.time()
-    seed = 0xCBC00002 + (0 if strong else rank)
-    pb = host.synth(seed, args.contig_len, args.reads, args.read_len, 0.003, 0.02, b"chr1", block_reads=args.block_reads)
+    long_fmt = args.workload == "cfg5"
+    seed = (0xCBC00005 if long_fmt else 0xCBC00002) + (0 if strong else rank)
+    if long_fmt:
+        pb = host.synth_long(seed, args.contig_len, args.reads, args.read_len, 0.05, b"chrL", block_reads=args.block_reads)
+    else:
+        pb = host.synth(seed, args.contig_len, args.reads, args.read_len, 0.003, 0.02, b"chr1", block_reads=args.block_reads)
     t_gen = time.time() - t0
     enc = gpu.Encoder(dev_index)
     L = gpu.lib()
     blocks = pb.blocks.copy()
-    scratch_bytes = int(L.cbc_gpu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data))
+    if long_fmt:
+        scratch_bytes = int(L.cbc_gpu_long_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, 8))
+    else:
+        scratch_bytes = int(L.cbc_gpu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data))
     b0, b1 = shard.shard_ranges(blocks["n_reads"], world)[rank] if strong else (0, pb.n_blocks)
 
     def to_dev(a):
@@ -172,7 +195,7 @@ def run_rank(args):
     d_out = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
     d_res = torch.full((pb.n_blocks * 16,), 0xff, dtype=torch.uint8, device=dev)   # a block that never reports reads as failed
     d_offs = torch.zeros(pb.n_blocks + 1, dtype=torch.int64, device=dev)
-    packed_cap = max(1 << 20, 8 * pb.n_recs)
+    packed_cap = max(1 << 20, 8 * pb.n_recs, pb.n_bases // 8 if long_fmt else 0)
     d_packed = torch.empty(packed_cap, dtype=torch.uint8, device=dev)
     caps = host.LdsCaps(pb.cap_pos, pb.cap_var)
 
@@ -187,7 +210,7 @@ def run_rank(args):
     my_blocks = b1 - b0
     n_recs = int(blocks["n_reads"][b0:b1].sum())
     n_bases = int(pb.info["n_bases"][b0:b1].sum())
-    lds_bytes = int(L.cbc_gpu_lds_bytes(ctypes.byref(caps)))
+    lds_bytes = int((L.cbc_gpu_long_lds_bytes if long_fmt else L.cbc_gpu_lds_bytes)(ctypes.byref(caps)))
 
     gather_cap = None
     gather_list = None
@@ -197,13 +220,13 @@ def run_rank(args):
         d, lo, n = (db, b0, my_blocks) if d is None else (d, lo, n)
         if n == 0:
             return
-        enc.encode_device(d, stream)
+        (enc.encode_long_device if long_fmt else enc.encode_device)(d, stream)
         enc.compact_device(d_out.data_ptr(), d_blocks.data_ptr() + 64 * lo, d_res.data_ptr() + 16 * lo, n,
                            d_offs.data_ptr(), d_packed.data_ptr(), packed_cap, stream)
 
     def step():
         if args.mode == "decode":
-            enc.decode_device(dec["db"], stream)
+            (enc.decode_long_device if long_fmt else enc.decode_device)(dec["db"], stream)
             return
         encode_once()
         if world > 1:
@@ -255,27 +278,43 @@ def run_rank(args):
         dblocks["n_reads"] = blocks["n_reads"][b0:b1]
         rb = np.concatenate([[0], np.cumsum(blocks["n_reads"][b0:b1].astype(np.uint64))])[:-1]
         dblocks["rec_base"] = rb
-        dblocks["seq_base"] = rb * stride
-        dblocks["read_length"] = args.read_len
+        if long_fmt:                                          # bases are written compactly: block base = bases before it
+            nbv = pb.info["n_bases"][b0:b1].astype(np.uint64)
+            dblocks["seq_base"] = np.concatenate([[0], np.cumsum((nbv + 7) & ~np.uint64(7))])[:-1]
+            dblocks["reserved"][:, 0] = nbv.astype(np.uint32)
+            stride = 0
+            seq_out_bytes = int(((nbv + 7) & ~np.uint64(7)).sum()) + 16
+        else:
+            dblocks["seq_base"] = rb * stride
+            seq_out_bytes = n_recs * stride + 16
+        dblocks["read_length"] = min(args.read_len, 256)
         dblocks["seq_stride"] = stride
         dec = {"blocks": to_dev(dblocks),
                "recs": torch.zeros(n_recs * 16, dtype=torch.uint8, device=dev),
-               "seq": torch.zeros(n_recs * stride + 16, dtype=torch.uint8, device=dev),
+               "seq": torch.zeros(seq_out_bytes, dtype=torch.uint8, device=dev),
                "res": torch.full((my_blocks * 16,), 0xff, dtype=torch.uint8, device=dev),
                "vs": torch.zeros(max(my_blocks * pb.cap_var, 1), dtype=torch.int32, device=dev)}
         dec["db"] = gpu.DecDeviceBatch(d_packed.data_ptr(), packed_cap, dec["blocks"].data_ptr(), my_blocks,
                                        d_ref.data_ptr(), d_ref.numel(), dec["recs"].data_ptr(), n_recs,
                                        dec["seq"].data_ptr(), dec["seq"].numel(), dec["res"].data_ptr(),
                                        dec["vs"].data_ptr(), dec["vs"].numel(), caps)
-        enc.decode_device(dec["db"], stream)
+        (enc.decode_long_device if long_fmt else enc.decode_device)(dec["db"], stream)
         torch.cuda.synchronize()
         dres = dec["res"].cpu().numpy().view(host.RESULT_DTYPE)
         if (dres["status"] != 0).any():
             raise SystemExit("decode failed: %r" % (dres[dres["status"] != 0][:1],))
         r0 = int(blocks["rec_base"][b0]) if my_blocks else 0
-        got = dec["seq"][:n_recs * stride].view(n_recs, stride)[:, :args.read_len].cpu().numpy()
-        if not (got == pb.seq[r0 * args.read_len:(r0 + n_recs) * args.read_len].reshape(n_recs, args.read_len)).all():
-            raise SystemExit("decode does not reproduce the packed bases")
+        if long_fmt:                                          # fixed-length synthetic reads: every block's bases are contiguous on both sides
+            got = dec["seq"].cpu().numpy()
+            for k in range(my_blocks):
+                o, nbk, s0 = int(dblocks["seq_base"][k]), int(dblocks["reserved"][k][0]), int(blocks["seq_base"][b0 + k])
+                if not (got[o:o + nbk] == pb.seq[s0:s0 + nbk]).all():
+                    raise SystemExit("decode does not reproduce the packed bases (block %d)" % (b0 + k))
+            del got
+        else:
+            got = dec["seq"][:n_recs * stride].view(n_recs, stride)[:, :args.read_len].cpu().numpy()
+            if not (got == pb.seq[r0 * args.read_len:(r0 + n_recs) * args.read_len].reshape(n_recs, args.read_len)).all():
+                raise SystemExit("decode does not reproduce the packed bases")
 
     for _ in range(args.warmup):
         step()
@@ -312,19 +351,33 @@ def run_rank(args):
     ms_per_step = elapsed * 1e3 / args.steps
     value = total_bases * args.steps / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
-    alg_bytes = (2 * args.read_len + 18) * n_recs          # per launch, this rank
+    n_tok_mine = int(blocks["n_tok"][b0:b1].sum())
+    # per launch, this rank: read + reference bases + 16 B record + ~2 B out; long reads also carry their CIGAR tokens
+    alg_bytes = (2 * args.read_len + 18) * n_recs + (4 * n_tok_mine if long_fmt else 0)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
     # HBM traffic and issue-port counters per launch: PMC counters cannot be read from inside this process; the
     # committed rocprofv3 passes of this same command (profiles/README.md) are reported for the default workload.
     traffic, traffic_src, issue = None, None, None
-    if args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096 and not strong:
+    if args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096 and not strong and not long_fmt:
         traffic, traffic_src, issue = issue_picture(
             ROOT, "r*_pmc_hbm.json" if args.mode == "encode" else "r*_decode_pmc.json", k_ms, n_recs)
 
     cpu = None
     whole_file_bits = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and long_fmt:
+        from oracle import oracle                            # the format's CPU statement, timed as the reported baseline
+        sample = min(args.cpu_sample_reads, args.reads)
+        spb = host.synth_long(0xCBC00005, args.contig_len, sample, args.read_len, 0.05, b"chrL", block_reads=args.block_reads)
+        t1 = time.perf_counter()
+        cbytes = oracle.cpu_encode_blocks(spb, long_reads=True)
+        t_blk = time.perf_counter() - t1
+        cpu = {"value": round(spb.n_bases / t_blk / 1e6, 2), "unit": "Mbases/s", "cores": 1, "kind": "port",
+               "sample": "%d reads x %d bp of the same synthetic workload as packed blocks (no text parsing), oracle/cbc_long.c "
+                         "block by block, %.1f s of CPU; the format has no reference implementation" % (sample, args.read_len, t_blk),
+               "host_cpus": os.cpu_count(), "payload_bytes": int(cbytes)}
+        spb.close()
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle                            # checker, timed as the reported baseline
         sample = min(args.cpu_sample_reads, args.reads)
         spb, sam, fa = host.synth(0xCBC00002, args.contig_len, sample, args.read_len, 0.003, 0.02, b"chr1",
@@ -352,14 +405,16 @@ def run_rank(args):
     if rank == 0:
         n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         out = {
-            "metric": "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM" if args.mode == "encode"
+            "metric": ("Mbases/s %s on synthetic 10 kb long-read SAM (format extension v3: no reference parity exists)" % (
+                           "encoded (== CPU statement of the format)" if args.mode == "encode" else "decoded (round trip verified)")) if long_fmt else
+                      "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM" if args.mode == "encode"
                       else "Mbases/s decoded (round trip verified) on synthetic 150 bp SAM",
             "value": round(value, 2), "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %d bp SAM, %d reads %s vs a chr1-sized (%d bp) uniform-ACGT "
+            "config": {"workload": "%s: synthetic %d bp SAM, %d reads %s vs a %d bp uniform-ACGT "
                                    "contig, block-parallel %s" % (
-                                       {10_000_000: "cfg2", 49_791_284: "cfg3 (30x)"}.get(args.reads, "custom"),
+                                       "cfg5 (long reads, 5 %% edits)" if long_fmt else {10_000_000: "cfg2", 49_791_284: "cfg3 (30x)"}.get(args.reads, "custom"),
                                        args.read_len, args.reads, "in total" if strong else "per GPU", args.contig_len, args.mode),
                        "reads_rank0": n_recs, "blocks_rank0": my_blocks, "block_reads": args.block_reads,
                        "lds_bytes_per_block": lds_bytes, "payload_bytes_rank0": payload_bytes,
@@ -371,7 +426,8 @@ def run_rank(args):
                        "host_pack_seconds": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "cbc_%s_blocks_kernel%s" % (args.mode, "_w6" if args.mode == "encode" and my_blocks > 10 * n_cus else ""),
+                         "kernel": ("cbc_long_%s_kernel" % args.mode) if long_fmt else
+                                   "cbc_%s_blocks_kernel%s" % (args.mode, "_w6" if args.mode == "encode" and my_blocks > 10 * n_cus else ""),
                          "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
                          "issue": issue},
             "cpu_baseline": cpu,
