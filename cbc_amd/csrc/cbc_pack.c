@@ -1057,7 +1057,7 @@ API int cbc_pack_sam(const char *sam, size_t sam_len, const char *fasta, size_t 
         goto done;
     }
     if (S->P->read_length < 1 || S->P->read_length > 256) {
-        rc = fail(S, CBC_E_INPUT, "header read length %s%lld outside 1..256", "", S->P->read_length); goto done;
+        rc = fail(S, CBC_E_INPUT, "header read length %s%lld outside 1..256 (the reference's limit is 252 bases per read; longer reads need the long-read format: cbc --long / long_reads)", "", S->P->read_length); goto done;
     }
     if (S->o.n_threads != 1) {
         int nt = (int)S->o.n_threads;
@@ -1435,6 +1435,97 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
     }
     memcpy(d, payloads, (size_t)out_offsets[p->n_blocks]);
     return (int64_t)total;
+}
+
+
+/* ================================= 2-bit transport ======================= */
+typedef struct { const uint8_t *b; uint32_t *codes; uint64_t i0, i1; cbc_2bit_run *runs; uint64_t n_runs, cap_runs; int rc; } twobit_job;
+
+static inline uint32_t base_code(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
+
+static void *twobit_run(void *arg)
+{
+    twobit_job *J = (twobit_job *)arg;                     /* [i0, i1) is a multiple of 16 bases except at the very end */
+    const uint8_t *b = J->b;
+    for (uint64_t i = J->i0; i < J->i1; i += 16) {
+        uint32_t w = 0;
+        const uint64_t e = i + 16 < J->i1 ? i + 16 : J->i1;
+        for (uint64_t k = i; k < e; k++) {
+            uint32_t c = base_code(b[k]);
+            if (c < 4u) w |= c << (2u * (uint32_t)(k & 15u));
+            else {                                          /* an exception: extend the current run or open one */
+                cbc_2bit_run *last = J->n_runs ? &J->runs[J->n_runs - 1] : NULL;
+                if (last && last->start + last->length == k && last->byte == b[k] && last->length < 0xffffffffu) last->length++;
+                else {
+                    if (grow((void **)&J->runs, &J->cap_runs, J->n_runs + 1, sizeof(cbc_2bit_run))) { J->rc = CBC_E_NOMEM; return NULL; }
+                    J->runs[J->n_runs].start = k; J->runs[J->n_runs].length = 1; J->runs[J->n_runs].byte = b[k]; J->n_runs++;
+                }
+            }
+        }
+        J->codes[i >> 4] = w;
+    }
+    return NULL;
+}
+
+API void cbc_2bit_free(cbc_2bit *p) { if (p) { free(p->codes); free(p->runs); free(p); } }
+
+API int cbc_2bit_pack(const uint8_t *bases, uint64_t n, uint32_t n_threads, cbc_2bit **out)
+{
+    if (!bases || !out) return CBC_E_ARG;
+    *out = NULL;
+    int nt = n_threads ? (int)n_threads : online_cpus();
+    if (nt > 64) nt = 64;
+    if (n < ((uint64_t)1 << 22)) nt = 1;
+    cbc_2bit *P = (cbc_2bit *)calloc(1, sizeof(cbc_2bit));
+    twobit_job *jobs = (twobit_job *)calloc((size_t)nt, sizeof(twobit_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+    int rc = 0;
+    if (!P || !jobs || !th) { rc = CBC_E_NOMEM; goto done; }
+    P->n_bases = n;
+    P->codes = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)((n + 15) / 16 + 1));
+    if (!P->codes) { rc = CBC_E_NOMEM; goto done; }
+    {
+        const uint64_t words = (n + 15) / 16;
+        int started = 0;
+        for (int t = 0; t < nt; t++) {
+            jobs[t].b = bases; jobs[t].codes = P->codes;
+            jobs[t].i0 = words * (uint64_t)t / (uint64_t)nt * 16; jobs[t].i1 = (t == nt - 1) ? n : words * (uint64_t)(t + 1) / (uint64_t)nt * 16;
+            if (jobs[t].i1 > n) jobs[t].i1 = n;
+        }
+        for (int t = 0; t < nt; t++) { if (pthread_create(&th[t], NULL, twobit_run, &jobs[t]) != 0) break; started++; }
+        for (int t = started; t < nt; t++) twobit_run(&jobs[t]);
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    }
+    {   /* concatenate the threads' runs, merging a run that continues across a boundary */
+        uint64_t total = 0;
+        for (int t = 0; t < nt; t++) { if (jobs[t].rc) rc = jobs[t].rc; total += jobs[t].n_runs; }
+        if (rc) goto done;
+        P->runs = (cbc_2bit_run *)malloc(sizeof(cbc_2bit_run) * (size_t)(total ? total : 1));
+        if (!P->runs) { rc = CBC_E_NOMEM; goto done; }
+        for (int t = 0; t < nt; t++)
+            for (uint64_t k = 0; k < jobs[t].n_runs; k++) {
+                cbc_2bit_run *r = &jobs[t].runs[k], *last = P->n_runs ? &P->runs[P->n_runs - 1] : NULL;
+                if (last && last->start + last->length == r->start && last->byte == r->byte && (uint64_t)last->length + r->length <= 0xffffffffull) last->length += r->length;
+                else P->runs[P->n_runs++] = *r;
+            }
+    }
+    *out = P; P = NULL;
+done:
+    if (jobs) for (int t = 0; t < nt; t++) free(jobs[t].runs);
+    free(jobs); free(th); cbc_2bit_free(P);
+    return rc;
+}
+
+API int cbc_2bit_unpack(const cbc_2bit *p, uint8_t *bases)
+{
+    if (!p || !bases) return CBC_E_ARG;
+    static const char ACGT[4] = { 'A', 'C', 'G', 'T' };
+    for (uint64_t i = 0; i < p->n_bases; i++) bases[i] = (uint8_t)ACGT[(p->codes[i >> 4] >> (2u * (uint32_t)(i & 15u))) & 3u];
+    for (uint64_t k = 0; k < p->n_runs; k++) {
+        if (p->runs[k].start + p->runs[k].length > p->n_bases) return CBC_E_INPUT;
+        memset(bases + p->runs[k].start, (int)p->runs[k].byte, p->runs[k].length);
+    }
+    return 0;
 }
 
 /* ================================= sharding =============================================== */

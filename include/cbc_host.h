@@ -119,6 +119,22 @@ int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets);
 int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
                             uint8_t *dst, uint64_t dst_cap);
 
+/* ---- 2-bit transport of bases ------------------------------------------------
+ * Bases travel to the device (reference, reads) and back (decoded reads) at 2 bits each: A C G T = 0 1 2 3, sixteen
+ * bases per 32-bit word, base i in bits 2 (i & 15) of word i >> 4.  Every byte that is not one of 'A' 'C' 'G' 'T'
+ * ('N', other IUPAC letters, the zero pad behind a contig) is an EXCEPTION, kept exactly: runs of one repeated byte
+ * as (start, length, byte) -- an N-run of a chromosome is one entry -- so that unpacking restores the byte array
+ * bit for bit (the match test compares bytes: src/read_compression.c:291-296).  cbc_2bit_pack runs on n_threads
+ * threads (0 = one per CPU); cbc_2bit_unpack is the host inverse (the device inverse is cbc_gpu_expand_2bit). */
+typedef struct cbc_2bit_run { uint64_t start; uint32_t length; uint32_t byte; } cbc_2bit_run;
+typedef struct cbc_2bit {
+    uint32_t     *codes;   uint64_t n_bases;     /* (n_bases + 15) / 16 words */
+    cbc_2bit_run *runs;    uint64_t n_runs;      /* sorted by start, disjoint  */
+} cbc_2bit;
+int  cbc_2bit_pack(const uint8_t *bases, uint64_t n_bases, uint32_t n_threads, cbc_2bit **out);
+int  cbc_2bit_unpack(const cbc_2bit *p, uint8_t *bases /* n_bases */);
+void cbc_2bit_free(cbc_2bit *p);
+
 /* ---- sharding over devices ---------------------------------------------------------
  * Blocks are independent streams; a contig's blocks share its reference, so whole contigs are dealt to the parts,
  * largest first, each to the part with the least records so far (cfg4: chromosome-sharded).  part_of_contig[c]
