@@ -88,6 +88,63 @@ cbc_long_encode_kernel(cbc_long_args A) { if (blockIdx.x < A.n_blocks) cbc_long_
 __global__ void __launch_bounds__(64)
 cbc_long_decode_kernel(cbc_dec_args A) { if (blockIdx.x < A.n_blocks) cbc_long_decode<WaveGPU>(A, blockIdx.x, cbc_lds); }
 
+/* ---- 2-bit transport (include/cbc_gpu.h): expand = one code word per lane -> 16 bases, one 16-byte store per lane ---- */
+__global__ void __launch_bounds__(256)
+cbc_expand_2bit_kernel(const uint32_t *__restrict__ codes, uint64_t n_words, uint8_t *__restrict__ out, uint64_t n_bases)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t c = codes[w];
+    uint32_t v[4];
+    for (int q = 0; q < 4; q++) {
+        uint32_t x = 0;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t code = (c >> (2 * (4 * q + k))) & 3u;
+            x |= (uint32_t)("ACGT"[code]) << (8 * k);
+        }
+        v[q] = x;
+    }
+    const uint64_t b0 = w * 16;
+    if (b0 + 16 <= n_bases && ((uintptr_t)(out + b0) & 15) == 0) *(uint4 *)(out + b0) = make_uint4(v[0], v[1], v[2], v[3]);
+    else for (int k = 0; k < 16 && b0 + k < n_bases; k++) out[b0 + k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+}
+/* exception runs: workgroup = run, threads stride over its bytes */
+__global__ void __launch_bounds__(256)
+cbc_apply_runs_kernel(const cbc_2bit_run_dev *__restrict__ runs, uint64_t n_runs, uint8_t *__restrict__ out, uint64_t n_bases)
+{
+    const uint64_t r = blockIdx.x;
+    if (r >= n_runs) return;
+    const uint64_t s0 = runs[r].start; const uint32_t len = runs[r].length; const uint8_t b = (uint8_t)runs[r].byte;
+    if (s0 > n_bases || len > n_bases - s0) return;
+    for (uint32_t i = threadIdx.x; i < len; i += 256) out[s0 + i] = b;
+}
+/* pack decoded reads: thread = one 16-base word of one read row; bases past the read's length are not looked at */
+__global__ void __launch_bounds__(256)
+cbc_pack_2bit_kernel(const uint8_t *__restrict__ seq, const cbc_read_rec *__restrict__ recs, uint64_t n_recs, uint32_t stride,
+                     uint32_t *__restrict__ codes, uint64_t *__restrict__ exc_idx, uint8_t *__restrict__ exc_val,
+                     uint64_t exc_cap, unsigned long long *__restrict__ n_exc)
+{
+    const uint32_t row_words = stride >> 4;
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_recs * row_words) return;
+    const uint64_t r = w / row_words; const uint32_t k0 = (uint32_t)(w % row_words) * 16u;
+    const uint32_t rl = recs[r].rlen;
+    const uint4 raw = *(const uint4 *)(seq + r * stride + k0);             /* rows are 16-byte aligned (stride % 16 == 0) */
+    const uint32_t v[4] = { raw.x, raw.y, raw.z, raw.w };
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < 16u; k++) {
+        if (k0 + k >= rl) break;
+        const uint8_t b = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+        const uint32_t code = b == 'A' ? 0u : b == 'C' ? 1u : b == 'G' ? 2u : b == 'T' ? 3u : 4u;
+        if (code < 4u) c |= code << (2 * k);
+        else {
+            const unsigned long long at = atomicAdd(n_exc, 1ull);
+            if (at < exc_cap) { exc_idx[at] = r * stride + k0 + k; exc_val[at] = b; }
+        }
+    }
+    codes[w] = c;
+}
+
 /* exclusive scan of the per-block payload sizes -> offsets[n_blocks+1]; one workgroup */
 __global__ void __launch_bounds__(1024)
 cbc_scan_sizes_kernel(const cbc_block_result *__restrict__ results, uint64_t *__restrict__ offsets, uint32_t n_blocks)
@@ -280,9 +337,61 @@ API int cbc_gpu_compact_device(cbc_gpu_ctx *ctx, const uint8_t *d_scratch, const
     return CBC_OK;
 }
 
+static int expand_2bit(cbc_gpu_ctx *ctx, const uint32_t *codes, uint64_t n_bases, const cbc_2bit_run_dev *runs, uint64_t n_runs,
+                       uint8_t *d_out, void **d_tmp_codes, void **d_tmp_runs)
+{
+    const uint64_t n_words = (n_bases + 15) / 16;
+    if (n_words == 0) return CBC_OK;
+    if (n_runs > 0x7fffffffull || n_words > 0x7fffffffull * 256ull) return set_err(ctx, CBC_E_ARG, "2-bit transport: too many words or runs", hipSuccess);
+    HIPCHK(hipMalloc(d_tmp_codes, n_words * 4), "hipMalloc 2-bit codes");
+    HIPCHK(hipMemcpyAsync(*d_tmp_codes, codes, n_words * 4, hipMemcpyHostToDevice, ctx->stream), "H2D 2-bit codes");
+    hipLaunchKernelGGL(cbc_expand_2bit_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)*d_tmp_codes, n_words, d_out, n_bases);
+    HIPCHK(hipGetLastError(), "launch cbc_expand_2bit_kernel");
+    if (n_runs) {
+        HIPCHK(hipMalloc(d_tmp_runs, n_runs * sizeof(cbc_2bit_run_dev)), "hipMalloc 2-bit runs");
+        HIPCHK(hipMemcpyAsync(*d_tmp_runs, runs, n_runs * sizeof(cbc_2bit_run_dev), hipMemcpyHostToDevice, ctx->stream), "H2D 2-bit runs");
+        hipLaunchKernelGGL(cbc_apply_runs_kernel, dim3((unsigned)n_runs), dim3(256), 0, ctx->stream,
+                           (const cbc_2bit_run_dev *)*d_tmp_runs, n_runs, d_out, n_bases);
+        HIPCHK(hipGetLastError(), "launch cbc_apply_runs_kernel");
+    }
+    return CBC_OK;
+}
+
+API int cbc_gpu_upload_reference_2bit(cbc_gpu_ctx *ctx, const uint32_t *codes, uint64_t n_bases, const cbc_2bit_run_dev *runs, uint64_t n_runs)
+{
+    if (!ctx || !codes || n_bases == 0 || (n_runs && !runs)) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->d_ref) { (void)hipFree(ctx->d_ref); ctx->d_ref = NULL; ctx->ref_bytes = 0; }
+    HIPCHK(hipMalloc((void **)&ctx->d_ref, n_bases + 16), "hipMalloc(reference)");
+    void *d_codes = NULL, *d_runs = NULL;
+    int rc = expand_2bit(ctx, codes, n_bases, runs, n_runs, ctx->d_ref, &d_codes, &d_runs);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(ctx, CBC_E_NODEV, "2-bit reference expansion", hipGetLastError());
+    if (d_codes) (void)hipFree(d_codes); if (d_runs) (void)hipFree(d_runs);
+    if (rc) { (void)hipFree(ctx->d_ref); ctx->d_ref = NULL; return rc; }
+    ctx->ref_bytes = n_bases;
+    return CBC_OK;
+}
+
+static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const uint32_t *seq_codes, const cbc_2bit_run_dev *seq_runs,
+                              uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results);
+
 /* host-buffer entry point: H2D, encode, size scan, device-side compaction, D2H */
 API int cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_t *out, uint64_t out_cap,
                               uint64_t *out_offsets, cbc_block_result *results)
+{
+    if (!hb || !hb->seq) return CBC_E_ARG;
+    return encode_blocks_impl(ctx, hb, NULL, NULL, 0, out, out_cap, out_offsets, results);
+}
+API int cbc_gpu_encode_blocks_2bit(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const uint32_t *seq_codes, const cbc_2bit_run_dev *seq_runs,
+                                   uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results)
+{
+    if (!seq_codes || (n_seq_runs && !seq_runs)) return CBC_E_ARG;
+    return encode_blocks_impl(ctx, hb, seq_codes, seq_runs, n_seq_runs, out, out_cap, out_offsets, results);
+}
+
+static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const uint32_t *seq_codes, const cbc_2bit_run_dev *seq_runs,
+                              uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results)
 {
     if (!ctx || !hb || !out || !out_offsets) return CBC_E_ARG;
     if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
@@ -292,7 +401,7 @@ API int cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const uint64_t scratch = cbc_plan_output(hb->blocks, nb, hb->recs, hb->tok);
     void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_blocks = NULL, *d_out = NULL, *d_res = NULL,
-         *d_off = NULL, *d_packed = NULL;
+         *d_off = NULL, *d_packed = NULL, *d_codes = NULL, *d_runs = NULL;
     cbc_block_result *res = NULL;
     int rc = CBC_OK;
     uint64_t total = 0;
@@ -307,6 +416,10 @@ API int cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_
     GO(hipMalloc(&d_res, (uint64_t)nb * sizeof(cbc_block_result)), "hipMalloc results");
     GO(hipMalloc(&d_off, ((uint64_t)nb + 1) * 8), "hipMalloc offsets");
     GO(hipMemcpyAsync(d_recs, hb->recs, hb->n_recs * sizeof(cbc_read_rec), hipMemcpyHostToDevice, ctx->stream), "H2D recs");
+    if (seq_codes) {                                      /* 2-bit transport: a quarter of the bytes cross PCIe, expanded here */
+        rc = expand_2bit(ctx, seq_codes, hb->seq_bytes, seq_runs, n_seq_runs, (uint8_t *)d_seq, &d_codes, &d_runs);
+        if (rc) goto done;
+    } else
     GO(hipMemcpyAsync(d_seq, hb->seq, hb->seq_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D seq");
     GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
     GO(hipMemcpyAsync(d_names, hb->names, hb->names_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D names");
@@ -350,6 +463,7 @@ done:
     if (d_recs) (void)hipFree(d_recs); if (d_seq) (void)hipFree(d_seq); if (d_tok) (void)hipFree(d_tok);
     if (d_names) (void)hipFree(d_names); if (d_blocks) (void)hipFree(d_blocks); if (d_out) (void)hipFree(d_out);
     if (d_res) (void)hipFree(d_res); if (d_off) (void)hipFree(d_off); if (d_packed) (void)hipFree(d_packed);
+    if (d_codes) (void)hipFree(d_codes); if (d_runs) (void)hipFree(d_runs);
     return rc;
 }
 
@@ -806,5 +920,86 @@ done:
     if (res && res != results) free(res);
     if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
     if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res);
+    return rc;
+}
+
+/* decode with the bases returned as 2-bit rows (include/cbc_gpu.h) */
+API int cbc_gpu_decode_blocks_2bit(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
+                                   uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
+                                   uint32_t *codes_out, uint64_t *exc_idx, uint8_t *exc_val, uint64_t exc_cap, uint64_t *n_exc,
+                                   cbc_block_result *results)
+{
+    if (!ctx || !in || !blocks || !caps || !recs || !codes_out || !n_exc || (exc_cap && (!exc_idx || !exc_val))) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    *n_exc = 0;
+    if (n_blocks == 0) return CBC_OK;
+    const uint32_t stride = blocks[0].seq_stride;
+    if (stride < 16 || stride > 256 || (stride & 15u)) return set_err(ctx, CBC_E_ARG, "2-bit decode wants seq_stride to be a multiple of 16", hipSuccess);
+    for (uint32_t b = 0; b < n_blocks; b++) if (blocks[b].seq_stride != stride || blocks[b].seq_base != blocks[b].rec_base * stride)
+        return set_err(ctx, CBC_E_ARG, "2-bit decode wants one stride and seq_base = rec_base * stride", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    void *d_in = NULL, *d_blocks = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL, *d_vs = NULL, *d_codes = NULL, *d_ei = NULL, *d_ev = NULL, *d_n = NULL;
+    cbc_block_result *res = NULL;
+    int rc = CBC_OK;
+    const uint64_t vs_words = (uint64_t)n_blocks * caps->cap_var, seq_bytes = n_recs * stride, n_words = n_recs * (stride >> 4);
+    unsigned long long got = 0;
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+    GO(hipMalloc(&d_vs, vs_words * 4 + 16), "hipMalloc var scratch");
+    GO(hipMalloc(&d_in, in_bytes + 16), "hipMalloc in");
+    GO(hipMalloc(&d_blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc)), "hipMalloc blocks");
+    GO(hipMalloc(&d_recs, n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
+    GO(hipMalloc(&d_seq, seq_bytes + 32), "hipMalloc seq");
+    GO(hipMalloc(&d_res, (uint64_t)n_blocks * sizeof(cbc_block_result)), "hipMalloc results");
+    GO(hipMalloc(&d_codes, n_words * 4 + 16), "hipMalloc codes");
+    GO(hipMalloc(&d_ei, (exc_cap ? exc_cap : 1) * 8), "hipMalloc exceptions");
+    GO(hipMalloc(&d_ev, (exc_cap ? exc_cap : 1)), "hipMalloc exceptions");
+    GO(hipMalloc(&d_n, 8), "hipMalloc counter");
+    GO(hipMemsetAsync(d_n, 0, 8, ctx->stream), "memset counter");
+    GO(hipMemsetAsync((uint8_t *)d_in + in_bytes, 0, 16, ctx->stream), "memset pad");
+    GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D payloads");
+    GO(hipMemcpyAsync(d_blocks, blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
+    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)n_blocks * sizeof(cbc_block_result), ctx->stream), "memset results");
+    GO(hipMemsetAsync(d_seq, 0, seq_bytes + 32, ctx->stream), "memset seq");
+    {
+        cbc_dec_device_batch db;
+        memset(&db, 0, sizeof db);
+        db.d_in = (const uint8_t *)d_in; db.in_bytes = in_bytes + 16; db.d_blocks = (const cbc_dec_block_desc *)d_blocks;
+        db.n_blocks = n_blocks; db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = (cbc_read_rec *)d_recs;
+        db.n_recs = n_recs; db.d_seq = (uint8_t *)d_seq; db.seq_bytes = seq_bytes + 32; db.d_results = (cbc_block_result *)d_res;
+        db.caps = *caps; db.d_var_scratch = (uint32_t *)d_vs; db.var_scratch_words = vs_words;
+        rc = cbc_gpu_decode_blocks_device(ctx, &db, CBC_CTX_STREAM);
+        if (rc) goto done;
+    }
+    if (n_words) {
+        hipLaunchKernelGGL(cbc_pack_2bit_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint8_t *)d_seq, (const cbc_read_rec *)d_recs, n_recs, stride, (uint32_t *)d_codes,
+                           (uint64_t *)d_ei, (uint8_t *)d_ev, exc_cap, (unsigned long long *)d_n);
+        GO(hipGetLastError(), "launch cbc_pack_2bit_kernel");
+    }
+    res = results ? results : (cbc_block_result *)malloc((size_t)n_blocks * sizeof(cbc_block_result));
+    if (!res) { rc = CBC_E_NOMEM; goto done; }
+    GO(hipMemcpyAsync(res, d_res, (uint64_t)n_blocks * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
+    GO(hipMemcpyAsync(recs, d_recs, n_recs * sizeof(cbc_read_rec), hipMemcpyDeviceToHost, ctx->stream), "D2H recs");
+    GO(hipMemcpyAsync(codes_out, d_codes, n_words * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H codes");
+    GO(hipMemcpyAsync(&got, d_n, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H counter");
+    GO(hipStreamSynchronize(ctx->stream), "decode kernel");
+    *n_exc = got;
+    if (got > exc_cap) { rc = set_err(ctx, CBC_E_ARG, "more non-ACGT bases than exc_cap", hipSuccess); goto done; }
+    if (got) {
+        GO(hipMemcpyAsync(exc_idx, d_ei, got * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H exceptions");
+        GO(hipMemcpyAsync(exc_val, d_ev, got, hipMemcpyDeviceToHost, ctx->stream), "D2H exceptions");
+        GO(hipStreamSynchronize(ctx->stream), "D2H exceptions");
+    }
+    for (uint32_t b = 0; b < n_blocks; b++)
+        if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
+            snprintf(ctx->err, sizeof ctx->err, "block %u failed to decode with status %u at record %u", b, res[b].status, res[b].fail_read);
+            rc = CBC_E_BLOCK;
+        }
+done:
+#undef GO
+    if (res && res != results) free(res);
+    if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
+    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vs) (void)hipFree(d_vs);
+    if (d_codes) (void)hipFree(d_codes); if (d_ei) (void)hipFree(d_ei); if (d_ev) (void)hipFree(d_ev); if (d_n) (void)hipFree(d_n);
     return rc;
 }

@@ -118,6 +118,15 @@ def lib():
                                             ctypes.c_uint32, ctypes.POINTER(StreamResult)]
         L.cbc_stream_read_length.restype = ctypes.c_uint32
         L.cbc_stream_read_length.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_gpu_upload_reference_2bit.restype = ctypes.c_int
+        L.cbc_gpu_upload_reference_2bit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_gpu_encode_blocks_2bit.restype = ctypes.c_int
+        L.cbc_gpu_encode_blocks_2bit.argtypes = [ctypes.c_void_p, ctypes.POINTER(HostBatch), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                                 ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_gpu_decode_blocks_2bit.restype = ctypes.c_int
+        L.cbc_gpu_decode_blocks_2bit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32,
+                                                 ctypes.POINTER(host.LdsCaps), ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
         L.cbc_gpu_long_plan_output.restype = ctypes.c_uint64
         L.cbc_gpu_long_plan_output.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
         L.cbc_gpu_long_lds_bytes.restype = ctypes.c_uint32
@@ -145,6 +154,7 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_decode_blocks_device", "cbc_gpu_decode_blocks",
            "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_last_kernel_variant", "cbc_gpu_synchronize",
            "cbc_gpu_encode_stream", "cbc_gpu_encode_stream_blocks", "cbc_gpu_decode_stream", "cbc_stream_read_length",
+           "cbc_gpu_upload_reference_2bit", "cbc_gpu_encode_blocks_2bit", "cbc_gpu_decode_blocks_2bit",
            "cbc_gpu_long_plan_output", "cbc_gpu_long_lds_bytes", "cbc_gpu_long_encode_blocks_device",
            "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks"]
 
@@ -170,6 +180,59 @@ class Encoder:
     def upload_reference(self, ref: np.ndarray):
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         self._check(lib().cbc_gpu_upload_reference(self._ctx, ref.ctypes.data, ref.size), "cbc_gpu_upload_reference")
+
+    def upload_reference_2bit(self, codes: np.ndarray, runs: np.ndarray, n_bases: int):
+        """The reference over PCIe at 2 bits per base (host.pack_2bit), expanded on the device."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint32)
+        runs = np.ascontiguousarray(runs, dtype=host.RUN_DTYPE)
+        self._check(lib().cbc_gpu_upload_reference_2bit(self._ctx, codes.ctypes.data, n_bases, runs.ctypes.data if len(runs) else None,
+                                                        len(runs)), "cbc_gpu_upload_reference_2bit")
+
+    def encode_blocks_2bit(self, pb: "host.PackedBatch", codes: np.ndarray, runs: np.ndarray):
+        """cbc_gpu_encode_blocks with the batch's bases given in 2-bit transport form (host.pack_2bit(pb.seq))."""
+        nb = pb.n_blocks
+        hb, blocks = self._host_batch(pb)
+        hb.seq = None
+        total = lib().cbc_gpu_plan_output(blocks.ctypes.data, nb, pb.recs.ctypes.data, pb.tok.ctypes.data)
+        out = np.zeros(int(total), dtype=np.uint8)
+        offs = np.zeros(nb + 1, dtype=np.uint64)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        codes = np.ascontiguousarray(codes, dtype=np.uint32); runs = np.ascontiguousarray(runs, dtype=host.RUN_DTYPE)
+        rc = lib().cbc_gpu_encode_blocks_2bit(self._ctx, ctypes.byref(hb), codes.ctypes.data, runs.ctypes.data if len(runs) else None, len(runs),
+                                              out.ctypes.data, out.size, offs.ctypes.data, res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_encode_blocks_2bit")
+        return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res, offs, out[:int(offs[nb])]
+
+    def decode_blocks_2bit(self, plan: "host.UnpackPlan", stride=None):
+        """cbc_gpu_decode_blocks with the bases coming back as 2-bit rows.  Returns (recs, bases[n, stride] rebuilt on the
+        host, results, bytes that crossed PCIe for the bases)."""
+        nb = plan.n_blocks
+        stride = stride or (plan.seq_stride + 15) // 16 * 16
+        blocks = plan.blocks.copy()
+        blocks["seq_stride"] = stride
+        blocks["seq_base"] = blocks["rec_base"] * stride
+        recs = np.zeros(plan.n_recs, dtype=host.REC_DTYPE)
+        row_words = stride // 16
+        codes = np.zeros(plan.n_recs * row_words + 4, dtype=np.uint32)
+        cap = max(1024, plan.n_recs * 4)
+        ei = np.zeros(cap, dtype=np.uint64); ev = np.zeros(cap, dtype=np.uint8)
+        n_exc = ctypes.c_uint64(0)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        caps = host.LdsCaps(plan.cap_pos, plan.cap_var)
+        pay = np.ascontiguousarray(plan.payloads)
+        rc = lib().cbc_gpu_decode_blocks_2bit(self._ctx, pay.ctypes.data, pay.size, blocks.ctypes.data, nb, ctypes.byref(caps),
+                                              recs.ctypes.data, plan.n_recs, codes.ctypes.data, ei.ctypes.data, ev.ctypes.data, cap,
+                                              ctypes.byref(n_exc), res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_decode_blocks_2bit")
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        c = codes[:plan.n_recs * row_words]
+        bases = lut[(c[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3].reshape(plan.n_recs, stride)
+        k = int(n_exc.value)
+        if k:
+            bases.reshape(-1)[ei[:k].astype(np.int64)] = ev[:k]
+        return recs, bases, res, c.nbytes + 9 * k
 
     def encode_blocks(self, pb: "host.PackedBatch"):
         """Host-buffer path.  Returns (list of payload bytes per block, results array, out_offsets)."""

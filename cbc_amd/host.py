@@ -99,6 +99,18 @@ class SynthOpts(ctypes.Structure):
                 ("name", ctypes.c_char_p)]
 
 
+class TwoBitRun(ctypes.Structure):
+    _fields_ = [("start", ctypes.c_uint64), ("length", ctypes.c_uint32), ("byte", ctypes.c_uint32)]
+
+
+class TwoBitC(ctypes.Structure):
+    _fields_ = [("codes", ctypes.POINTER(ctypes.c_uint32)), ("n_bases", ctypes.c_uint64),
+                ("runs", ctypes.POINTER(TwoBitRun)), ("n_runs", ctypes.c_uint64)]
+
+
+RUN_DTYPE = np.dtype([("start", "<u8"), ("length", "<u4"), ("byte", "<u4")])
+
+
 class CbcInputError(ValueError):
     """The input violates a limit of the reference format (message from the packer)."""
 
@@ -133,6 +145,11 @@ def lib():
         L.cbc_container_write.restype = ctypes.c_int64
         L.cbc_container_write.argtypes = [ctypes.POINTER(Packed), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
                                           ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_2bit_pack.restype = ctypes.c_int
+        L.cbc_2bit_pack.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.POINTER(TwoBitC))]
+        L.cbc_2bit_unpack.restype = ctypes.c_int
+        L.cbc_2bit_unpack.argtypes = [ctypes.POINTER(TwoBitC), ctypes.c_void_p]
+        L.cbc_2bit_free.argtypes = [ctypes.POINTER(TwoBitC)]
         L.cbc_assign_contigs.restype = ctypes.c_int
         L.cbc_assign_contigs.argtypes = [ctypes.POINTER(Packed), ctypes.c_uint32, ctypes.c_void_p]
         L.cbc_unpack_plan_create.restype = ctypes.c_int
@@ -262,6 +279,33 @@ class PackedBatch:
             self.close()
         except Exception:
             pass
+
+
+def pack_2bit(bases: np.ndarray, threads=0):
+    """Bases -> 2-bit transport form (cbc_2bit_pack): (codes uint32 array, exception runs array of RUN_DTYPE)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    out = ctypes.POINTER(TwoBitC)()
+    rc = lib().cbc_2bit_pack(bases.ctypes.data, bases.size, threads, ctypes.byref(out))
+    if rc != 0:
+        raise RuntimeError("cbc_2bit_pack failed: %d" % rc)
+    p = out.contents
+    codes = _np_view(p.codes, (int(p.n_bases) + 15) // 16, np.uint32).copy()
+    runs = _np_view(p.runs, p.n_runs, RUN_DTYPE).copy() if p.n_runs else np.zeros(0, dtype=RUN_DTYPE)
+    lib().cbc_2bit_free(out)
+    return codes, runs
+
+
+def unpack_2bit(codes: np.ndarray, runs: np.ndarray, n_bases: int) -> np.ndarray:
+    """Host inverse of pack_2bit (cbc_2bit_unpack)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint32)
+    runs = np.ascontiguousarray(runs, dtype=RUN_DTYPE)
+    c = TwoBitC(codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n_bases,
+                ctypes.cast(runs.ctypes.data, ctypes.POINTER(TwoBitRun)) if len(runs) else None, len(runs))
+    out = np.zeros(n_bases, dtype=np.uint8)
+    rc = lib().cbc_2bit_unpack(ctypes.byref(c), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("cbc_2bit_unpack failed: %d" % rc)
+    return out
 
 
 def pack_sam(sam: bytes, fasta: bytes, **kw) -> PackedBatch:

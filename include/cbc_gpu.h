@@ -277,6 +277,30 @@ int  cbc_gpu_long_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in
                                 uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
                                 uint8_t *seq, uint64_t seq_bytes, cbc_block_result *results /* or NULL */);
 
+/* ---- 2-bit transport of bases over PCIe (layout: include/cbc_host.h cbc_2bit) ------------
+ * The codec kernels read and write one byte per base in HBM; what crosses PCIe can be a quarter of that.  Host side:
+ * cbc_2bit_pack() (libcbc_host).  Device side: an expand kernel (16 bases per lane: one code word in, one 16-byte
+ * store out) followed by the exception runs, and the inverse pack kernel for decoded reads.
+ *   cbc_gpu_upload_reference_2bit   reference as 2-bit codes + exception runs (N-runs, the pads) -> the same device
+ *                                   reference cbc_gpu_upload_reference() makes (bit-identical bytes)
+ *   cbc_gpu_encode_blocks_2bit      as cbc_gpu_encode_blocks, the batch's bases given as codes + runs (batch->seq may be
+ *                                   NULL; batch->seq_bytes = number of bases incl. the 8 pad bytes)
+ *   cbc_gpu_decode_blocks_2bit      as cbc_gpu_decode_blocks, but the bases come back as 2-bit rows: read r occupies
+ *                                   words [r * row_words, (r + 1) * row_words) of codes_out (row_words = seq_stride / 16,
+ *                                   seq_stride a multiple of 16), and every base of a read that is not A/C/G/T comes back
+ *                                   in exc_idx[] (= r * seq_stride + position) / exc_val[]; *n_exc = how many (CBC_E_ARG if
+ *                                   more than exc_cap) */
+typedef struct cbc_2bit_run_dev { uint64_t start; uint32_t length; uint32_t byte; } cbc_2bit_run_dev;   /* = cbc_2bit_run */
+int  cbc_gpu_upload_reference_2bit(cbc_gpu_ctx *ctx, const uint32_t *codes, uint64_t n_bases,
+                                   const cbc_2bit_run_dev *runs, uint64_t n_runs);
+int  cbc_gpu_encode_blocks_2bit(cbc_gpu_ctx *ctx, const cbc_host_batch *batch, const uint32_t *seq_codes,
+                                const cbc_2bit_run_dev *seq_runs, uint64_t n_seq_runs,
+                                uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results);
+int  cbc_gpu_decode_blocks_2bit(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
+                                uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
+                                uint32_t *codes_out, uint64_t *exc_idx, uint8_t *exc_val, uint64_t exc_cap, uint64_t *n_exc,
+                                cbc_block_result *results);
+
 /* Timing of the most recent encode launch made through this context, measured with HIP events
  * recorded on the launch stream around the kernel (valid after the stream has been synchronised). */
 int  cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms);
