@@ -65,7 +65,8 @@ def test_gpu_2bit_transport(built):
     plan = host.UnpackPlan(pb.container(flat, offs), fa)
     recs, seq, dres = enc.decode_blocks(plan)
     recs2, bases2, dres2, pcie = enc.decode_blocks_2bit(plan)
-    assert (dres2["status"] == 0).all() and recs2.tobytes() == recs.tobytes()
+    assert (dres2["status"] == 0).all()
+    assert all((recs2[k] == recs[k]).all() for k in ("pos", "flag", "rlen"))       # seq_off differs: rows are 160 bytes here
     want = seq[:plan.n_recs * plan.seq_stride].reshape(plan.n_recs, plan.seq_stride)[:, :150]
     assert (bases2[:, :150] == want).all()
     assert pcie < 0.3 * plan.n_recs * plan.seq_stride
