@@ -19,6 +19,7 @@
 #include "cbc_plan.h"
 #include "cbc_stream_body.h"
 #include "cbc_long_body.h"
+#include "cbc_tokenise.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 /* internal marker: "use the context's own stream" (host-buffer entry points only) */
@@ -374,7 +375,26 @@ API int cbc_gpu_upload_reference_2bit(cbc_gpu_ctx *ctx, const uint32_t *codes, u
 }
 
 static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const uint32_t *seq_codes, const cbc_2bit_run_dev *seq_runs,
-                              uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results);
+                              uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results,
+                              const uint8_t *d_seq_ext = NULL, const uint32_t *d_tok_ext = NULL, const cbc_tok_record_summary *sums = NULL);
+
+/* cbc_plan_output() when the tokens are on the device: the per-record var-symbol bound travels in the summaries */
+static uint64_t plan_output_from_summaries(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_tok_record_summary *sums)
+{
+    uint64_t off = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        cbc_block_desc *bd = &blocks[b];
+        uint64_t nev = 0;
+        for (uint32_t r = 0; r < bd->n_reads; r++) nev += sums[bd->rec_base + r].nt_ev >> 16;
+        const uint64_t nsym = 136u + 2u * CBC_CAP_NAME + 16ull * bd->n_reads + 2 * nev;
+        uint64_t payload_cap = (3 * nsym + 256 + 255) & ~255ull;
+        uint64_t cap = payload_cap + ((4 * (nev + 64) + 255) & ~255ull);
+        if (cap > 0xffffff00ull) { cap = 0xffffff00ull; payload_cap = cap / 2; payload_cap &= ~255ull; }
+        bd->out_off = off; bd->out_cap = (uint32_t)cap; bd->reserved = (uint32_t)payload_cap;
+        off += cap;
+    }
+    return off;
+}
 
 /* host-buffer entry point: H2D, encode, size scan, device-side compaction, D2H */
 API int cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, uint8_t *out, uint64_t out_cap,
@@ -391,7 +411,8 @@ API int cbc_gpu_encode_blocks_2bit(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, c
 }
 
 static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const uint32_t *seq_codes, const cbc_2bit_run_dev *seq_runs,
-                              uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results)
+                              uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results,
+                              const uint8_t *d_seq_ext, const uint32_t *d_tok_ext, const cbc_tok_record_summary *sums)
 {
     if (!ctx || !hb || !out || !out_offsets) return CBC_E_ARG;
     if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
@@ -399,7 +420,7 @@ static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const 
     out_offsets[0] = 0;
     if (nb == 0) return CBC_OK;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    const uint64_t scratch = cbc_plan_output(hb->blocks, nb, hb->recs, hb->tok);
+    const uint64_t scratch = sums ? plan_output_from_summaries(hb->blocks, nb, sums) : cbc_plan_output(hb->blocks, nb, hb->recs, hb->tok);
     void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_blocks = NULL, *d_out = NULL, *d_res = NULL,
          *d_off = NULL, *d_packed = NULL, *d_codes = NULL, *d_runs = NULL;
     cbc_block_result *res = NULL;
@@ -408,27 +429,28 @@ static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const 
     const uint64_t ntok = hb->n_tok ? hb->n_tok : 1;
 #define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
     GO(hipMalloc(&d_recs, hb->n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
-    GO(hipMalloc(&d_seq, hb->seq_bytes + 16), "hipMalloc seq");
-    GO(hipMalloc(&d_tok, ntok * 4 + 16), "hipMalloc tok");
+    if (!d_seq_ext) GO(hipMalloc(&d_seq, hb->seq_bytes + 16), "hipMalloc seq");
+    if (!d_tok_ext) GO(hipMalloc(&d_tok, ntok * 4 + 16), "hipMalloc tok");
     GO(hipMalloc(&d_names, hb->names_bytes + 16), "hipMalloc names");
     GO(hipMalloc(&d_blocks, (uint64_t)nb * sizeof(cbc_block_desc)), "hipMalloc blocks");
     GO(hipMalloc(&d_out, scratch), "hipMalloc out scratch");
     GO(hipMalloc(&d_res, (uint64_t)nb * sizeof(cbc_block_result)), "hipMalloc results");
     GO(hipMalloc(&d_off, ((uint64_t)nb + 1) * 8), "hipMalloc offsets");
     GO(hipMemcpyAsync(d_recs, hb->recs, hb->n_recs * sizeof(cbc_read_rec), hipMemcpyHostToDevice, ctx->stream), "H2D recs");
-    if (seq_codes) {                                      /* 2-bit transport: a quarter of the bytes cross PCIe, expanded here */
+    if (d_seq_ext) { /* already resident */ }
+    else if (seq_codes) {                                      /* 2-bit transport: a quarter of the bytes cross PCIe, expanded here */
         rc = expand_2bit(ctx, seq_codes, hb->seq_bytes, seq_runs, n_seq_runs, (uint8_t *)d_seq, &d_codes, &d_runs);
         if (rc) goto done;
     } else
     GO(hipMemcpyAsync(d_seq, hb->seq, hb->seq_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D seq");
-    GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
+    if (!d_tok_ext) GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
     GO(hipMemcpyAsync(d_names, hb->names, hb->names_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D names");
     GO(hipMemcpyAsync(d_blocks, hb->blocks, (uint64_t)nb * sizeof(cbc_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
     GO(hipMemsetAsync(d_res, 0xff, (uint64_t)nb * sizeof(cbc_block_result), ctx->stream), "memset results");
     {
         cbc_device_batch db;
         memset(&db, 0, sizeof db);
-        db.d_recs = (const cbc_read_rec *)d_recs; db.d_seq = (const uint8_t *)d_seq; db.d_tok = (const uint32_t *)d_tok;
+        db.d_recs = (const cbc_read_rec *)d_recs; db.d_seq = d_seq_ext ? d_seq_ext : (const uint8_t *)d_seq; db.d_tok = d_tok_ext ? d_tok_ext : (const uint32_t *)d_tok;
         db.d_names = (const uint8_t *)d_names; db.d_blocks = (const cbc_block_desc *)d_blocks; db.n_blocks = nb;
         db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_out = (uint8_t *)d_out; db.out_bytes = scratch;
         db.d_results = (cbc_block_result *)d_res; db.seq_bytes = hb->seq_bytes; db.n_tok = ntok; db.n_recs = hb->n_recs;
@@ -1002,4 +1024,159 @@ done:
     if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vs) (void)hipFree(d_vs);
     if (d_codes) (void)hipFree(d_codes); if (d_ei) (void)hipFree(d_ei); if (d_ev) (void)hipFree(d_ev); if (d_n) (void)hipFree(d_n);
     return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * SAM text -> packed records on the device (cbc_tokenise.h)
+ * ---------------------------------------------------------------------------------------------- */
+static int scan_u32(cbc_gpu_ctx *ctx, const uint32_t *d_v, uint64_t n, uint64_t *d_out, uint64_t *d_tmp /* >= n/1024 + 2 */, uint64_t *grand)
+{
+    if (n == 0) { *grand = 0; return CBC_OK; }
+    const uint64_t nb = (n + 1023) / 1024;
+    hipLaunchKernelGGL(cbc_scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, d_v, n, d_out, d_tmp);
+    hipLaunchKernelGGL(cbc_scan_totals_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_tmp, nb, d_tmp + nb);
+    hipLaunchKernelGGL(cbc_scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_out, n, (const uint64_t *)d_tmp);
+    HIPCHK(hipGetLastError(), "launch scan kernels");
+    HIPCHK(hipMemcpyAsync(grand, d_tmp + nb, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H scan total");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "scan");
+    return CBC_OK;
+}
+
+__global__ void __launch_bounds__(256)
+cbc_tok_status_kernel(const cbc_tok_perline *__restrict__ pl, uint64_t n_lines, unsigned long long *__restrict__ first_bad, unsigned long long *__restrict__ n_unmapped)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_lines) return;
+    const uint32_t st = pl[k].status;
+    if (st >= CBC_TOK_NEEDS_HOST) atomicMin(first_bad, (unsigned long long)k);
+    if (st == CBC_TOK_UNMAPPED) atomicAdd(n_unmapped, 1ull);
+}
+
+API void cbc_gpu_tokenise_free(cbc_gpu_ctx *ctx, cbc_tok_result *t)
+{
+    if (!t) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    free(t->summaries); free(t->rname_change); free(t->change_name_off); free(t->change_name_len);
+    if (t->d_seq) (void)hipFree(t->d_seq); if (t->d_tok) (void)hipFree(t->d_tok);
+    memset(t, 0, sizeof *t);
+}
+
+API int cbc_gpu_tokenise_sam(cbc_gpu_ctx *ctx, const char *sam, uint64_t len, uint64_t body_off, cbc_tok_result *out)
+{
+    if (!ctx || !sam || !out || body_off > len) return CBC_E_ARG;
+    memset(out, 0, sizeof *out);
+    if (len == 0) return CBC_OK;
+    if (len > 0xffffffffull * 64) return set_err(ctx, CBC_E_ARG, "SAM text too large for one launch", hipSuccess);
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const uint64_t n_tiles = (len + CBC_TOK_TILE - 1) / CBC_TOK_TILE;
+    void *d_sam = NULL, *d_tc = NULL, *d_tb = NULL, *d_tmp = NULL, *d_ls = NULL, *d_pl = NULL, *d_isrec = NULL, *d_vrl = NULL, *d_vnt = NULL,
+         *d_recof = NULL, *d_seqof = NULL, *d_tokof = NULL, *d_sum = NULL, *d_chg = NULL, *d_cnt = NULL;
+    int rc = CBC_OK;
+    uint64_t n_nl = 0, n_lines = 0, n_recs = 0, seq_bytes = 0, n_tok = 0;
+    unsigned long long cnt[2] = { ~0ull, 0ull };
+    cbc_tok_perline bad_pl;
+#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
+#define GOR(call) do { rc = (call); if (rc) goto done; } while (0)
+    GO(hipMalloc(&d_sam, len + 64), "hipMalloc SAM text");
+    GO(hipMemcpyAsync(d_sam, sam, len, hipMemcpyHostToDevice, ctx->stream), "H2D SAM text");
+    GO(hipMalloc(&d_tc, n_tiles * 4 + 16), "hipMalloc tiles");
+    GO(hipMalloc(&d_tb, n_tiles * 8 + 16), "hipMalloc tiles");
+    GO(hipMalloc(&d_tmp, (len / 1024 + n_tiles / 1024 + 16) * 8), "hipMalloc scan scratch");   /* block totals of the largest scan: n_lines <= len */
+    hipLaunchKernelGGL(cbc_tok_count_kernel, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, (const uint8_t *)d_sam, len, (uint32_t *)d_tc);
+    GO(hipGetLastError(), "launch cbc_tok_count_kernel");
+    GOR(scan_u32(ctx, (const uint32_t *)d_tc, n_tiles, (uint64_t *)d_tb, (uint64_t *)d_tmp, &n_nl));
+    n_lines = n_nl + ((uint8_t)sam[len - 1] != '\n' ? 1 : 0);
+    GO(hipMalloc(&d_ls, (n_lines + 2) * 8), "hipMalloc line starts");
+    {
+        const uint64_t zero = 0;
+        GO(hipMemcpyAsync(d_ls, &zero, 8, hipMemcpyHostToDevice, ctx->stream), "line start 0");
+        GO(hipMemcpyAsync((uint64_t *)d_ls + n_lines, &len, 8, hipMemcpyHostToDevice, ctx->stream), "line start n");
+    }
+    hipLaunchKernelGGL(cbc_tok_lines_kernel, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, (const uint8_t *)d_sam, len, (const uint64_t *)d_tb, (uint64_t *)d_ls);
+    GO(hipGetLastError(), "launch cbc_tok_lines_kernel");
+    GO(hipMalloc(&d_pl, n_lines * sizeof(cbc_tok_perline) + 16), "hipMalloc per-line");
+    GO(hipMalloc(&d_isrec, n_lines * 4 + 16), "hipMalloc"); GO(hipMalloc(&d_vrl, n_lines * 4 + 16), "hipMalloc"); GO(hipMalloc(&d_vnt, n_lines * 4 + 16), "hipMalloc");
+    GO(hipMalloc(&d_recof, n_lines * 8 + 16), "hipMalloc"); GO(hipMalloc(&d_seqof, n_lines * 8 + 16), "hipMalloc"); GO(hipMalloc(&d_tokof, n_lines * 8 + 16), "hipMalloc");
+    GO(hipMalloc(&d_cnt, 16), "hipMalloc counters");
+    GO(hipMemcpyAsync(d_cnt, cnt, 16, hipMemcpyHostToDevice, ctx->stream), "H2D counters");
+    hipLaunchKernelGGL(cbc_tok_parse_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)d_sam,
+                       (const uint64_t *)d_ls, n_lines, body_off, (cbc_tok_perline *)d_pl, (uint32_t *)d_isrec, (uint32_t *)d_vrl, (uint32_t *)d_vnt);
+    GO(hipGetLastError(), "launch cbc_tok_parse_kernel");
+    hipLaunchKernelGGL(cbc_tok_status_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, (const cbc_tok_perline *)d_pl,
+                       n_lines, (unsigned long long *)d_cnt, (unsigned long long *)d_cnt + 1);
+    GO(hipGetLastError(), "launch cbc_tok_status_kernel");
+    GOR(scan_u32(ctx, (const uint32_t *)d_isrec, n_lines, (uint64_t *)d_recof, (uint64_t *)d_tmp, &n_recs));
+    GOR(scan_u32(ctx, (const uint32_t *)d_vrl, n_lines, (uint64_t *)d_seqof, (uint64_t *)d_tmp, &seq_bytes));
+    GOR(scan_u32(ctx, (const uint32_t *)d_vnt, n_lines, (uint64_t *)d_tokof, (uint64_t *)d_tmp, &n_tok));
+    GO(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream), "D2H counters");
+    GO(hipStreamSynchronize(ctx->stream), "tokenise pass 1");
+    out->n_lines = n_lines; out->n_recs = n_recs; out->n_unmapped = cnt[1]; out->seq_bytes = seq_bytes; out->n_tok = n_tok;
+    if (cnt[0] != ~0ull) {                                    /* a line the device path does not take: say which and why */
+        GO(hipMemcpy(&bad_pl, (cbc_tok_perline *)d_pl + cnt[0], sizeof bad_pl, hipMemcpyDeviceToHost), "D2H status");
+        out->status = bad_pl.status; out->bad_line = cnt[0];
+        goto done;
+    }
+    GO(hipMalloc((void **)&out->d_seq, seq_bytes + 16), "hipMalloc seq");
+    GO(hipMalloc((void **)&out->d_tok, (n_tok + 4) * 4), "hipMalloc tok");
+    GO(hipMemsetAsync(out->d_seq + seq_bytes, 0, 16, ctx->stream), "memset seq pad");
+    GO(hipMalloc(&d_sum, (n_recs + 1) * sizeof(cbc_tok_summary)), "hipMalloc summaries");
+    GO(hipMalloc(&d_chg, n_recs + 16), "hipMalloc change flags");
+    if (n_recs) {
+        hipLaunchKernelGGL(cbc_tok_emit_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)d_sam,
+                           (const uint64_t *)d_ls, n_lines, (const cbc_tok_perline *)d_pl, (const uint64_t *)d_recof, (const uint64_t *)d_tokof,
+                           out->d_tok, (cbc_tok_summary *)d_sum);
+        GO(hipGetLastError(), "launch cbc_tok_emit_kernel");
+        hipLaunchKernelGGL(cbc_tok_seq_kernel, dim3((unsigned)((n_recs + 15) / 16)), dim3(64), 0, ctx->stream, (const uint8_t *)d_sam,
+                           (const uint64_t *)d_ls, (const cbc_tok_summary *)d_sum, n_recs, (const uint64_t *)d_seqof, out->d_seq);
+        GO(hipGetLastError(), "launch cbc_tok_seq_kernel");
+        hipLaunchKernelGGL(cbc_tok_names_kernel, dim3((unsigned)((n_recs + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)d_sam,
+                           (const cbc_tok_perline *)d_pl, (const cbc_tok_summary *)d_sum, n_recs, (uint8_t *)d_chg);
+        GO(hipGetLastError(), "launch cbc_tok_names_kernel");
+    }
+    out->summaries = (cbc_tok_record_summary *)malloc((size_t)(n_recs + 1) * sizeof(cbc_tok_record_summary));
+    out->rname_change = (uint8_t *)malloc((size_t)n_recs + 1);
+    if (!out->summaries || !out->rname_change) { rc = CBC_E_NOMEM; goto done; }
+    GO(hipMemcpyAsync(out->summaries, d_sum, n_recs * sizeof(cbc_tok_summary), hipMemcpyDeviceToHost, ctx->stream), "D2H summaries");
+    GO(hipMemcpyAsync(out->rname_change, d_chg, n_recs, hipMemcpyDeviceToHost, ctx->stream), "D2H change flags");
+    GO(hipStreamSynchronize(ctx->stream), "tokenise pass 2");
+    {   /* where each new RNAME sits in the text: one small copy per contig change */
+        uint64_t nc = 0;
+        for (uint64_t r = 0; r < n_recs; r++) nc += out->rname_change[r] != 0;
+        out->change_name_off = (uint64_t *)malloc((size_t)(nc + 1) * 8); out->change_name_len = (uint32_t *)malloc((size_t)(nc + 1) * 4);
+        if (!out->change_name_off || !out->change_name_len) { rc = CBC_E_NOMEM; goto done; }
+        uint64_t k = 0;
+        for (uint64_t r = 0; r < n_recs; r++) if (out->rname_change[r]) {
+            cbc_tok_perline one;
+            GO(hipMemcpy(&one, (cbc_tok_perline *)d_pl + out->summaries[r].line, sizeof one, hipMemcpyDeviceToHost), "D2H contig name");
+            out->change_name_off[k] = one.rname; out->change_name_len[k] = one.rname_len; k++;
+        }
+        out->n_changes = nc;
+    }
+done:
+#undef GO
+#undef GOR
+    if (d_sam) (void)hipFree(d_sam); if (d_tc) (void)hipFree(d_tc); if (d_tb) (void)hipFree(d_tb); if (d_tmp) (void)hipFree(d_tmp);
+    if (d_ls) (void)hipFree(d_ls); if (d_pl) (void)hipFree(d_pl); if (d_isrec) (void)hipFree(d_isrec); if (d_vrl) (void)hipFree(d_vrl);
+    if (d_vnt) (void)hipFree(d_vnt); if (d_recof) (void)hipFree(d_recof); if (d_seqof) (void)hipFree(d_seqof); if (d_tokof) (void)hipFree(d_tokof);
+    if (d_sum) (void)hipFree(d_sum); if (d_chg) (void)hipFree(d_chg); if (d_cnt) (void)hipFree(d_cnt);
+    if (rc) cbc_gpu_tokenise_free(ctx, out);
+    return rc;
+}
+
+API int cbc_gpu_tokenise_fetch(cbc_gpu_ctx *ctx, const cbc_tok_result *t, uint8_t *seq, uint32_t *tok)
+{
+    if (!ctx || !t || !seq || !tok) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (t->d_seq) HIPCHK(hipMemcpy(seq, t->d_seq, t->seq_bytes + 8, hipMemcpyDeviceToHost), "D2H seq");
+    if (t->d_tok && t->n_tok) HIPCHK(hipMemcpy(tok, t->d_tok, t->n_tok * 4, hipMemcpyDeviceToHost), "D2H tok");
+    return CBC_OK;
+}
+
+API int cbc_gpu_encode_blocks_tokenised(cbc_gpu_ctx *ctx, const cbc_tok_result *t, const cbc_host_batch *hb,
+                                        uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results)
+{
+    if (!t || !t->d_seq || !t->d_tok || !hb) return CBC_E_ARG;
+    if (hb->seq_bytes != t->seq_bytes + 8 || hb->n_tok != t->n_tok) return set_err(ctx, CBC_E_ARG, "batch and tokeniser result disagree", hipSuccess);
+    if (!t->summaries || hb->n_recs != t->n_recs) return set_err(ctx, CBC_E_ARG, "batch and tokeniser result disagree", hipSuccess);
+    return encode_blocks_impl(ctx, hb, NULL, NULL, 0, out, out_cap, out_offsets, results, t->d_seq, t->d_tok, t->summaries);
 }

@@ -42,6 +42,7 @@ static void usage(const char *p)
             "         --threads N (SAM parser threads, default one per CPU)  --verbose (stage times)\n"
             "         --compat (write the reference's own single-stream format; slow: one stream = one wavefront)\n"
             "         --devices 0,1,... (shard the contigs / block ranges over several MI355X, one host thread each)\n"
+            "         --device-parse (tokenise the SAM text on the GPU; falls back to the host parser for leading soft clips / records without MD)\n"
             "         --long (long-read format extension: reads up to 65535 bases, any SAM line length; not a reference format)\n", p, p);
 }
 
@@ -183,7 +184,7 @@ static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, c
 }
 
 static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose, int compat,
-                       const int *devs, int ndev, int long_reads)
+                       const int *devs, int ndev, int long_reads, int device_parse)
 {
     size_t sam_len = 0, fa_len = 0;
     double t0 = now_s();
@@ -199,7 +200,24 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     po.long_reads = long_reads ? 1u : 0u;
     if (long_reads && !block_reads) po.block_reads = 64;
     cbc_packed *p = NULL;
-    int rc = cbc_pack_sam(sam, sam_len, fa, fa_len, &po, &p, err, sizeof err);
+    int rc = 0;
+    cbc_gpu_ctx *tctx = NULL; cbc_tok_result tr; int tokenised = 0;
+    memset(&tr, 0, sizeof tr);
+    if (device_parse && !compat && !long_reads && ndev <= 1) {
+        /* SAM text -> bases + tokens on the device (cbc_gpu_tokenise_sam); the host only cuts the blocks */
+        rc = cbc_gpu_init(device, &tctx);
+        if (rc) { fprintf(stderr, "cbc: no usable MI355X (cbc_gpu_init = %d); there is no CPU fallback\n", rc); return 1; }
+        rc = cbc_gpu_tokenise_sam(tctx, sam, sam_len, cbc_sam_body_offset(sam, sam_len), &tr);
+        if (rc) { fprintf(stderr, "cbc: %s\n", cbc_gpu_last_error(tctx)); return 1; }
+        if (tr.status == 3) { if (verbose) printf("device tokeniser: line %llu needs the host packer (leading soft clip or no MD field); parsing on the host\n", (unsigned long long)tr.bad_line + 1); }
+        else if (tr.status) { fprintf(stderr, "cbc: malformed SAM at line %llu (tokeniser status %u)\n", (unsigned long long)tr.bad_line + 1, tr.status); return 1; }
+        else {
+            rc = cbc_pack_from_device_tokens(sam, sam_len, fa, fa_len, &po, tr.summaries, tr.rname_change, tr.change_name_off, tr.change_name_len,
+                                             tr.n_recs, tr.n_unmapped, NULL, tr.seq_bytes, NULL, tr.n_tok, &p, err, sizeof err);
+            tokenised = !rc;
+        }
+    }
+    if (!tokenised && !rc) rc = cbc_pack_sam(sam, sam_len, fa, fa_len, &po, &p, err, sizeof err);
     unmap_file(sam, sam_len); unmap_file(fa, fa_len);
     double t1 = now_s();
     if (rc) { fprintf(stderr, "cbc: %s\n", err); return 1; }
@@ -208,8 +226,8 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
         cbc_packed_free(p);
         return rc;
     }
-    cbc_gpu_ctx *ctx = NULL;
-    rc = cbc_gpu_init(device, &ctx);
+    cbc_gpu_ctx *ctx = tctx;
+    if (!ctx) rc = cbc_gpu_init(device, &ctx);
     if (rc) { fprintf(stderr, "cbc: no usable MI355X (cbc_gpu_init = %d); there is no CPU fallback\n", rc); cbc_packed_free(p); return 1; }
     rc = cbc_gpu_upload_reference(ctx, p->ref, p->ref_bytes);
     if (rc) { fprintf(stderr, "cbc: %s\n", cbc_gpu_last_error(ctx)); return 1; }
@@ -235,7 +253,8 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
         free(stream); cbc_gpu_shutdown(ctx); cbc_packed_free(p);
         return 0;
     }
-    uint64_t cap = cbc_gpu_plan_output(p->blocks, p->n_blocks, p->recs, p->tok);
+    uint64_t cap = tokenised ? 4096ull * p->n_blocks + 48ull * p->n_recs + 16ull * p->n_tok
+                             : cbc_gpu_plan_output(p->blocks, p->n_blocks, p->recs, p->tok);
     uint8_t *payloads = (uint8_t *)malloc(cap ? cap : 1);
     uint64_t *offs = (uint64_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint64_t));
     if (!payloads || !offs) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
@@ -247,6 +266,9 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
         payloads = (uint8_t *)malloc(cap);
         if (!payloads) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
         rc = cbc_gpu_long_encode_blocks(ctx, &hb, payloads, cap, offs, NULL);
+    } else if (tokenised) {
+        rc = cbc_gpu_encode_blocks_tokenised(ctx, &tr, &hb, payloads, cap, offs, NULL);
+        cbc_gpu_tokenise_free(ctx, &tr);
     } else
     rc = cbc_gpu_encode_blocks(ctx, &hb, payloads, cap, offs, NULL);
     if (rc) { fprintf(stderr, "cbc: encode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
@@ -273,7 +295,7 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, const i
 int main(int argc, char **argv)
 {
     const char *files[3] = { 0, 0, 0 };
-    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0, long_reads = 0;
+    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0, long_reads = 0, device_parse = 0;
     int devs[CBC_MAX_DEVICES] = { 0 }, ndev = 0;
     uint32_t block_reads = 0;
     for (int i = 1; i < argc; i++) {
@@ -295,6 +317,7 @@ int main(int argc, char **argv)
         if (!strcmp(a, "--verbose")) { verbose = 1; continue; }
         if (!strcmp(a, "--compat")) { compat = 1; continue; }
         if (!strcmp(a, "--long")) { long_reads = 1; continue; }
+        if (!strcmp(a, "--device-parse")) { device_parse = 1; continue; }
         if (!strcmp(a, "-h") || !strcmp(a, "--help")) { usage(argv[0]); return 0; }
         switch (a[1]) {
         case 'c':
@@ -330,6 +353,6 @@ int main(int argc, char **argv)
         return 1;
     }
     if (ndev == 0) { devs[0] = device; ndev = 1; }
-    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat, devs, ndev, long_reads)
+    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat, devs, ndev, long_reads, device_parse)
                      : cbc_cli_decompress(files[0], files[1], files[2], devs, ndev);
 }

@@ -1438,6 +1438,77 @@ API int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, co
 }
 
 
+
+/* ================================= after the device tokeniser ============ */
+API uint64_t cbc_sam_body_offset(const char *sam, size_t len)
+{
+    size_t off = 0;
+    if (!sam) return 0;
+    (void)header_read_length(sam, len, &off, 0);
+    return off;
+}
+
+typedef struct { uint32_t pos; uint16_t flag, rl; uint32_t nt_ev; uint32_t line; } dev_summary;
+
+API int cbc_pack_from_device_tokens(const char *sam, size_t sam_len, const char *fasta, size_t fasta_len, const cbc_pack_opts *opts,
+                                    const void *summaries, const uint8_t *rname_change, const uint64_t *change_name_off,
+                                    const uint32_t *change_name_len, uint64_t n_recs, uint64_t n_unmapped,
+                                    uint8_t *seq, uint64_t seq_bytes, uint32_t *tok, uint64_t n_tok,
+                                    cbc_packed **out, char *errbuf, size_t errlen)
+{
+    if (!sam || !fasta || !out || (n_recs && (!summaries || !rname_change || !change_name_off || !change_name_len))) return CBC_E_ARG;
+    packer_t *S = (packer_t *)malloc(sizeof(packer_t));
+    if (!S) return CBC_E_NOMEM;
+    int rc = packer_init(S, opts, errbuf, errlen);
+    if (rc) goto done;
+    if (S->o.whole_file || S->o.long_reads) { rc = fail(S, CBC_E_ARG, "the device tokeniser feeds block mode only%s%lld", "", 0); goto done; }
+    rc = load_reference(S, fasta, fasta_len, S->o.n_threads);
+    if (rc) goto done;
+    cbc_packed *P = S->P;
+    {
+        size_t off = 0;
+        P->read_length = header_read_length(sam, sam_len, &off, (int)S->o.var_length);
+        if (P->read_length < 1 || P->read_length > 256) { rc = fail(S, CBC_E_INPUT, "header read length %s%lld outside 1..256", "", P->read_length); goto done; }
+    }
+    if (grow((void **)&P->recs, &P->cap_recs, n_recs + 1, sizeof(cbc_read_rec))) { rc = CBC_E_NOMEM; goto done; }
+    {
+        const dev_summary *sm = (const dev_summary *)summaries;
+        uint64_t k = 0;
+        for (uint64_t r = 0; r < n_recs && !rc; r++) {
+            if (rname_change[r]) {
+                if (change_name_off[k] + change_name_len[k] > sam_len) { rc = fail(S, CBC_E_ARG, "contig name outside the text%s%lld", "", 0); break; }
+                rc = contig_open(S, sam + change_name_off[k], change_name_len[k]); k++;
+                if (rc) break;
+            }
+            const cbc_contig_info *ctg = &P->contigs[S->contig];
+            const uint32_t nt = sm[r].nt_ev & 0xffffu, ev = sm[r].nt_ev >> 16;
+            if ((uint64_t)sm[r].pos - 1 + sm[r].rl > ctg->length + CBC_REF_PAD - 8) {
+                rc = fail(S, CBC_E_INPUT, "record at %s POS %lld runs past the contig end + pad", (const char *)P->names + ctg->name_off, sm[r].pos); break; }
+            if (ev + 1 > S->o.max_cap_var) { rc = fail(S, CBC_E_INPUT, "record at %s:%lld has more edits than max_cap_var", (const char *)P->names + ctg->name_off, sm[r].pos); break; }
+            rc = place_record(S, sm[r].pos, sm[r].flag, sm[r].rl, ev, nt);
+        }
+        if (rc) goto done;
+    }
+    if (P->seq_bytes != seq_bytes || P->n_tok != n_tok) { rc = fail(S, CBC_E_ARG, "summaries and array sizes disagree%s%lld", "", 0); goto done; }
+    P->n_skipped_unmapped = n_unmapped;
+    close_block(S);
+    if (seq) { free(P->seq); P->seq = seq; P->cap_seq = seq_bytes + 8; memset(P->seq + seq_bytes, 0, 8); }
+    if (tok) { free(P->tok); P->tok = tok; P->cap_tok = n_tok; }
+    P->seq_bytes += 8;                                  /* the 8 readable pad bytes (the device array has them too) */
+    if (P->caps.cap_pos < 64) P->caps.cap_pos = 64;
+    if (P->caps.cap_var < 64) P->caps.cap_var = 64;
+    P->caps.cap_pos = (P->caps.cap_pos + 63u) & ~63u;
+    P->caps.cap_var = (P->caps.cap_var + 63u) & ~63u;
+    if (P->n_tok == 0 && !P->tok) { if (grow((void **)&P->tok, &P->cap_tok, 1, sizeof(uint32_t))) { rc = CBC_E_NOMEM; goto done; } P->tok[0] = 0; }
+    P->whole_file = 0;
+done:
+    packer_release(S);
+    if (rc) { if (seq && S->P && S->P->seq == seq) S->P->seq = NULL; if (tok && S->P && S->P->tok == tok) S->P->tok = NULL; cbc_packed_free(S->P); *out = NULL; }
+    else *out = S->P;
+    free(S);
+    return rc;
+}
+
 /* ================================= 2-bit transport ======================= */
 typedef struct { const uint8_t *b; uint32_t *codes; uint64_t i0, i1; cbc_2bit_run *runs; uint64_t n_runs, cap_runs; int rc; } twobit_job;
 

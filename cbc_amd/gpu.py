@@ -59,6 +59,18 @@ class StreamResult(ctypes.Structure):
                 ("n_symbols", ctypes.c_uint64)]
 
 
+class TokResult(ctypes.Structure):
+    _fields_ = [("n_lines", ctypes.c_uint64), ("n_recs", ctypes.c_uint64), ("n_unmapped", ctypes.c_uint64), ("seq_bytes", ctypes.c_uint64),
+                ("n_tok", ctypes.c_uint64), ("summaries", ctypes.c_void_p), ("rname_change", ctypes.c_void_p),
+                ("change_name_off", ctypes.c_void_p), ("change_name_len", ctypes.c_void_p), ("n_changes", ctypes.c_uint64),
+                ("d_seq", ctypes.c_void_p), ("d_tok", ctypes.c_void_p), ("status", ctypes.c_uint32), ("bad_line", ctypes.c_uint64)]
+
+
+TOK_STATUS = {3: "the file needs the host packer (leading soft clip or a record without MD)", 4: "fewer than 11 columns",
+              5: "line longer than 1023 bytes", 6: "bad CIGAR length", 7: "CIGAR '*' on a mapped record", 8: "MD gap too large",
+              9: "MD inconsistent with CIGAR/SEQ", 10: "read length outside 1..252", 11: "POS < 1", 12: "too many CIGAR/MD tokens"}
+
+
 class CbcGpuError(RuntimeError):
     pass
 
@@ -118,6 +130,14 @@ def lib():
                                             ctypes.c_uint32, ctypes.POINTER(StreamResult)]
         L.cbc_stream_read_length.restype = ctypes.c_uint32
         L.cbc_stream_read_length.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_gpu_tokenise_sam.restype = ctypes.c_int
+        L.cbc_gpu_tokenise_sam.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(TokResult)]
+        L.cbc_gpu_tokenise_fetch.restype = ctypes.c_int
+        L.cbc_gpu_tokenise_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(TokResult), ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_gpu_tokenise_free.argtypes = [ctypes.c_void_p, ctypes.POINTER(TokResult)]
+        L.cbc_gpu_encode_blocks_tokenised.restype = ctypes.c_int
+        L.cbc_gpu_encode_blocks_tokenised.argtypes = [ctypes.c_void_p, ctypes.POINTER(TokResult), ctypes.POINTER(HostBatch), ctypes.c_void_p,
+                                                      ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         L.cbc_gpu_upload_reference_2bit.restype = ctypes.c_int
         L.cbc_gpu_upload_reference_2bit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
         L.cbc_gpu_encode_blocks_2bit.restype = ctypes.c_int
@@ -154,6 +174,7 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_plan_output", "cbc_gpu_lds_bytes", "cbc_gpu_decode_blocks_device", "cbc_gpu_decode_blocks",
            "cbc_gpu_decode_lds_bytes", "cbc_gpu_last_kernel_ms", "cbc_gpu_last_kernel_variant", "cbc_gpu_synchronize",
            "cbc_gpu_encode_stream", "cbc_gpu_encode_stream_blocks", "cbc_gpu_decode_stream", "cbc_stream_read_length",
+           "cbc_gpu_tokenise_sam", "cbc_gpu_tokenise_fetch", "cbc_gpu_tokenise_free", "cbc_gpu_encode_blocks_tokenised",
            "cbc_gpu_upload_reference_2bit", "cbc_gpu_encode_blocks_2bit", "cbc_gpu_decode_blocks_2bit",
            "cbc_gpu_long_plan_output", "cbc_gpu_long_lds_bytes", "cbc_gpu_long_encode_blocks_device",
            "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks"]
@@ -180,6 +201,57 @@ class Encoder:
     def upload_reference(self, ref: np.ndarray):
         ref = np.ascontiguousarray(ref, dtype=np.uint8)
         self._check(lib().cbc_gpu_upload_reference(self._ctx, ref.ctypes.data, ref.size), "cbc_gpu_upload_reference")
+
+    def tokenise_sam(self, sam: bytes, fasta: bytes, fetch=False, **kw):
+        """SAM text -> packed batch with the tokenising done on the device (cbc_gpu_tokenise_sam + the host's serial half,
+        cbc_pack_from_device_tokens).  Returns (PackedBatch, TokResult): with fetch=False the batch carries no bases / tokens
+        (they stay on the device for encode_blocks_tokenised); fetch=True copies them back (parity tests).  Raises
+        host.CbcInputError with the offending line when the text is malformed or needs the host packer."""
+        tr = TokResult()
+        rc = lib().cbc_gpu_tokenise_sam(self._ctx, sam, len(sam), host.sam_body_offset(sam), ctypes.byref(tr))
+        self._check(rc, "cbc_gpu_tokenise_sam")
+        if tr.status:
+            st, line = int(tr.status), int(tr.bad_line)
+            lib().cbc_gpu_tokenise_free(self._ctx, ctypes.byref(tr))
+            raise host.CbcInputError("device tokeniser: line %d: %s (status %d)" % (line + 1, TOK_STATUS.get(st, "?"), st))
+        n, nc = int(tr.n_recs), int(tr.n_changes)
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((ctypes.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype)
+        summ = view(tr.summaries, n, host.SUMMARY_DTYPE); chg = view(tr.rname_change, n, np.uint8)
+        coff = view(tr.change_name_off, nc, np.uint64); clen = view(tr.change_name_len, nc, np.uint32)
+        seq = tok = None
+        if fetch:
+            seq = np.zeros(int(tr.seq_bytes) + 8, dtype=np.uint8); tok = np.zeros(max(int(tr.n_tok), 1), dtype=np.uint32)
+            self._check(lib().cbc_gpu_tokenise_fetch(self._ctx, ctypes.byref(tr), seq.ctypes.data, tok.ctypes.data), "cbc_gpu_tokenise_fetch")
+        try:
+            pb = host.pack_from_device_tokens(sam, fasta, summ, chg, coff, clen, int(tr.n_unmapped), seq=seq, tok=tok,
+                                              seq_bytes=int(tr.seq_bytes), n_tok=int(tr.n_tok), **kw)
+        except Exception:
+            lib().cbc_gpu_tokenise_free(self._ctx, ctypes.byref(tr))
+            raise
+        return pb, tr
+
+    def tokenise_free(self, tr):
+        lib().cbc_gpu_tokenise_free(self._ctx, ctypes.byref(tr))
+
+    def encode_blocks_tokenised(self, pb, tr):
+        """cbc_gpu_encode_blocks over the tokeniser's device-resident bases and tokens."""
+        nb = pb.n_blocks
+        blocks = pb.blocks.copy()
+        hb = HostBatch(pb.recs.ctypes.data, pb.n_recs, None, int(tr.seq_bytes) + 8, None, int(tr.n_tok),
+                       pb.names.ctypes.data, len(pb.names), blocks.ctypes.data, nb, host.LdsCaps(pb.cap_pos, pb.cap_var))
+        # the planner wants the tokens: worst case from the summaries instead (3 bytes per symbol, 16 per record + 2 per var symbol)
+        total = int(4096 * nb + 3 * (16 * pb.n_recs + 2 * int(tr.n_tok)) + 256 * nb + 8 * int(tr.n_tok))
+        out = np.zeros(total, dtype=np.uint8)
+        offs = np.zeros(nb + 1, dtype=np.uint64)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        rc = lib().cbc_gpu_encode_blocks_tokenised(self._ctx, ctypes.byref(tr), ctypes.byref(hb), out.ctypes.data, out.size,
+                                                   offs.ctypes.data, res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_encode_blocks_tokenised")
+        return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res, offs, out[:int(offs[nb])]
 
     def upload_reference_2bit(self, codes: np.ndarray, runs: np.ndarray, n_bases: int):
         """The reference over PCIe at 2 bits per base (host.pack_2bit), expanded on the device."""

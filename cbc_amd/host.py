@@ -145,6 +145,13 @@ def lib():
         L.cbc_container_write.restype = ctypes.c_int64
         L.cbc_container_write.argtypes = [ctypes.POINTER(Packed), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64),
                                           ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_pack_from_device_tokens.restype = ctypes.c_int
+        L.cbc_pack_from_device_tokens.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(PackOpts),
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                                  ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                                  ctypes.POINTER(ctypes.POINTER(Packed)), ctypes.c_char_p, ctypes.c_size_t]
+        L.cbc_sam_body_offset.restype = ctypes.c_uint64
+        L.cbc_sam_body_offset.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         L.cbc_2bit_pack.restype = ctypes.c_int
         L.cbc_2bit_pack.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.POINTER(TwoBitC))]
         L.cbc_2bit_unpack.restype = ctypes.c_int
@@ -279,6 +286,41 @@ class PackedBatch:
             self.close()
         except Exception:
             pass
+
+
+SUMMARY_DTYPE = np.dtype([("pos", "<u4"), ("flag", "<u2"), ("rl", "<u2"), ("nt_ev", "<u4"), ("line", "<u4")])
+
+
+def sam_body_offset(sam: bytes) -> int:
+    return int(lib().cbc_sam_body_offset(sam, len(sam)))
+
+
+def pack_from_device_tokens(sam: bytes, fasta: bytes, summaries, rname_change, change_off, change_len, n_unmapped,
+                            seq=None, tok=None, seq_bytes=None, n_tok=None, **kw) -> PackedBatch:
+    """The serial half of packing after the device tokeniser (cbc_pack_from_device_tokens): contig numbering and block
+    cutting over the record summaries.  seq / tok: numpy copies of the tokeniser's arrays (the C side keeps its own
+    copies) or None when they stay on the device."""
+    o = _opts(**kw)
+    out = ctypes.POINTER(Packed)()
+    err = ctypes.create_string_buffer(512)
+    summaries = np.ascontiguousarray(summaries, dtype=SUMMARY_DTYPE)
+    rname_change = np.ascontiguousarray(rname_change, dtype=np.uint8)
+    change_off = np.ascontiguousarray(change_off, dtype=np.uint64); change_len = np.ascontiguousarray(change_len, dtype=np.uint32)
+    n = len(summaries)
+    cseq = ctok = None
+    if seq is not None:                       # hand the C side malloc'ed copies it may own
+        libc = ctypes.CDLL(None)
+        libc.malloc.restype = ctypes.c_void_p
+        seq_bytes, n_tok = int(seq_bytes if seq_bytes is not None else len(seq) - 8), int(n_tok if n_tok is not None else len(tok))
+        cseq = libc.malloc(seq_bytes + 16); ctok = libc.malloc(max(n_tok, 1) * 4)
+        ctypes.memmove(cseq, np.ascontiguousarray(seq, dtype=np.uint8).ctypes.data, seq_bytes)
+        ctypes.memmove(ctok, np.ascontiguousarray(tok, dtype=np.uint32).ctypes.data, n_tok * 4)
+    rc = lib().cbc_pack_from_device_tokens(sam, len(sam), fasta, len(fasta), ctypes.byref(o), summaries.ctypes.data,
+                                           rname_change.ctypes.data, change_off.ctypes.data, change_len.ctypes.data, n, n_unmapped,
+                                           cseq, int(seq_bytes), ctok, int(n_tok), ctypes.byref(out), err, 512)
+    if rc != 0:
+        raise CbcInputError("cbc_pack_from_device_tokens failed (%d): %s" % (rc, err.value.decode(errors="replace")))
+    return PackedBatch(out)
 
 
 def pack_2bit(bases: np.ndarray, threads=0):

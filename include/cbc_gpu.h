@@ -301,6 +301,29 @@ int  cbc_gpu_decode_blocks_2bit(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in
                                 uint32_t *codes_out, uint64_t *exc_idx, uint8_t *exc_val, uint64_t exc_cap, uint64_t *n_exc,
                                 cbc_block_result *results);
 
+/* ---- SAM text -> packed records on the device (rules: cbc_amd/csrc/cbc_tok_core.h) ----------
+ * load_sam_line(), src/sam_file_allocation.c:437-529, one GPU thread per line.  The text is copied to the device once;
+ * bases and token words are produced in device memory (where cbc_gpu_encode_blocks_tokenised reads them) and the host
+ * gets 16 bytes per mapped record + one change flag, from which libcbc_host's cbc_pack_from_device_tokens() cuts the
+ * blocks exactly as cbc_pack_sam() does (the arrays are identical; tests).  status != 0: the first offending line
+ * (bad_line, 0-based, '@' lines included) and why (CBC_TOK_* of cbc_tok_core.h: 3 = the file needs the host packer --
+ * a leading soft clip or a record without MD -- 4.. = malformed input). */
+typedef struct cbc_tok_record_summary { uint32_t pos; uint16_t flag, rl; uint32_t nt_ev /* words | var bound << 16 */; uint32_t line; } cbc_tok_record_summary;
+typedef struct cbc_tok_result {
+    uint64_t n_lines, n_recs, n_unmapped, seq_bytes /* without the 8 pad bytes */, n_tok;
+    cbc_tok_record_summary *summaries;      /* host, n_recs                                                     */
+    uint8_t  *rname_change;                 /* host, n_recs: RNAME differs from the previous mapped record's    */
+    uint64_t *change_name_off; uint32_t *change_name_len; uint64_t n_changes;   /* host: where each new RNAME sits in the text */
+    uint8_t  *d_seq; uint32_t *d_tok;       /* device: seq_bytes + 8 zero bytes; n_tok words                    */
+    uint32_t status; uint64_t bad_line;
+} cbc_tok_result;
+int  cbc_gpu_tokenise_sam(cbc_gpu_ctx *ctx, const char *sam, uint64_t sam_len, uint64_t body_off, cbc_tok_result *out);
+int  cbc_gpu_tokenise_fetch(cbc_gpu_ctx *ctx, const cbc_tok_result *t, uint8_t *seq /* seq_bytes + 8 */, uint32_t *tok /* n_tok */);
+void cbc_gpu_tokenise_free(cbc_gpu_ctx *ctx, cbc_tok_result *t);
+/* cbc_gpu_encode_blocks over a batch whose bases and tokens are the tokeniser's device arrays (batch->seq / tok unused) */
+int  cbc_gpu_encode_blocks_tokenised(cbc_gpu_ctx *ctx, const cbc_tok_result *t, const cbc_host_batch *batch,
+                                     uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results);
+
 /* Timing of the most recent encode launch made through this context, measured with HIP events
  * recorded on the launch stream around the kernel (valid after the stream has been synchronised). */
 int  cbc_gpu_last_kernel_ms(cbc_gpu_ctx *ctx, float *ms);

@@ -119,6 +119,20 @@ int64_t cbc_container_size(const cbc_packed *p, const uint64_t *out_offsets);
 int64_t cbc_container_write(const cbc_packed *p, const uint8_t *payloads, const uint64_t *out_offsets,
                             uint8_t *dst, uint64_t dst_cap);
 
+/* ---- the serial half of packing after the DEVICE tokeniser ------------------------------
+ * cbc_gpu_tokenise_sam() (libcbc_gpu) turns the SAM text into bases, token words and one 16-byte summary per mapped
+ * record; what is inherently serial -- contig numbering in file order, block cutting -- happens here, with the very
+ * code path cbc_pack_sam() uses, so the resulting cbc_packed is identical to cbc_pack_sam()'s (tests).  seq / tok:
+ * host copies of the tokeniser's arrays (then owned by the result) or NULL when they stay on the device (the result
+ * then carries the sizes only).  summaries / rname_change / change_name_*: cbc_tok_result's arrays. */
+int  cbc_pack_from_device_tokens(const char *sam, size_t sam_len, const char *fasta, size_t fasta_len, const cbc_pack_opts *opts,
+                                 const void *summaries /* cbc_tok_record_summary[n_recs] */, const uint8_t *rname_change,
+                                 const uint64_t *change_name_off, const uint32_t *change_name_len, uint64_t n_recs, uint64_t n_unmapped,
+                                 uint8_t *seq, uint64_t seq_bytes, uint32_t *tok, uint64_t n_tok,
+                                 cbc_packed **out, char *errbuf, size_t errlen);
+/* offset of the first record line (behind the '@' header lines): the tokeniser's body_off */
+uint64_t cbc_sam_body_offset(const char *sam, size_t sam_len);
+
 /* ---- 2-bit transport of bases ------------------------------------------------
  * Bases travel to the device (reference, reads) and back (decoded reads) at 2 bits each: A C G T = 0 1 2 3, sixteen
  * bases per 32-bit word, base i in bits 2 (i & 15) of word i >> 4.  Every byte that is not one of 'A' 'C' 'G' 'T'

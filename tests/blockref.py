@@ -275,3 +275,23 @@ def emu_long_decode(plan):
     if L.emu_long_decode_blocks(ctypes.byref(db)) != 0:
         raise RuntimeError("emulation reported an invariant violation")
     return recs, seq, res
+
+
+def emu_tokenise(sam: bytes):
+    """cbc_tok_core.h (the device tokeniser's per-line functions) run line by line on the CPU.  Returns a dict like
+    cbc_tok_result, or raises with (status, line)."""
+    L = emu_lib()
+    L.emu_tokenise.restype = ctypes.c_int
+    L.emu_tokenise.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64] + [ctypes.c_void_p] * 7
+    n_max = sam.count(b"\n") + 2
+    summ = np.zeros(n_max, dtype=host.SUMMARY_DTYPE); chg = np.zeros(n_max, dtype=np.uint8)
+    coff = np.zeros(n_max, dtype=np.uint64); clen = np.zeros(n_max, dtype=np.uint32)
+    seq = np.zeros(len(sam) + 16, dtype=np.uint8); tok = np.zeros(len(sam) // 2 + 4096, dtype=np.uint32)
+    counts = np.zeros(8, dtype=np.uint64)
+    st = L.emu_tokenise(sam, len(sam), host.sam_body_offset(sam), summ.ctypes.data, chg.ctypes.data, coff.ctypes.data, clen.ctypes.data,
+                        seq.ctypes.data, tok.ctypes.data, counts.ctypes.data)
+    if st != 0:
+        raise ValueError((st, int(counts[6])))
+    n_lines, n_recs, n_unm, sb, nt, nc = (int(x) for x in counts[:6])
+    return dict(n_lines=n_lines, n_recs=n_recs, n_unmapped=n_unm, seq_bytes=sb, n_tok=nt, summaries=summ[:n_recs], rname_change=chg[:n_recs],
+                change_off=coff[:nc], change_len=clen[:nc], seq=seq[:sb + 8], tok=tok[:nt])

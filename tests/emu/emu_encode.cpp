@@ -11,6 +11,7 @@
 #include "../../cbc_amd/csrc/cbc_plan.h"
 #include "../../cbc_amd/csrc/cbc_stream_body.h"
 #include "../../cbc_amd/csrc/cbc_long_body.h"
+#include "../../cbc_amd/csrc/cbc_tok_core.h"
 
 static int g_emu_errors = 0;
 #ifdef CBC_EMU_TRACE
@@ -112,4 +113,40 @@ int emu_long_decode_blocks(const cbc_dec_device_batch *b)
         cbc_long_decode<WaveEmu>(A, blk, lds.data());
     }
     return g_emu_errors ? -100 : 0;
+}
+
+/* The device tokeniser's per-line / per-record functions (cbc_tok_core.h) run line by line on the CPU, producing
+ * what cbc_gpu_tokenise_sam() produces: summaries, change flags + names, bases, token words.  Returns the first
+ * non-zero status (and its line) or 0. */
+extern "C" __attribute__((visibility("default")))
+int emu_tokenise(const uint8_t *sam, uint64_t len, uint64_t body_off, cbc_tok_summary *sum, uint8_t *chg, uint64_t *chg_off, uint32_t *chg_len,
+                 uint8_t *seq, uint32_t *tok, uint64_t *counts /* n_lines, n_recs, n_unmapped, seq_bytes, n_tok, n_changes, bad_line */)
+{
+    uint64_t n_lines = 0, n_recs = 0, n_unm = 0, sb = 0, ntok = 0, nchg = 0;
+    uint64_t prev_off = 0; uint32_t prev_len = 0; int have_prev = 0;
+    for (uint64_t b = 0; b < len; n_lines++) {
+        uint64_t e = b;
+        while (e < len && sam[e] != '\n') e++;
+        if (e < len) e++;
+        cbc_tok_line L;
+        uint32_t st;
+        if (b < body_off) st = CBC_TOK_SKIP; else { cbc_tok_split(sam, b, e, &L); st = L.status; }
+        uint32_t nt = 0, ev = 0;
+        if (st == CBC_TOK_OK) st = cbc_tok_record(sam, &L, tok + ntok, &nt, &ev);
+        if (st >= CBC_TOK_NEEDS_HOST) { counts[6] = n_lines; return (int)st; }
+        if (st == CBC_TOK_UNMAPPED) n_unm++;
+        if (st == CBC_TOK_OK) {
+            cbc_tok_summary s; s.pos = (uint32_t)L.pos; s.flag = (uint16_t)L.flag; s.rl = (uint16_t)L.seq_len; s.nt_ev = nt | (ev << 16); s.line = (uint32_t)n_lines;
+            sum[n_recs] = s;
+            memcpy(seq + sb, sam + L.seq, L.seq_len);
+            int change = !have_prev || prev_len != L.rname_len || memcmp(sam + prev_off, sam + L.rname, prev_len) != 0;
+            chg[n_recs] = (uint8_t)change;
+            if (change) { chg_off[nchg] = L.rname; chg_len[nchg] = L.rname_len; nchg++; }
+            prev_off = L.rname; prev_len = L.rname_len; have_prev = 1;
+            n_recs++; sb += L.seq_len; ntok += nt;
+        }
+        b = e;
+    }
+    counts[0] = n_lines; counts[1] = n_recs; counts[2] = n_unm; counts[3] = sb; counts[4] = ntok; counts[5] = nchg; counts[6] = 0;
+    return 0;
 }

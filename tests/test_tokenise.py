@@ -1,0 +1,137 @@
+"""The device SAM tokeniser: cbc_amd/csrc/cbc_tok_core.h holds its per-line / per-record
+functions; the same functions run line by line on the CPU here (tests/emu) and one thread per line on the GPU (-m gpu).
+Parity = the resulting packed batch is IDENTICAL, array for array, to the host packer's (cbc_pack_sam)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import blockref
+import synth
+from cbc_amd import gpu, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARRAYS = ("recs", "seq", "tok", "blocks", "info", "names", "contigs")
+
+
+def _same(pd, ph):
+    for k in ARRAYS:
+        assert getattr(pd, k).tobytes() == getattr(ph, k).tobytes(), k
+    assert (pd.cap_pos, pd.cap_var, pd.read_length, pd.n_bases, pd.n_skipped_unmapped) == (ph.cap_pos, ph.cap_var, ph.read_length, ph.n_bases, ph.n_skipped_unmapped)
+
+
+def _emu_pack(sam, fa, **kw):
+    t = blockref.emu_tokenise(sam)
+    return host.pack_from_device_tokens(sam, fa, t["summaries"], t["rname_change"], t["change_off"], t["change_len"], t["n_unmapped"],
+                                        seq=t["seq"], tok=t["tok"], seq_bytes=t["seq_bytes"], n_tok=t["n_tok"], **kw)
+
+
+SHAPES = [
+    (dict(), 150, 1024),
+    (dict(sub_rate=0.02, indel_frac=0.5, dup_pos_frac=0.1, trailing_s_frac=0.2), 100, 512),
+    (dict(flags=(0, 16, 83, 99, 147, 163, 4, 77)), 150, 2048),          # unmapped records (FLAG & 4) are dropped
+    (dict(sub_rate=0.45, indel_frac=0.3), 150, 256),
+]
+
+
+@pytest.mark.parametrize("kw,L,br", SHAPES)
+def test_core_equals_host_packer(built, kw, L, br):
+    fa, sam, _, _ = synth.dataset(5, [300000, 120000], [2500, 900], L, **kw)
+    _same(_emu_pack(sam, fa, block_reads=br), host.pack_sam(sam, fa, block_reads=br, threads=1))
+
+
+def test_core_quirks_and_limits(built):
+    # Q2: MD as the last column keeps its newline -> the phantom N token
+    fa, _, rbc, _ = synth.dataset(9, [100000], [600], 100, sub_rate=0.02, indel_frac=0.0)
+    sam = synth.sam_text(rbc, md_last=True)
+    _same(_emu_pack(sam, fa, block_reads=200), host.pack_sam(sam, fa, block_reads=200, threads=1))
+    # header lines, a last line without '\n', consecutive tabs (strtok skips empty columns)
+    fa, sam, _, _ = synth.dataset(10, [60000], [50], 100)
+    sam2 = b"@HD\tVN:1.6\n@SQ\tSN:x\tLN:60000\n" + sam.rstrip(b"\n").replace(b"\t60\t", b"\t\t60\t", 5)
+    _same(_emu_pack(sam2, fa), host.pack_sam(sam2, fa, threads=1))
+    # what the device path hands to the host packer (status 3) and what it refuses like the host packer does
+    from test_emu_parity import _soft_clip_sam
+    fas, sams = _soft_clip_sam(3)
+    with pytest.raises(ValueError) as e:
+        blockref.emu_tokenise(sams)
+    assert e.value.args[0][0] == 3
+    fa, sam, _, _ = synth.dataset(10, [60000], [50], 100, sub_rate=0.03, indel_frac=0.0)
+    lines = sam.splitlines(keepends=True)
+    import re
+    k = next(i for i, ln in enumerate(lines) if re.search(rb"MD:Z:(\d+)[ACGT]", ln) and int(re.search(rb"MD:Z:(\d+)[ACGT]", ln).group(1)) >= 20)
+    for mutate, status in ((lambda f: f[:11], 3),                                             # no MD field
+                           (lambda f: f[:5] + [b"*"] + f[6:], 7),
+                           (lambda f: f[:9], 4),
+                           (lambda f: f[:9] + [f[9][:10]] + f[10:], 9),                       # the MD names a mismatch beyond the SEQ
+                           (lambda f: f[:9] + [f[9] * 3] + f[10:], 10)):
+        f = lines[k].rstrip(b"\n").split(b"\t")
+        bad = b"".join(lines[:k]) + b"\t".join(mutate(f)) + b"\n" + b"".join(lines[k + 1:])
+        with pytest.raises(ValueError) as e:
+            blockref.emu_tokenise(bad)
+        assert e.value.args[0] == (status, k), (status, e.value.args)
+        if status != 3:
+            with pytest.raises(host.CbcInputError):
+                host.pack_sam(bad, fa, threads=1)
+    long_line = b"".join(lines[:2]) + lines[2].rstrip(b"\n") + b"\tXX:Z:" + b"y" * 900 + b"\n"
+    with pytest.raises(ValueError) as e:
+        blockref.emu_tokenise(long_line)
+    assert e.value.args[0] == (5, 2)
+
+
+# ----------------------------------------------------------------------------------------- on the GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,L,br", SHAPES)
+def test_gpu_tokeniser_equals_host_packer(built, kw, L, br):
+    enc = gpu.Encoder(0)
+    fa, sam, _, _ = synth.dataset(5, [300000, 120000], [2500, 900], L, **kw)
+    pd, tr = enc.tokenise_sam(sam, fa, fetch=True, block_reads=br)
+    ph = host.pack_sam(sam, fa, block_reads=br)
+    _same(pd, ph)
+    # encode straight from the tokeniser's device arrays == encode of the host-packed batch
+    enc.upload_reference(ph.ref)
+    p_dev, r_dev, _, _ = enc.encode_blocks_tokenised(pd, tr)
+    p_host, r_host, _, _ = enc.encode_blocks(ph)
+    assert (r_dev["status"] == 0).all() and p_dev == p_host
+    enc.tokenise_free(tr)
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tokeniser_large_and_errors(built):
+    enc = gpu.Encoder(0)
+    pb, sam, fa = host.synth(0xCBC00002, 30_000_000, 1_000_000, 150, want_text=True)       # 358 MB of text, 1 M lines
+    pd, tr = enc.tokenise_sam(sam, fa, fetch=True)
+    _same(pd, pb)
+    enc.tokenise_free(tr)
+    from test_emu_parity import _soft_clip_sam
+    fas, sams = _soft_clip_sam(3)
+    with pytest.raises(host.CbcInputError, match="needs the host packer"):
+        enc.tokenise_sam(sams, fas)
+    lines = sam.splitlines(keepends=True)[:100]
+    f = lines[40].split(b"\t"); f[5] = b"*"
+    with pytest.raises(host.CbcInputError, match="line 41"):
+        enc.tokenise_sam(b"".join(lines[:40]) + b"\t".join(f) + b"".join(lines[41:]), fa)
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_cli_device_parse(built, tmp_path):
+    """`cbc -c --device-parse` writes the same container as the host-parsed run; with leading soft clips it falls back."""
+    exe = os.path.join(ROOT, "cbc_amd", "csrc", "cbc")
+    fa, sam, _, _ = synth.dataset(8, [200000, 80000], [3000, 1000], 100, sub_rate=0.01, indel_frac=0.2)
+    (tmp_path / "in.sam").write_bytes(sam); (tmp_path / "ref.fa").write_bytes(fa)
+    outs = []
+    for extra in ([], ["--device-parse"]):
+        o = tmp_path / ("o%d.cbc" % len(outs))
+        r = subprocess.run([exe, "-c", str(tmp_path / "in.sam"), str(o), str(tmp_path / "ref.fa"), "--block-reads", "1000"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(o.read_bytes())
+    assert outs[0] == outs[1]
+    from test_emu_parity import _soft_clip_sam
+    fas, sams = _soft_clip_sam(3)
+    (tmp_path / "s.sam").write_bytes(sams); (tmp_path / "s.fa").write_bytes(fas)
+    r = subprocess.run([exe, "-c", str(tmp_path / "s.sam"), str(tmp_path / "s1.cbc"), str(tmp_path / "s.fa"), "--device-parse", "--verbose"], capture_output=True, text=True)
+    assert r.returncode == 0 and "parsing on the host" in r.stdout, r.stdout + r.stderr
+    r2 = subprocess.run([exe, "-c", str(tmp_path / "s.sam"), str(tmp_path / "s2.cbc"), str(tmp_path / "s.fa")], capture_output=True, text=True)
+    assert (tmp_path / "s1.cbc").read_bytes() == (tmp_path / "s2.cbc").read_bytes()
