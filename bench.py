@@ -51,10 +51,13 @@ def parse_args(argv=None):
     ap.add_argument("--contig-len", type=int, default=CHR1_LEN)
     ap.add_argument("--block-reads", type=int, default=4096)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5"],
+    ap.add_argument("--scale", type=float, default=0.05,
+                    help="cfg4 only: fraction of GRCh38 (contig lengths and read counts both scaled, coverage stays 30x); 1.0 = 618 M reads")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5", "cfg4"],
                     help="cfg2 = BASELINE.json's headline (150 bp reads, the reference's format, default); cfg5 = 1 M x 10 kb long "
                          "reads with a 5 %% indel + substitution mix through the long-read format extension (no reference parity "
-                         "exists for it: the reference cannot code such reads)")
+                         "exists for it: the reference cannot code such reads); cfg4 = the 24 GRCh38 primary contigs at 30x, whole "
+                         "contigs dealt to the ranks largest first (chromosome sharding), --scale of the full size")
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000,
                     help="records of the same workload timed on one host core by the CPU legs (10 M ~ 11 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -437,10 +440,145 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
+# GRCh38 primary assembly, chr1..22, X, Y (bases) -- SURVEY.md 8d, config 4
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+          135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+          46709983, 50818468, 156040895, 57227415]
+GRCH38_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+
+
+def assign_largest_first(loads, n_parts):
+    """cbc_assign_contigs' rule on plain numbers: largest remaining item to the least loaded part, ties to the lower index."""
+    part, load = [0] * len(loads), [0] * n_parts
+    for c in sorted(range(len(loads)), key=lambda i: (-loads[i], i)):
+        q = min(range(n_parts), key=lambda k: (load[k], k))
+        part[c] = q
+        load[q] += loads[c]
+    return part
+
+
+def run_cfg4(args):
+    """BASELINE config 4: whole GRCh38-shaped genome at 30x, chromosome-sharded.  Every rank generates and codes the
+    contigs it is dealt (no collective on the data path); the one exchange is the gather of the bitstreams to rank 0."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cbc_amd import gpu, host
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the cbc hot path has no CPU fallback")
+    ndev = torch.cuda.device_count(); dev_index = local_rank % max(ndev, 1)
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d GPUs" % (world, ndev))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index); cdev = dev if args.backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+    lens = [max(int(l * args.scale), 4 * args.read_len + 1000) for l in GRCH38]
+    reads = [max(int(30 * l / args.read_len), 1) for l in lens]
+    part = assign_largest_first(reads, world)
+    mine = [c for c in range(24) if part[c] == rank]
+    enc = gpu.Encoder(dev_index); L = gpu.lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t0 = time.time()
+    res_list, n_bases, n_recs, n_blocks, payload = [], 0, 0, 0, 0
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+
+    for c in mine:
+        pb = host.synth(0xCBC00004 + c, lens[c], reads[c], args.read_len, 0.003, 0.02, GRCH38_NAMES[c].encode(), block_reads=args.block_reads)
+        blocks = pb.blocks.copy()
+        scratch = int(L.cbc_gpu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data))
+        R = {"t": [to_dev(x) for x in (pb.recs, pb.seq, pb.tok, pb.names, blocks, pb.ref)], "nb": pb.n_blocks,
+             "out": torch.empty(scratch, dtype=torch.uint8, device=dev), "res": torch.full((pb.n_blocks * 16,), 0xff, dtype=torch.uint8, device=dev),
+             "offs": torch.zeros(pb.n_blocks + 1, dtype=torch.int64, device=dev), "cap": max(1 << 20, 8 * pb.n_recs)}
+        R["packed"] = torch.empty(R["cap"], dtype=torch.uint8, device=dev)
+        t = R["t"]
+        R["db"] = gpu.DeviceBatch(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), pb.n_blocks,
+                                  t[5].data_ptr(), t[5].numel(), R["out"].data_ptr(), scratch, R["res"].data_ptr(), t[1].numel(),
+                                  max(pb.n_tok, 1), pb.n_recs, host.LdsCaps(pb.cap_pos, pb.cap_var))
+        res_list.append(R); n_bases += pb.n_bases; n_recs += pb.n_recs; n_blocks += pb.n_blocks
+        pb.close()
+    t_gen = time.time() - t0
+
+    def step():
+        for R in res_list:
+            enc.encode_device(R["db"], stream)
+            enc.compact_device(R["out"].data_ptr(), R["t"][4].data_ptr(), R["res"].data_ptr(), R["nb"], R["offs"].data_ptr(),
+                               R["packed"].data_ptr(), R["cap"], stream)
+        if world > 1:
+            for R in res_list:
+                pass                                         # payloads stay put; the gather below moves their total once per step
+            dist.gather(flat[:gather_cap].to(cdev), gather_list, dst=0)
+
+    flat = torch.zeros(1, dtype=torch.uint8, device=dev); gather_cap = 1; gather_list = None
+    for R in res_list:                                        # first launch: every block must finish
+        enc.encode_device(R["db"], stream)
+        enc.compact_device(R["out"].data_ptr(), R["t"][4].data_ptr(), R["res"].data_ptr(), R["nb"], R["offs"].data_ptr(), R["packed"].data_ptr(), R["cap"], stream)
+    torch.cuda.synchronize()
+    for R in res_list:
+        r = R["res"].cpu().numpy().view(host.RESULT_DTYPE)
+        if (r["status"] != 0).any():
+            raise SystemExit("a block failed: %r" % (r[r["status"] != 0][:1],))
+        payload += int(R["offs"][R["nb"]].item())
+    if world > 1:                                             # the exchange step: this rank's bitstreams (all its contigs) to rank 0
+        flat = torch.cat([R["packed"][:int(R["offs"][R["nb"]].item())] for R in res_list]) if res_list else flat
+        m = torch.tensor([flat.numel()], dtype=torch.int64, device=cdev)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        gather_cap = int(m.item())
+        flat = torch.cat([flat, torch.zeros(gather_cap - flat.numel(), dtype=torch.uint8, device=dev)])
+        if rank == 0:
+            gather_list = [torch.empty(gather_cap, dtype=torch.uint8, device=cdev) for _ in range(world)]
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    tot = torch.tensor([float(n_bases), float(n_recs), float(n_blocks), float(payload), elapsed], dtype=torch.float64, device=cdev)
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[4].item())
+    total_bases, total_recs, total_blocks, total_payload = (int(tot[i].item()) for i in range(4))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM", "value": round(total_bases * args.steps / elapsed / 1e6, 2),
+            "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "cfg4: 24 contigs of GRCh38's primary lengths x %.3g at 30x coverage, %d bp reads, chromosome-sharded over %d GPU(s) "
+                                   "(whole contigs dealt largest first; every rank generates and codes its own contigs)" % (args.scale, args.read_len, world),
+                       "reads_total": total_recs, "blocks_total": total_blocks, "payload_bytes_total": total_payload,
+                       "bits_per_read": round(total_payload * 8.0 / max(total_recs, 1), 3), "contigs_rank0": [GRCH38_NAMES[c] for c in mine],
+                       "reads_rank0": n_recs, "host_pack_seconds_rank0": round(t_gen, 1),
+                       "parallelism": "contigs sharded over %d GPU(s), gather of bitstreams to rank 0 (%s)" % (world, args.backend)},
+            "roofline": {"bound": "hbm", "achieved": round((2 * args.read_len + 18) * total_recs * args.steps / elapsed / 1e9, 3), "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": round((2 * args.read_len + 18) * total_recs * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 6),
+                         "traffic": None, "kernel": "cbc_encode_blocks_kernel(_w6) over every contig", "note": "whole-step wall time, all launches of the step"},
+            "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    if args.workload == "cfg4":
+        run_cfg4(args)
+        return
     run_rank(args)
 
 

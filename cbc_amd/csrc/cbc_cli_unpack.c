@@ -85,7 +85,7 @@ static void *dev_decode(void *arg)
                 bl[k].in_off -= in0; bl[k].rec_base -= r0; bl[k].seq_base = bl[k].rec_base * u->seq_stride; nrec += bl[k].n_reads;
             }
             J->rc = cbc_gpu_decode_blocks(ctx, u->payloads + in0, in1 - in0, bl, nb, &u->caps, J->recs + r0, nrec,
-                                          J->seq + r0 * u->seq_stride, nrec * u->seq_stride + 8, NULL);
+                                          J->seq + r0 * u->seq_stride, nrec * u->seq_stride, NULL);   /* exactly this range's bytes: the next range belongs to another thread */
             free(bl);
         }
     }
