@@ -505,14 +505,19 @@ def run_cfg4(args):
         pb.close()
     t_gen = time.time() - t0
 
+    # one launch per contig; the launches of a step go round-robin over four HIP streams so that small contigs overlap
+    side = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    hs = [ctypes.c_void_p(x.cuda_stream) for x in side]
+
     def step():
-        for R in res_list:
-            enc.encode_device(R["db"], stream)
+        for i, R in enumerate(res_list):
+            q = hs[i % len(hs)]
+            enc.encode_device(R["db"], q)
             enc.compact_device(R["out"].data_ptr(), R["t"][4].data_ptr(), R["res"].data_ptr(), R["nb"], R["offs"].data_ptr(),
-                               R["packed"].data_ptr(), R["cap"], stream)
+                               R["packed"].data_ptr(), R["cap"], q)
+        for x in side:
+            x.synchronize()
         if world > 1:
-            for R in res_list:
-                pass                                         # payloads stay put; the gather below moves their total once per step
             dist.gather(flat[:gather_cap].to(cdev), gather_list, dst=0)
 
     flat = torch.zeros(1, dtype=torch.uint8, device=dev); gather_cap = 1; gather_list = None

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <stdint.h>
 #include <new>
+#include <time.h>
 
 #include "../../include/cbc_gpu.h"
 #include "cbc_wave_gpu.h"
@@ -1077,8 +1078,12 @@ API int cbc_gpu_tokenise_sam(cbc_gpu_ctx *ctx, const char *sam, uint64_t len, ui
     cbc_tok_perline bad_pl;
 #define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
 #define GOR(call) do { rc = (call); if (rc) goto done; } while (0)
+    const bool times = getenv("CBC_TOK_TIMES") != NULL;            /* diagnostic: stage wall times on stderr */
+    auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double T0 = now(), T1 = T0, T2 = T0, T3 = T0;
     GO(hipMalloc(&d_sam, len + 64), "hipMalloc SAM text");
     GO(hipMemcpyAsync(d_sam, sam, len, hipMemcpyHostToDevice, ctx->stream), "H2D SAM text");
+    if (times) { GO(hipStreamSynchronize(ctx->stream), "H2D SAM text"); T1 = now(); }
     GO(hipMalloc(&d_tc, n_tiles * 4 + 16), "hipMalloc tiles");
     GO(hipMalloc(&d_tb, n_tiles * 8 + 16), "hipMalloc tiles");
     GO(hipMalloc(&d_tmp, (len / 1024 + n_tiles / 1024 + 16) * 8), "hipMalloc scan scratch");   /* block totals of the largest scan: n_lines <= len */
@@ -1110,6 +1115,7 @@ API int cbc_gpu_tokenise_sam(cbc_gpu_ctx *ctx, const char *sam, uint64_t len, ui
     GOR(scan_u32(ctx, (const uint32_t *)d_vnt, n_lines, (uint64_t *)d_tokof, (uint64_t *)d_tmp, &n_tok));
     GO(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream), "D2H counters");
     GO(hipStreamSynchronize(ctx->stream), "tokenise pass 1");
+    T2 = now();
     out->n_lines = n_lines; out->n_recs = n_recs; out->n_unmapped = cnt[1]; out->seq_bytes = seq_bytes; out->n_tok = n_tok;
     if (cnt[0] != ~0ull) {                                    /* a line the device path does not take: say which and why */
         GO(hipMemcpy(&bad_pl, (cbc_tok_perline *)d_pl + cnt[0], sizeof bad_pl, hipMemcpyDeviceToHost), "D2H status");
@@ -1139,6 +1145,9 @@ API int cbc_gpu_tokenise_sam(cbc_gpu_ctx *ctx, const char *sam, uint64_t len, ui
     GO(hipMemcpyAsync(out->summaries, d_sum, n_recs * sizeof(cbc_tok_summary), hipMemcpyDeviceToHost, ctx->stream), "D2H summaries");
     GO(hipMemcpyAsync(out->rname_change, d_chg, n_recs, hipMemcpyDeviceToHost, ctx->stream), "D2H change flags");
     GO(hipStreamSynchronize(ctx->stream), "tokenise pass 2");
+    T3 = now();
+    if (times) fprintf(stderr, "tokenise: H2D of %.0f MB %.3f s, line index + parse + scans %.3f s, emit + bases + D2H of the summaries %.3f s\n",
+                       (double)len / 1e6, T1 - T0, T2 - T1, T3 - T2);
     {   /* where each new RNAME sits in the text: one small copy per contig change */
         uint64_t nc = 0;
         for (uint64_t r = 0; r < n_recs; r++) nc += out->rname_change[r] != 0;

@@ -220,8 +220,9 @@ class PackedBatch:
         self._ptr = ptr
         p = ptr.contents
         self.recs = _np_view(p.recs, p.n_recs, REC_DTYPE)
-        self.seq = _np_view(p.seq, p.seq_bytes, np.uint8)
-        self.tok = _np_view(p.tok, max(int(p.n_tok), 1), np.uint32)
+        # a batch from the device tokeniser may carry sizes only: the bases and tokens are resident on the GPU
+        self.seq = _np_view(p.seq, p.seq_bytes, np.uint8) if p.seq else np.zeros(0, dtype=np.uint8)
+        self.tok = _np_view(p.tok, max(int(p.n_tok), 1), np.uint32) if p.tok else np.zeros(0, dtype=np.uint32)
         self.names = _np_view(p.names, p.names_bytes, np.uint8)
         self.blocks = _np_view(p.blocks, p.n_blocks, BLOCK_DTYPE)
         self.info = _np_view(p.info, p.n_blocks, INFO_DTYPE)

@@ -18,6 +18,17 @@ exe = os.path.join("cbc_amd", "csrc", "cbc")
 for rep in range(2):
     t = time.time(); r = subprocess.run([exe, "-c", d + "/a.sam", d + "/a.cbc", d + "/a.fa", "--verbose"], capture_output=True, text=True); dt = time.time() - t
     print(r.stdout.strip(), r.stderr.strip()); print("cbc -c wall %.2fs -> %.1f Mbases/s end to end" % (dt, n * 150 / dt / 1e6), flush=True)
+for rep in range(2):       # the same with the text tokenised on the device (cbc_gpu_tokenise_sam): identical container
+    t = time.time(); r = subprocess.run([exe, "-c", d + "/a.sam", d + "/b.cbc", d + "/a.fa", "--verbose", "--device-parse"], capture_output=True, text=True); dt = time.time() - t
+    print(r.stdout.strip(), r.stderr.strip()); print("cbc -c --device-parse wall %.2fs -> %.1f Mbases/s end to end; same container: %s" % (
+        dt, n * 150 / dt / 1e6, open(d + "/a.cbc", "rb").read() == open(d + "/b.cbc", "rb").read()), flush=True)
+# tokeniser alone, in process (text already in memory): device vs the threaded host packer
+from cbc_amd import gpu
+enc = gpu.Encoder(0)
+for rep in range(3):
+    t = time.time(); pd, tr = enc.tokenise_sam(sam, fa); dt = time.time() - t
+    print("device tokeniser + host block cutting %.3fs  %.0f MB/s of SAM text  %.1f Mbases/s (H2D of the text included)" % (dt, len(sam) / dt / 1e6, n * 150 / dt / 1e6), flush=True)
+    enc.tokenise_free(tr); del pd
 t = time.time(); r = subprocess.run([exe, "-d", d + "/a.cbc", d + "/a.txt", d + "/a.fa"], capture_output=True, text=True); dt = time.time() - t
 print(r.stdout.strip(), r.stderr.strip()); print("cbc -d wall %.2fs" % dt)
 want = b"".join(l.split(b"\t")[9] + b"\n" for l in sam.split(b"\n") if l)
