@@ -659,80 +659,93 @@ struct CbcDec {
             const V32 bo = ln * 4u;
             uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
             if (D.status == CBC_ST_OK && nSnp == 0u) {
-                uint32_t c3[3] = { 0u, 0u, 0u };
-#pragma unroll 1
-                for (uint32_t q = 0; q < 3u; q++) {
-                    const uint32_t v = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-                    c3[0] = q == 0u ? v : c3[0]; c3[1] = q == 1u ? v : c3[1]; c3[2] = q == 2u ? v : c3[2];
-                }
-                nSnp = c3[0]; nDel = c3[1]; nIns = c3[2];
+                nSnp = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nDel = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nIns = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
             }
             if (D.status != CBC_ST_OK) return false;
             if (nIns > rl) { D.fail(CBC_ST_ASSERT); return false; }
-            /* ONE loop codes the three edit lists (deletions, SNPs, insertions: read_decompression.c:417-519) so that
-             * var_dec and the chars search are instantiated once: the kernel's code has to share an instruction cache
-             * with nine other wavefronts.  An SNP-only read (the common imperfect read) is the reference window with a
-             * few bytes replaced and is patched in the register that holds it (`fast`); a read with indels goes through
-             * the LDS scratch read: deletions shift the gather, insertions are merged by counting. */
-            const bool fast = (nDel | nIns) == 0u;
-            const uint32_t T = rl - nIns;                          /* insertion-free length */
-            V32 w = refw;
-            for (uint32_t phase = fast ? 1u : 0u; phase < (fast ? 2u : 3u) && D.status == CBC_ST_OK; phase++) {
-                const uint32_t n = phase == 0u ? nDel : phase == 1u ? nSnp : nIns;
-                if (phase == 1u && !fast) {
-                    /* insertion-free read from the reference: base m comes from ref[pos-1 + m + #{dels at <= m}] */
-                    for (uint32_t b = 0; b < T; b += 64u) {
-                        V32 m = ln + b;
-                        V32 sh = W::splat(0u);
-                        for (uint32_t d = 0; d < nDel; d++) { uint32_t dc = W::read_uni(dels, d); sh = sh + W::select(m >= dc, W::splat(1u), W::splat(0u)); }
-                        V32 ch = W::load8(refb + (pos - 1u), m + sh, (m < T) & ((m + sh) < 512u));
-                        W::store8(tmpb, m, ch, m < T);
-                    }
-                }
+            if ((nDel | nIns) == 0u) {
+                /* SNPs only (read_decompression.c:440-458): the read is the reference window with a few
+                 * bytes replaced -- patched in the register that holds 4 bases per lane, no LDS scratch read */
+                V32 w = refw;
                 uint32_t p = 0;
-#pragma unroll 1
-                for (uint32_t k = 0; k < n && D.status == CBC_ST_OK; k++) {
-                    const uint32_t ctx = phase == 1u ? ((((D.win_first(p, rl) << 7) + p) << 1) | strand) : ((p << 1) | strand);
-                    const uint32_t g = D.var_dec(ctx);
+                for (uint32_t sidx = 0; sidx < nSnp && D.status == CBC_ST_OK; sidx++) {
+                    uint32_t dl = D.win_first(p, rl);
+                    uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
                     if (D.status != CBC_ST_OK) return false;
-                    if (phase == 0u) { p += g; W::write_uni(dels, k, p); continue; }      /* cumulative matched coordinate of the deleted base */
-                    uint32_t at = 0, row = 5u;
-                    if (phase == 1u) {
-                        at = p + g; p += g + 1u;
-                        D.win_set(p - 1u);
-                        const uint32_t shf = (at & 3u) * 8u;
-                        uint32_t refch = 0u;                       /* the reference-derived base is the chars context (:454-455) */
-                        if (fast) { if (at < rl) refch = (W::readlane(w, (at >> 2) & 63u) >> shf) & 0xffu; }
-                        else if (at < T) refch = (W::read_uni(tmpw, at >> 2) >> shf) & 0xffu;
-                        row = cbc_basepair(refch);
-                    } else p += g;
-                    const uint32_t alt = D.small_dec(CBC_LT_CHARS + row * 8u, 5u, 8u);
-                    if (phase == 1u) {
-                        const uint32_t shf = (at & 3u) * 8u;
-                        if (fast) { if (at < rl) w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w); }
-                        else if (at < T) { uint32_t wv = W::read_uni(tmpw, at >> 2); W::write_uni(tmpw, at >> 2, (wv & ~(0xffu << shf)) | (cbc_basechar(alt) << shf)); }
-                    } else W::write_uni(insl, k, ((p + k) << 8) | cbc_basechar(alt));       /* output index = matched coordinate + earlier insertions */
+                    uint32_t at = p + g;
+                    p += g + 1u;
+                    D.win_set(p - 1u);
+                    const uint32_t shf = (at & 3u) * 8u;
+                    uint32_t refch = at < rl ? ((W::readlane(w, (at >> 2) & 63u) >> shf) & 0xffu) : 0u;
+                    uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
+                    if (at < rl)
+                        w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w);
+                }
+                if (D.status != CBC_ST_OK) return false;
+                W::store32_bytes(dst, bo, w, bo < rl);
+            } else {
+            const uint32_t T = rl - nIns;                          /* insertion-free length */
+            /* deletions: cumulative matched coordinate of each deleted base */
+            uint32_t p = 0;
+            for (uint32_t d = 0; d < nDel && D.status == CBC_ST_OK; d++) {
+                uint32_t g = D.var_dec((p << 1) | strand);
+                p += g;
+                W::write_uni(dels, d, p);
+            }
+            if (D.status != CBC_ST_OK) return false;
+            /* insertion-free read from the reference: base m comes from ref[pos-1 + m + #{dels at <= m}] */
+            for (uint32_t b = 0; b < T; b += 64u) {
+                V32 m = ln + b;
+                V32 sh = W::splat(0u);
+                for (uint32_t d = 0; d < nDel; d++) { uint32_t dc = W::read_uni(dels, d); sh = sh + W::select(m >= dc, W::splat(1u), W::splat(0u)); }
+                V32 ch = W::load8(refb + (pos - 1u), m + sh, (m < T) & ((m + sh) < 512u));
+                W::store8(tmpb, m, ch, m < T);
+            }
+            /* SNPs (read_decompression.c:440-458) */
+            p = 0;
+            for (uint32_t s = 0; s < nSnp && D.status == CBC_ST_OK; s++) {
+                uint32_t dl = D.win_first(p, rl);
+                uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
+                if (D.status != CBC_ST_OK) return false;
+                uint32_t at = p + g;
+                p += g + 1u;
+                D.win_set(p - 1u);
+                uint32_t refch = at < T ? ((W::read_uni(tmpw, at >> 2) >> ((at & 3u) * 8u)) & 0xffu) : 0u;
+                uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
+                if (at < T) {
+                    uint32_t wv = W::read_uni(tmpw, at >> 2), shf = (at & 3u) * 8u;
+                    W::write_uni(tmpw, at >> 2, (wv & ~(0xffu << shf)) | (cbc_basechar(alt) << shf));
                 }
             }
             if (D.status != CBC_ST_OK) return false;
-            if (fast) W::store32_bytes(dst, bo, w, bo < rl);
-            else {
-                for (uint32_t b = 0; b < rl; b += 64u) {
-                    V32 q = ln + b;
-                    V32 nb = W::splat(0u), isins = W::splat(0u), ich = W::splat(0u);
-                    for (uint32_t i = 0; i < nIns; i++) {
-                        uint32_t e = W::read_uni(insl, i), oi = e >> 8;
-                        nb = nb + W::select(q > oi, W::splat(1u), W::splat(0u));
-                        Mask here = q == oi;
-                        isins = W::select(here, W::splat(1u), isins);
-                        ich = W::select(here, W::splat(e & 0xffu), ich);
-                    }
-                    V32 m = q - nb;
-                    V32 ch = W::load8(tmpb, m, (q < rl) & (m < 320u) & (isins == 0u));
-                    ch = W::select(isins != 0u, ich, ch);
-                    W::store8(dst, q, ch, q < rl);
-                }
+            /* insertions: output index = matched coordinate + number of earlier insertions */
+            p = 0;
+            for (uint32_t i = 0; i < nIns && D.status == CBC_ST_OK; i++) {
+                uint32_t g = D.var_dec((p << 1) | strand);
+                p += g;
+                uint32_t base = D.small_dec(CBC_LT_CHARS + 5u * 8u, 5u, 8u);
+                W::write_uni(insl, i, ((p + i) << 8) | cbc_basechar(base));
             }
+            if (D.status != CBC_ST_OK) return false;
+            for (uint32_t b = 0; b < rl; b += 64u) {
+                V32 q = ln + b;
+                V32 nb = W::splat(0u), isins = W::splat(0u), ich = W::splat(0u);
+                for (uint32_t i = 0; i < nIns; i++) {
+                    uint32_t e = W::read_uni(insl, i), oi = e >> 8;
+                    nb = nb + W::select(q > oi, W::splat(1u), W::splat(0u));
+                    Mask here = q == oi;
+                    isins = W::select(here, W::splat(1u), isins);
+                    ich = W::select(here, W::splat(e & 0xffu), ich);
+                }
+                V32 m = q - nb;
+                V32 ch = W::load8(tmpb, m, (q < rl) & (m < 320u) & (isins == 0u));
+                ch = W::select(isins != 0u, ich, ch);
+                W::store8(dst, q, ch, q < rl);
+            }
+            }
+        
             return true;
     }
 };

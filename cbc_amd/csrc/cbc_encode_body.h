@@ -37,6 +37,7 @@
 #include "../../include/cbc_gpu.h"
 #include "cbc_plan.h"
 
+#define CBC_REC_PACK_AT 56u    /* CbcEnc::step packs once this many steps are recorded (see room()) */
 #define CBC_AWORD     26u
 #define CBC_M26       ((1u << 26) - 1u)
 #define CBC_M25       ((1u << 25) - 1u)
@@ -337,9 +338,23 @@ struct CbcEnc {
         W::set_lane_uv(rec_a, rec_n, rec);
         W::set_lane_uv(rec_s, rec_n, k3);
         nsym++;
-        if (++rec_n == 64u) { pack(rec_a, rec_s, 64u); rec_n = 0; }
+        if (++rec_n >= CBC_REC_PACK_AT) { pack(rec_a, rec_s, rec_n); rec_n = 0; }    /* leaves room for a record's 8 fixed symbols */
     }
     CBC_MFN void flush_recs() { if (rec_n) { pack(rec_a, rec_s, rec_n); rec_n = 0; } }
+    /* The per-record fixed symbols go through step_fixed(): the same step without the "lanes full -> pack" test, so that
+     * pack() is instantiated at a handful of sites and not at every fixed symbol -- the kernel's code shares an
+     * instruction cache with the other wavefronts of two CUs.  Invariant: step() packs once CBC_REC_PACK_AT = 56 steps
+     * are recorded, room(8) at the top of a record packs unless more than 8 lanes are free, so the at most 8 step_fixed()
+     * calls of a record (with or without drained symbols in between) always find a lane. */
+    CBC_MFN void room(uint32_t k) { if (rec_n + k >= 64u) flush_recs(); }      /* a later step() must still find lane <= 63 free */
+    CBC_MFN void step_fixed(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi)
+    {
+        Uv rec, k3;
+        code1(lo, hi, n, flo, fhi, rec, k3);
+        W::set_lane_uv(rec_a, rec_n, rec);
+        W::set_lane_uv(rec_s, rec_n, k3);
+        nsym++; rec_n++;
+    }
     /* the symbols queued by this wavefront itself (fused form; in the coder wave: its own few queued ones).
      * The two divisions of a step, floor(range * c / n) for c = cum and c = cum + count, need no divide on
      * the serial path: f = floor(c * 2^32 / n) is computed for all queued symbols at once (one lane
@@ -1397,7 +1412,8 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             if ((F.bad >> j) & 1ull) { E.fail(W::readlane(F.st, j)); break; }
             /* -- compress_rname (id_compression.c:39-65): same_ref is (1,1) until record 0 codes symbol 1,
              *    after which only symbol 0 is coded; the name itself is the model wave's segment -- */
-            if (r != 0u) E.step(0u, W::readlane(sr_hi, j), 10u * r + 2u, 0u, W::readlane(sr_fh, j));
+            E.room(8u);                                       /* same_ref, rlength x 4, pos, flag, match */
+            if (r != 0u) E.step_fixed(0u, W::readlane(sr_hi, j), 10u * r + 2u, 0u, W::readlane(sr_fh, j));
             else {
                 E.encode(1u, 1u, 2u); E.drain_q();
                 if (fused) { gen_rname(); E.seg_end(); } else E.seg_consume();
@@ -1407,21 +1423,21 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
              *    pass; contexts 1..3 only ever code symbol 0, each once per record -- */
             {
                 const uint32_t tn = 255u + 10u * r, th = W::readlane(t_hi, j), tf = W::readlane(t_fh, j);
-                E.step(W::readlane(F.rl_lo, j), W::readlane(rl_hi, j), tn, W::readlane(rl_fl, j), W::readlane(rl_fh, j));
-                E.step(0u, th, tn, 0u, tf);
-                E.step(0u, th, tn, 0u, tf);
-                E.step(0u, th, tn, 0u, tf);
+                E.step_fixed(W::readlane(F.rl_lo, j), W::readlane(rl_hi, j), tn, W::readlane(rl_fl, j), W::readlane(rl_fh, j));
+                E.step_fixed(0u, th, tn, 0u, tf);
+                E.step_fixed(0u, th, tn, 0u, tf);
+                E.step_fixed(0u, th, tn, 0u, tf);
             }
             /* -- compress_pos: hit, or escape + the four bytes of the new delta -- */
-            E.step(W::readlane(F.p_lo, j), W::readlane(p_hi, j), W::readlane(p_n, j), W::readlane(p_fl, j), W::readlane(p_fh, j));
+            E.step_fixed(W::readlane(F.p_lo, j), W::readlane(p_hi, j), W::readlane(p_n, j), W::readlane(p_fl, j), W::readlane(p_fh, j));
             if ((F.esc >> j) & 1ull) {
                 const uint32_t card = W::readlane(F.p_card, j);
                 E.pos_alpha(W::read_uni(E.pos_val, card), card);
                 E.drain_q();
             }
             /* -- compress_flag (read_compression.c:50-70), then the match flag -- */
-            E.step(W::readlane(F.fl_lo, j), W::readlane(fl_hi, j), 65536u + 8u * r, W::readlane(fl_fl, j), W::readlane(fl_fh, j));
-            E.step(W::readlane(F.m_lo, j), W::readlane(m_hi, j), W::readlane(F.m_n, j), W::readlane(m_fl, j), W::readlane(m_fh, j));
+            E.step_fixed(W::readlane(F.fl_lo, j), W::readlane(fl_hi, j), 65536u + 8u * r, W::readlane(fl_fl, j), W::readlane(fl_fh, j));
+            E.step_fixed(W::readlane(F.m_lo, j), W::readlane(m_hi, j), W::readlane(F.m_n, j), W::readlane(m_fl, j), W::readlane(m_fh, j));
             if ((neq >> j) & 1ull) {
                 if (fused) {
                     const uint32_t so = W::readlane(r_seq, j), to = W::readlane(r_tok, j), flw = W::readlane(r_fl, j);

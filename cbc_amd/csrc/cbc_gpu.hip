@@ -1133,7 +1133,7 @@ API int cbc_gpu_tokenise_sam(cbc_gpu_ctx *ctx, const char *sam, uint64_t len, ui
                            out->d_tok, (cbc_tok_summary *)d_sum);
         GO(hipGetLastError(), "launch cbc_tok_emit_kernel");
         hipLaunchKernelGGL(cbc_tok_seq_kernel, dim3((unsigned)((n_recs + 15) / 16)), dim3(64), 0, ctx->stream, (const uint8_t *)d_sam,
-                           (const uint64_t *)d_ls, (const cbc_tok_summary *)d_sum, n_recs, (const uint64_t *)d_seqof, out->d_seq);
+                           (const cbc_tok_perline *)d_pl, (const cbc_tok_summary *)d_sum, n_recs, (const uint64_t *)d_seqof, out->d_seq);
         GO(hipGetLastError(), "launch cbc_tok_seq_kernel");
         hipLaunchKernelGGL(cbc_tok_names_kernel, dim3((unsigned)((n_recs + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)d_sam,
                            (const cbc_tok_perline *)d_pl, (const cbc_tok_summary *)d_sum, n_recs, (uint8_t *)d_chg);

@@ -46,9 +46,10 @@ cbc_tok_lines_kernel(const uint8_t *__restrict__ sam, uint64_t len, const uint64
     }
 }
 
-struct cbc_tok_perline {            /* what pass 1 leaves per line */
+struct cbc_tok_perline {            /* what pass 1 leaves per line: the column split is done once */
     uint64_t rname; uint32_t rname_len; uint32_t status;
     uint32_t rl, nt;                /* of a mapped, well-formed record; 0 otherwise */
+    cbc_tok_line L;                 /* offsets of the columns the later passes read (CIGAR, SEQ, MD) */
 };
 
 __global__ void __launch_bounds__(256)
@@ -66,6 +67,7 @@ cbc_tok_parse_kernel(const uint8_t *__restrict__ sam, const uint64_t *__restrict
     cbc_tok_perline o;
     o.rname = status == CBC_TOK_OK ? L.rname : 0; o.rname_len = status == CBC_TOK_OK ? L.rname_len : 0; o.status = status;
     o.rl = status == CBC_TOK_OK ? L.seq_len : 0; o.nt = status == CBC_TOK_OK ? nt : 0;
+    if (b >= body_off) o.L = L; else memset(&o.L, 0, sizeof o.L);
     pl[k] = o;
     is_rec[k] = status == CBC_TOK_OK ? 1u : 0u; v_rl[k] = o.rl; v_nt[k] = o.nt;
 }
@@ -77,8 +79,7 @@ cbc_tok_emit_kernel(const uint8_t *__restrict__ sam, const uint64_t *__restrict_
 {
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n_lines || pl[k].status != CBC_TOK_OK) return;
-    cbc_tok_line L;
-    cbc_tok_split(sam, line_start[k], line_start[k + 1], &L);
+    const cbc_tok_line L = pl[k].L;
     uint32_t nt = 0, ev = 0;
     (void)cbc_tok_record(sam, &L, tok + tok_of[k], &nt, &ev);
     cbc_tok_summary s;
@@ -88,17 +89,15 @@ cbc_tok_emit_kernel(const uint8_t *__restrict__ sam, const uint64_t *__restrict_
 
 /* SEQ bytes of record r to seq[seq_of[line]]: one wavefront per 16 records, 64 bytes per step */
 __global__ void __launch_bounds__(64)
-cbc_tok_seq_kernel(const uint8_t *__restrict__ sam, const uint64_t *__restrict__ line_start, const cbc_tok_summary *__restrict__ sum,
+cbc_tok_seq_kernel(const uint8_t *__restrict__ sam, const cbc_tok_perline *__restrict__ pl, const cbc_tok_summary *__restrict__ sum,
                    uint64_t n_recs, const uint64_t *__restrict__ seq_of, uint8_t *__restrict__ seq)
 {
     for (uint32_t q = 0; q < 16; q++) {
         const uint64_t r = (uint64_t)blockIdx.x * 16 + q;
         if (r >= n_recs) return;
         const uint32_t line = sum[r].line, rl = sum[r].rl;
-        cbc_tok_line L;
-        cbc_tok_split(sam, line_start[line], line_start[line + 1], &L);          /* uniform over the wavefront */
-        const uint64_t dst = seq_of[line];
-        for (uint32_t i = threadIdx.x; i < rl; i += 64) seq[dst + i] = sam[L.seq + i];
+        const uint64_t src = pl[line].L.seq, dst = seq_of[line];
+        for (uint32_t i = threadIdx.x; i < rl; i += 64) seq[dst + i] = sam[src + i];
     }
 }
 
