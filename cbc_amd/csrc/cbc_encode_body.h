@@ -347,10 +347,11 @@ struct CbcEnc {
      * are recorded, room(8) at the top of a record packs unless more than 8 lanes are free, so the at most 8 step_fixed()
      * calls of a record (with or without drained symbols in between) always find a lane. */
     CBC_MFN void room(uint32_t k) { if (rec_n + k >= 64u) flush_recs(); }      /* a later step() must still find lane <= 63 free */
-    CBC_MFN void step_fixed(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi)
+    template <class FLO, class FHI, class FN>
+    CBC_MFN void step_fixed(FLO lo_of, FHI hi_of, FN n_of, uint32_t flo, uint32_t fhi)
     {
         Uv rec, k3;
-        code1(lo, hi, n, flo, fhi, rec, k3);
+        code1_lazy(flo, fhi, lo_of, hi_of, n_of, rec, k3);
         W::set_lane_uv(rec_a, rec_n, rec);
         W::set_lane_uv(rec_s, rec_n, k3);
         nsym++; rec_n++;
@@ -437,8 +438,16 @@ struct CbcEnc {
      * scalar unit is what the kernel queues on. */
     CBC_MFN void code1(uint32_t lo, uint32_t hi, uint32_t n, uint32_t flo, uint32_t fhi, Uv &rec, Uv &k3)
     {
+        code1_lazy(flo, fhi, [&]() { return lo; }, [&]() { return hi; }, [&]() { return n; }, rec, k3);
+    }
+    /* the same step with cum / cum + count / total fetched only where they are needed: the remainder test that one step
+     * in 64 takes (and the emulation's cross-check).  The fixed symbols keep their operands in lanes of vector registers
+     * (one lane per record), so every operand costs a v_readlane: two per step on the usual path instead of five. */
+    template <class FLO, class FHI, class FN>
+    CBC_MFN void code1_lazy(uint32_t flo, uint32_t fhi, FLO lo_of, FHI hi_of, FN n_of, Uv &rec, Uv &k3)
+    {
 #ifdef CBC_ABLATE_CODER          /* timing experiments only: keeps the operands live, skips the coder */
-        l ^= lo; rng ^= hi + n; rec = W::uv(0u); k3 = rec; return;
+        l ^= flo; rng ^= fhi; rec = W::uv(0u); k3 = rec; return;
 #endif
         const Uv range = rng;
         /* floor(range * c / n) for c = lo and c = hi, given f = floor(c * 2^32 / n) (clamped to 2^32 - 1
@@ -450,12 +459,13 @@ struct CbcEnc {
         Uv ql, qh, tl, th;
         W::mul64(range, flo, ql, tl); W::mul64(range, fhi, qh, th);
         if (W::uv_scalar(tl | th) >= 0xfc000000u) {
+            const uint32_t lo = lo_of(), hi = hi_of(), n = n_of();
             ql += (range * lo - ql * n >= n) ? 1u : 0u;
             qh += (range * hi - qh * n >= n) ? 1u : 0u;
         }
 #ifndef __HIP_DEVICE_COMPILE__     /* emulation: every quotient against integer division */
-        W::expect_eq(W::uv_scalar(ql), (uint32_t)((uint64_t)W::uv_scalar(range) * lo / n), "scaled_div(cum)");
-        W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi / n), "scaled_div(cum + count)");
+        W::expect_eq(W::uv_scalar(ql), (uint32_t)((uint64_t)W::uv_scalar(range) * lo_of() / n_of()), "scaled_div(cum)");
+        W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi_of() / n_of()), "scaled_div(cum + count)");
 #endif
         const Uv u = l + qh - 1u;                                /* the state is (l, range): every E1/E2/E3 shift doubles the range */
         l = l + ql;
@@ -1413,7 +1423,8 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             /* -- compress_rname (id_compression.c:39-65): same_ref is (1,1) until record 0 codes symbol 1,
              *    after which only symbol 0 is coded; the name itself is the model wave's segment -- */
             E.room(8u);                                       /* same_ref, rlength x 4, pos, flag, match */
-            if (r != 0u) E.step_fixed(0u, W::readlane(sr_hi, j), 10u * r + 2u, 0u, W::readlane(sr_fh, j));
+#define CBC_LZ(expr) [&]() -> uint32_t { return (expr); }
+            if (r != 0u) E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(sr_hi, j)), CBC_LZ(10u * r + 2u), 0u, W::readlane(sr_fh, j));
             else {
                 E.encode(1u, 1u, 2u); E.drain_q();
                 if (fused) { gen_rname(); E.seg_end(); } else E.seg_consume();
@@ -1422,22 +1433,23 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1): rlength[0] from the group
              *    pass; contexts 1..3 only ever code symbol 0, each once per record -- */
             {
-                const uint32_t tn = 255u + 10u * r, th = W::readlane(t_hi, j), tf = W::readlane(t_fh, j);
-                E.step_fixed(W::readlane(F.rl_lo, j), W::readlane(rl_hi, j), tn, W::readlane(rl_fl, j), W::readlane(rl_fh, j));
-                E.step_fixed(0u, th, tn, 0u, tf);
-                E.step_fixed(0u, th, tn, 0u, tf);
-                E.step_fixed(0u, th, tn, 0u, tf);
+                const uint32_t tn = 255u + 10u * r, tf = W::readlane(t_fh, j);
+                E.step_fixed(CBC_LZ(W::readlane(F.rl_lo, j)), CBC_LZ(W::readlane(rl_hi, j)), CBC_LZ(tn), W::readlane(rl_fl, j), W::readlane(rl_fh, j));
+                E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), 0u, tf);
+                E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), 0u, tf);
+                E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), 0u, tf);
             }
             /* -- compress_pos: hit, or escape + the four bytes of the new delta -- */
-            E.step_fixed(W::readlane(F.p_lo, j), W::readlane(p_hi, j), W::readlane(p_n, j), W::readlane(p_fl, j), W::readlane(p_fh, j));
+            E.step_fixed(CBC_LZ(W::readlane(F.p_lo, j)), CBC_LZ(W::readlane(p_hi, j)), CBC_LZ(W::readlane(p_n, j)), W::readlane(p_fl, j), W::readlane(p_fh, j));
             if ((F.esc >> j) & 1ull) {
                 const uint32_t card = W::readlane(F.p_card, j);
                 E.pos_alpha(W::read_uni(E.pos_val, card), card);
                 E.drain_q();
             }
             /* -- compress_flag (read_compression.c:50-70), then the match flag -- */
-            E.step_fixed(W::readlane(F.fl_lo, j), W::readlane(fl_hi, j), 65536u + 8u * r, W::readlane(fl_fl, j), W::readlane(fl_fh, j));
-            E.step_fixed(W::readlane(F.m_lo, j), W::readlane(m_hi, j), W::readlane(F.m_n, j), W::readlane(m_fl, j), W::readlane(m_fh, j));
+            E.step_fixed(CBC_LZ(W::readlane(F.fl_lo, j)), CBC_LZ(W::readlane(fl_hi, j)), CBC_LZ(65536u + 8u * r), W::readlane(fl_fl, j), W::readlane(fl_fh, j));
+            E.step_fixed(CBC_LZ(W::readlane(F.m_lo, j)), CBC_LZ(W::readlane(m_hi, j)), CBC_LZ(W::readlane(F.m_n, j)), W::readlane(m_fl, j), W::readlane(m_fh, j));
+#undef CBC_LZ
             if ((neq >> j) & 1ull) {
                 if (fused) {
                     const uint32_t so = W::readlane(r_seq, j), to = W::readlane(r_tok, j), flw = W::readlane(r_fl, j);
