@@ -158,6 +158,13 @@ struct CbcDec {
         W::expect_eq(q, (uint32_t)((uint64_t)range * cnt0 / n), "step_known0 quotient");
         if (q == 0u || t - l >= q) { fail(CBC_ST_ASSERT); return; }        /* another symbol was coded here */
         u = l + q - 1u;
+        /* mostly nothing shifts after a symbol this probable: l < 2^25 between steps, so E1/E2 need u < 2^25 and E3
+         * needs l >= 2^24 and u < 3 * 2^24 -- neither when q exceeds the bound below (cf. CbcEnc::step_known0) */
+        if (q > (((l & (1u << 24)) | (1u << 25)) - l)) {
+            W::expect_eq(((l ^ u) >> 25) & 1u, 1u, "step_known0: E1/E2 would shift");
+            W::expect_eq((l >> 24) & (~u >> 24) & 1u, 0u, "step_known0: E3 would shift");
+            return;
+        }
         renorm();
     }
     /* arithmetic_decoder_step, Arithmetic_stream.c:389-454, loops in closed form (cf. CbcEnc::code1) */

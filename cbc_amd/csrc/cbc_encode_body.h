@@ -140,6 +140,13 @@ struct CbcEnc {
     /* ---- range coder + bit writer (Arithmetic_stream.c:155-194, 274-371) ---- */
     typedef typename W::Uv Uv;               /* a wave-uniform value kept in a VECTOR register (see cbc_wave_gpu.h) */
     Uv l, rng;                               /* lower bound, range = u - l + 1 (vector registers)   */
+    Uv lm1;                                  /* l - 1, formed at the end of a step (beside the next step's multiplies) */
+    Uv thr0;                                 /* step_known0(): the new range above which nothing shifts (a function of l) */
+    CBC_MFN void set_l_forms()
+    {
+        lm1 = W::uv_opaque(l - 1u);
+        thr0 = ((l & (1u << 24)) | (1u << 25)) - l;
+    }
     uint32_t scale3;                         /* E3 count pending after the steps packed so far      */
     uint32_t bitpos, flushed;               /* bits produced; words already stored (multiple of 64)  */
     uint32_t *ring;                         /* CBC_RING_WORDS of LDS, zero except for the pending bits */
@@ -458,7 +465,7 @@ struct CbcEnc {
          * multiply per division on the usual path instead of three quarter-rate ones. */
         Uv ql, qh, tl, th;
         W::mul64(range, flo, ql, tl); W::mul64(range, fhi, qh, th);
-        if (W::uv_scalar(tl | th) >= 0xfc000000u) {
+        if (W::uv_ge(tl | th, 0xfc000000u)) {
             const uint32_t lo = lo_of(), hi = hi_of(), n = n_of();
             ql += (range * lo - ql * n >= n) ? 1u : 0u;
             qh += (range * hi - qh * n >= n) ? 1u : 0u;
@@ -467,30 +474,76 @@ struct CbcEnc {
         W::expect_eq(W::uv_scalar(ql), (uint32_t)((uint64_t)W::uv_scalar(range) * lo_of() / n_of()), "scaled_div(cum)");
         W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(range) * hi_of() / n_of()), "scaled_div(cum + count)");
 #endif
-        const Uv u = l + qh - 1u;                                /* the state is (l, range): every E1/E2/E3 shift doubles the range */
+        code_tail(ql, qh, rec, k3);
+    }
+    /* the step once its two quotients are known */
+    CBC_MFN void code_tail(Uv ql, Uv qh, Uv &rec, Uv &k3)
+    {
+        const Uv u = lm1 + qh;                                   /* the state is (l, range): every E1/E2/E3 shift doubles the range */
         l = l + ql;
-        /* Branch-free, in 32-bit arithmetic, and with the two shifts merged.  E1/E2 shift k1 = number of
-         * common leading bits (of 26); E3 then shifts out the run, below the new MSB, where l has 1 and u
-         * has 0.  After E1/E2 the low k1 bits of l are 0 and of u are 1, so that run can be read from the
-         * unshifted values, y = (l & ~u) << (k1 + 7) (the 32-bit shift drops exactly the bits the masks
-         * would; for k1 >= 25, l & ~u is 0 and the shift count does not matter), k1 + k3 <= 26, and
+        /* Branch-free, in 32-bit arithmetic, and with the two shifts merged.  E1/E2 shift k1 = number of common
+         * leading bits (of 26); E3 then shifts out the run, below the new MSB, where l has 1 and u has 0.  After E1/E2
+         * the low k1 bits of l are 0 and of u are 1, so that run can be read from the unshifted values:
+         * y = ((l & ~u) << 7) << k1 (32-bit shifts drop exactly the bits the masks would), k3 = its leading ones,
+         * k1 + k3 <= 26, and
          *     l' = (l << (k1 + k3)) & M25,   u' = ((u << (k1 + k3)) & M25) | 2^25 | (2^(k1 + k3) - 1)
          * equal the two updates of Arithmetic_stream.c:296-341 applied one after the other (k1 = 0 or
          * k3 = 0 make the respective part the identity: bit 25 of l is then 0 and of u is 1).  Each of
          * those shifts maps [l, u] with slope 2 (u' - l' + 1 = 2 (u - l + 1)), so instead of u' the
          * state keeps range' = (qh - ql) << (k1 + k3), which is also what the next step starts from.
-         * The pending-E3 bookkeeping is not done here: pack() derives it from the recorded k3 of all steps. */
+         * The pending-E3 bookkeeping is not done here: pack() derives it from the recorded k3 of all steps.
+         * What does not need k1 is formed beside the k1 chain (the wavefront issues in order and a dependent
+         * instruction waits ~8 cycles for its operand): l - 1 at the end of the previous step, and the complement of
+         * (l & ~u) << 7 -- its low 7 bits are set, so shifted by k1 <= 26 it stays non-zero and its leading zeros
+         * are y's leading ones.  (Shifting l and the range in two stages, by k1 and then by k3, shortens the chain by
+         * one more instruction but adds one, and measures slower: profiles/r02_ab_kernels.log run 7.) */
         const Uv x = l ^ u;
+        const Uv nya = ((~l | u) << 7) | 127u;
         const Uv k1 = W::clz_uv((x << 6) | 32u);                 /* leading zeros of the 26-bit x; 26 when x = 0 */
         rec = l | (k1 << 26);                                    /* pack() takes the k1 leading bits of l from here */
-        const Uv y = (l & ~u) << ((k1 + 7u) & 31u);
-        k3 = W::clz_uv(~y);                                      /* ~y != 0: its low 7 bits are set */
+        k3 = W::clz_uv(nya << k1);
         const Uv sh = k1 + k3;
         l = (l << sh) & CBC_M25;
         rng = (qh - ql) << sh;
+        set_l_forms();
 #ifndef __HIP_DEVICE_COMPILE__     /* emulation: the explicit upper bound against the range form */
         W::expect_eq(W::uv_scalar(l + rng - 1u), W::uv_scalar(((u << sh) & CBC_M25) | (1u << 25) | ((1u << sh) - 1u)), "range form of the upper bound");
 #endif
+    }
+    /* A fixed symbol that is symbol 0 of its model (same_ref after record 0, rlength[1..3]): cum = 0, so the lower bound
+     * stays and range' = floor(range * count0 / n).  These counts lie within 254 of their totals, the range shrinks by a
+     * fraction of a percent and mostly nothing shifts: with l < 2^25 (true between steps: bit 25 of l is clear after any
+     * step), E1/E2 need u' < 2^25 and E3 needs l >= 2^24 and u' < 3 * 2^24, so neither applies when
+     *     range' > thr0 = (2^25 | (l & 2^24)) - l.
+     * Such a step records nothing (pack() would find k1 = k3 = 0) and costs one multiply and two tests instead of the
+     * whole recurrence; any other goes through the usual tail. */
+    template <class FHI, class FN>
+    CBC_MFN void step_known0(FHI hi_of, FN n_of, uint32_t fhi)
+    {
+        Uv qh, th;
+        W::mul64(rng, fhi, qh, th);
+        if (W::uv_ge(th, 0xfc000000u)) {
+            const uint32_t hi = hi_of(), n = n_of();
+            qh += (rng * hi - qh * n >= n) ? 1u : 0u;
+        }
+#ifndef __HIP_DEVICE_COMPILE__
+        W::expect_eq(W::uv_scalar(qh), (uint32_t)((uint64_t)W::uv_scalar(rng) * hi_of() / n_of()), "scaled_div(count0)");
+#endif
+        nsym++;
+        if (W::uv_gt(qh, thr0)) {
+#ifndef __HIP_DEVICE_COMPILE__     /* emulation: the recurrence agrees that nothing shifts */
+            const uint32_t lf = W::uv_scalar(l), uf = lf + W::uv_scalar(qh) - 1u;
+            W::expect_eq(((lf ^ uf) >> 25) & 1u, 1u, "step_known0: E1/E2 would shift");
+            W::expect_eq((lf >> 24) & (~uf >> 24) & 1u, 0u, "step_known0: E3 would shift");
+#endif
+            rng = qh;
+            return;
+        }
+        Uv rec, k3;
+        code_tail(W::uv(0u), qh, rec, k3);
+        W::set_lane_uv(rec_a, rec_n, rec);
+        W::set_lane_uv(rec_s, rec_n, k3);
+        rec_n++;
     }
     CBC_MFN uint32_t finish()                        /* encoder_last_step :348-363 + stream_finish_byte */
     {
@@ -1186,7 +1239,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const uint32_t L0 = bd->read_length, n_tok_blk = bd->n_tok;
 
     E.status = CBC_ST_OK; E.nsym = 0; E.fail_read = 0; E.cur_read = 0;
-    E.l = W::uv(0u); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
+    E.l = W::uv(0u); E.set_l_forms(); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
     E.ring = lds + CBC_LDS_RING;
     E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
     E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);
@@ -1424,7 +1477,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
              *    after which only symbol 0 is coded; the name itself is the model wave's segment -- */
             E.room(8u);                                       /* same_ref, rlength x 4, pos, flag, match */
 #define CBC_LZ(expr) [&]() -> uint32_t { return (expr); }
-            if (r != 0u) E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(sr_hi, j)), CBC_LZ(10u * r + 2u), 0u, W::readlane(sr_fh, j));
+            if (r != 0u) E.step_known0(CBC_LZ(W::readlane(sr_hi, j)), CBC_LZ(10u * r + 2u), W::readlane(sr_fh, j));
             else {
                 E.encode(1u, 1u, 2u); E.drain_q();
                 if (fused) { gen_rname(); E.seg_end(); } else E.seg_consume();
@@ -1435,9 +1488,9 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             {
                 const uint32_t tn = 255u + 10u * r, tf = W::readlane(t_fh, j);
                 E.step_fixed(CBC_LZ(W::readlane(F.rl_lo, j)), CBC_LZ(W::readlane(rl_hi, j)), CBC_LZ(tn), W::readlane(rl_fl, j), W::readlane(rl_fh, j));
-                E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), 0u, tf);
-                E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), 0u, tf);
-                E.step_fixed(CBC_LZ(0u), CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), 0u, tf);
+                E.step_known0(CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), tf);
+                E.step_known0(CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), tf);
+                E.step_known0(CBC_LZ(W::readlane(t_hi, j)), CBC_LZ(tn), tf);
             }
             /* -- compress_pos: hit, or escape + the four bytes of the new delta -- */
             E.step_fixed(CBC_LZ(W::readlane(F.p_lo, j)), CBC_LZ(W::readlane(p_hi, j)), CBC_LZ(W::readlane(p_n, j)), W::readlane(p_fl, j), W::readlane(p_fh, j));

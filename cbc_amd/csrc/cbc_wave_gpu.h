@@ -105,7 +105,11 @@ struct WaveGPU {
      * arithmetic back to the scalar unit. */
     typedef uint32_t Uv;
     static CBC_FN Uv uv(uint32_t x) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+    static CBC_FN Uv uv_opaque(Uv x) { asm volatile("" : "+v"(x)); return x; }     /* keeps the compiler from re-associating across it */
     static CBC_FN uint32_t uv_scalar(Uv x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    /* x >= c for a uniform x without the trip through a scalar register: v_cmp -> vcc -> branch */
+    static CBC_FN bool uv_gt(Uv x, Uv y) { return __builtin_amdgcn_uicmp(x, y, 34) != 0ull; }               /* 34 = ICMP_UGT */
+    static CBC_FN bool uv_ge(Uv x, uint32_t c) { return __builtin_amdgcn_uicmp(x, c, 35) != 0ull; }      /* 35 = ICMP_UGE */
     static CBC_FN void mul64(Uv a, uint32_t b, Uv &hi, Uv &lo) { uint64_t p = (uint64_t)a * b; hi = (uint32_t)(p >> 32); lo = (uint32_t)p; }
     static CBC_FN Uv clz_uv(Uv x) { return (uint32_t)__builtin_clz(x); }                  /* x != 0 */
     static CBC_FN void set_lane_uv(V32 &v, uint32_t k, Uv val) { v = lane() == k ? val : v; }

@@ -92,6 +92,9 @@ struct WaveEmu {
     typedef uint32_t Uv;
     static Uv uv(uint32_t x) { return x; }
     static uint32_t uv_scalar(Uv x) { return x; }
+    static Uv uv_opaque(Uv x) { return x; }
+    static bool uv_ge(Uv x, uint32_t c) { return x >= c; }
+    static bool uv_gt(Uv x, Uv y) { return x > y; }
     static void mul64(Uv a, uint32_t b, Uv &hi, Uv &lo) { uint64_t p = (uint64_t)a * b; hi = (uint32_t)(p >> 32); lo = (uint32_t)p; }
     static Uv clz_uv(Uv x) { return clz32(x); }
     static void set_lane_uv(V32 &v, uint32_t k, Uv val) { set_lane(v, k, val); }

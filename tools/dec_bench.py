@@ -19,12 +19,13 @@ td=lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)
 d_in=td(np.concatenate([flat, np.zeros(16,dtype=np.uint8)])); d_blocks=td(blocks); d_ref=td(pb.ref)
 d_recs=torch.zeros(nrec*16,dtype=torch.uint8,device=dev); d_seq=torch.zeros(nrec*stride+16,dtype=torch.uint8,device=dev); d_res=torch.zeros(pb.n_blocks*16,dtype=torch.uint8,device=dev)
 d_vs=torch.zeros(pb.n_blocks*pb.cap_var, dtype=torch.int32, device=dev)
-db=gpu.DecDeviceBatch(d_in.data_ptr(), d_in.numel(), d_blocks.data_ptr(), pb.n_blocks, d_ref.data_ptr(), d_ref.numel(), d_recs.data_ptr(), nrec, d_seq.data_ptr(), d_seq.numel(), d_res.data_ptr(), d_vs.data_ptr(), d_vs.numel(), host.LdsCaps(pb.cap_pos,pb.cap_var))
+NB=int(os.environ.get('DEC_NBLK', pb.n_blocks))     # decode only the first NB blocks of the same data (contention curve)
+db=gpu.DecDeviceBatch(d_in.data_ptr(), d_in.numel(), d_blocks.data_ptr(), NB, d_ref.data_ptr(), d_ref.numel(), d_recs.data_ptr(), nrec, d_seq.data_ptr(), d_seq.numel(), d_res.data_ptr(), d_vs.data_ptr(), d_vs.numel(), host.LdsCaps(pb.cap_pos,pb.cap_var))
 st=ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ms=[]
 for i in range(4):
     enc.decode_device(db, st); torch.cuda.synchronize(); ms.append(enc.last_kernel_ms())
-r=d_res.cpu().numpy().view(host.RESULT_DTYPE); assert (r['status']==0).all()
+r=d_res.cpu().numpy().view(host.RESULT_DTYPE); assert (r['status'][:NB]==0).all()
 allseq=d_seq.cpu().numpy()
 if os.environ.get('DEC_STAMP'):
     sums=np.zeros(16)
@@ -34,6 +35,7 @@ if os.environ.get('DEC_STAMP'):
     for n_,v in zip(names,sums): print('%-16s %8.0f cycles/read %5.1f%%'%(n_, v/nrec, 100*v/sums.sum()))
     print('total', sums.sum()/nrec)
 else:
-    got=allseq[:nrec*stride].reshape(nrec,stride)[:,:150]; assert (got==pb.seq[:nrec*150].reshape(nrec,150)).all()
+    nr=int(blocks[NB-1]['rec_base'])+int(blocks[NB-1]['n_reads'])
+    got=allseq[:nr*stride].reshape(nr,stride)[:,:150]; assert (got==pb.seq[:nr*150].reshape(nr,150)).all()
 caps=host.LdsCaps(pb.cap_pos,pb.cap_var)
-print('decode kernel ms', ms, 'Mbases/s', pb.n_bases/ (min(ms)*1e-3)/1e6, 'lds', L.cbc_gpu_decode_lds_bytes(ctypes.byref(caps)))
+print('blocks', NB, 'decode kernel ms', ms, 'Mbases/s', pb.n_bases/ (min(ms)*1e-3)/1e6, 'lds', L.cbc_gpu_decode_lds_bytes(ctypes.byref(caps)))
