@@ -180,6 +180,32 @@ struct CbcDec {
         renorm();
     }
 
+    /* ---- search by scaled bounds ------------------------------------------------------------------------------
+     * The decoder's symbol is the s with cum(s) <= target < cum(s + 1), target = floor(((t - l + 1) n - 1) / range)
+     * (Arithmetic_stream.c:373-381).  For an integer C:  target < C  <=>  (t - l + 1) n <= C range  <=>
+     * t - l < floor(range C / n).  So with a model's cumulative counts laid out one per lane, the symbol is the lane
+     * whose scaled bounds floor(range cum / n) enclose t - l -- and those two quotients are what the coder step needs
+     * next (:389-400): no target division, no search over counts, no second pair of divisions, and the 64 divisions
+     * are one vector instruction stream (W::muldiv_v) with no trip through scalar registers.  The models below fall
+     * back to target() + search when the tag lies outside the lanes they hold. */
+    CBC_MFN bool tag_ok(uint32_t n)                       /* the checks of target() */
+    {
+        if (n == 0u || t - l > u - l) { fail(CBC_ST_ASSERT); return false; }
+        return true;
+    }
+    CBC_MFN void step_q(uint32_t ql, uint32_t qh) { nsym++; u = l + qh - 1u; l = l + ql; renorm(); }
+    /* cum_incl: inclusive cumulative count per lane, non-decreasing over the live lanes [first, first + m), 0 elsewhere */
+    CBC_MFN bool prefix_find(V32 cum_incl, Mask live, uint32_t first, uint32_t n, uint32_t &idx, uint32_t &ql, uint32_t &qh)
+    {
+        const V32 qv = W::muldiv_v(u - l + 1u, cum_incl, n);
+        const uint64_t hb = W::ballot(live & (W::splat(t - l) < qv));
+        if (!hb) return false;
+        const uint32_t hl = W::ctz64(hb);
+        qh = W::readlane(qv, hl); ql = hl != first ? W::readlane(qv, hl - 1u) : 0u;
+        idx = hl - first;
+        return true;
+    }
+
     /* ---- lane-table literal models (match, same_ref, chars) ---- */
     /* a two-symbol literal-count model (match, same_ref): no target division and no search.  The tag lies in
      * symbol 0's interval exactly when t - l < floor(range * count0 / n)  (the same test the target of
@@ -208,22 +234,16 @@ struct CbcDec {
     CBC_MFN uint32_t small_dec(uint32_t base, uint32_t card, uint32_t stp)
     {
         if (card == 2u) return bin_dec(base, stp);
-        uint32_t n = 0;
-        for (uint32_t j = 0; j < card; j++) n += W::readlane(small, base + j);
-        uint32_t tg = target(n), lo = 0, cnt = 0, x = 0, found = 0;
-        for (uint32_t j = 0; j < card; j++) {
-            uint32_t c = W::readlane(small, base + j);
-            if (!found && tg < lo + c) { found = 1; x = j; cnt = c; }
-            if (!found) lo += c;
-        }
-        if (!found) { fail(CBC_ST_ASSERT); return 0u; }
-        step(lo, cnt, n);
         V32 ln = W::lane();
+        const Mask live = (ln >= base) & (ln < base + card);
+        const V32 inc = W::scan_incl_add(W::select(live, small, W::splat(0u)));
+        const uint32_t n = W::readlane(inc, base + card - 1u);
+        uint32_t x, ql, qh;
+        if (!tag_ok(n)) return 0u;
+        if (!prefix_find(inc, live, base, n, x, ql, qh)) { fail(CBC_ST_ASSERT); return 0u; }
+        step_q(ql, qh);
         small = W::select(ln == base + x, small + stp, small);
-        if (n + stp >= CBC_RESCALE) {
-            Mask m = (ln >= base) & (ln < base + card);
-            small = W::select(m, (small >> 1) + 1u, small);
-        }
+        if (n + stp >= CBC_RESCALE) small = W::select(live, (small >> 1) + 1u, small);
         return x;
     }
 
@@ -255,10 +275,29 @@ struct CbcDec {
     {
         V32 ln = W::lane();
         Mask live = (ln >= base) & (ln < base + count);
-        uint32_t tg = target(n), lo, cnt, hl; bool hit;
-        uint32_t x = pairs_search(key, exc, live, base, count, tg, lo, cnt, hl, hit);
-        if (x >= card) { fail(CBC_ST_ASSERT); return 0u; }
-        step(lo, cnt, n);
+        if (!tag_ok(n)) return 0u;
+        /* A = cum(key) = key + the excess of all smaller keys; a seen key owns [A, A + 1 + excess) */
+        V32 A = key;
+        for (uint32_t j = 0; j < count; j++) {
+            uint32_t kj = W::readlane(key, base + j), ej = W::readlane(exc, base + j);
+            A = A + W::select(key > kj, W::splat(ej), W::splat(0u));
+        }
+        const uint32_t range = u - l + 1u, d = t - l;
+        const V32 qlv = W::muldiv_v(range, W::select(live, A, W::splat(0u)), n);
+        const V32 qhv = W::muldiv_v(range, W::select(live, A + 1u + exc, W::splat(0u)), n);
+        const uint64_t hb = W::ballot(live & (qlv <= d) & (W::splat(d) < qhv));
+        uint32_t x, hl = 0; const bool hit = hb != 0ull;
+        if (hit) {
+            hl = W::ctz64(hb); x = W::readlane(key, hl);
+            if (x >= card) { fail(CBC_ST_ASSERT); return 0u; }
+            step_q(W::readlane(qlv, hl), W::readlane(qhv, hl));
+        } else {                                             /* an unseen symbol: count 1 at cum = target */
+            const uint32_t tg = target(n);
+            const uint32_t S = W::reduce_add(W::select(live & (A < tg), exc, W::splat(0u)));   /* A + e < tg here */
+            x = tg - S;
+            if (x >= card) { fail(CBC_ST_ASSERT); return 0u; }
+            step(tg, 1u, n);
+        }
         if (hit) exc = W::select(ln == hl, exc + stp, exc);
         else {
             if (count >= cap) { fail(cap_status); return 0u; }
@@ -351,6 +390,23 @@ struct CbcDec {
         if (rlen_n >= CBC_RESCALE) { W::write_uni(exc, x, cnt - 1u + 10u); dense_rescale(exc, 255u, rlen_n); }
         else { rl_memo_x = x; rl_memo_lo = lo; rl_memo_cnt = cnt + 10u; }
         rl_last_x = x;
+        return x;
+    }
+    /* the same for a table whose symbols are small in practice (the SNP / indel counts of a read): symbols 0..63 one
+     * per lane and the search by scaled bounds; any other symbol through dense_dec() */
+    CBC_MFN uint32_t dense_dec_low(uint32_t *exc, uint32_t card, uint32_t stp, uint32_t &n)
+    {
+        if (!tag_ok(n)) return 0u;
+        V32 ln = W::lane();
+        const Mask live = ln < card;
+        const V32 e = W::load32(exc, ln, live, 0u);
+        const V32 cum = W::select(live, W::scan_incl_add(e) + ln + 1u, W::splat(0u));
+        uint32_t x, ql, qh;
+        if (!prefix_find(cum, live, 0u, n, x, ql, qh)) return dense_dec(exc, card, stp, n);
+        step_q(ql, qh);
+        W::write_uni(exc, x, W::readlane(e, x) + stp);
+        n += stp;
+        if (n >= CBC_RESCALE) dense_rescale(exc, card, n);
         return x;
     }
     CBC_MFN uint32_t dense_dec(uint32_t *exc, uint32_t card, uint32_t stp, uint32_t &n)
@@ -450,14 +506,15 @@ struct CbcDec {
     CBC_MFN uint32_t pos_dec()                           /* returns x = delta + 1 */
     {
         V32 ln = W::lane();
-        uint32_t tg = target(pos_n);
+        if (!tag_ok(pos_n)) return 0u;
         Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
         V32 c = W::select(m0, pcnt, W::splat(0u));
         V32 inc = W::scan_incl_add(c);
-        uint64_t hb = W::ballot(m0 & ((inc - c) <= tg) & (tg < inc));
-        uint32_t idx = 0, lo = 0, cnt = 0, found = 0;
-        if (hb) { idx = W::ctz64(hb); lo = W::readlane(inc, idx) - W::readlane(c, idx); cnt = W::readlane(c, idx); found = 1; }
+        uint32_t idx = 0, ql, qh;
+        if (prefix_find(inc, m0, 0u, pos_n, idx, ql, qh)) step_q(ql, qh);       /* the first 64 entries: lanes */
         else {
+            const uint32_t tg = target(pos_n);
+            uint32_t lo = 0, cnt = 0, found = 0;
             uint32_t base_sum = W::readlane(inc, 63u);
             const uint32_t pc = W::uni(pos_card);
             for (uint32_t b = 64u; b < pc && !found; b += 64u) {
@@ -468,9 +525,9 @@ struct CbcDec {
                 if (h2) { uint32_t hl = W::ctz64(h2); idx = b + hl; lo = W::readlane(ic, hl) - W::readlane(cc, hl); cnt = W::readlane(cc, hl); found = 1; }
                 base_sum = W::readlane(ic, 63u);
             }
+            if (!found) { fail(CBC_ST_ASSERT); return 0u; }
+            step(lo, cnt, pos_n);
         }
-        if (!found) { fail(CBC_ST_ASSERT); return 0u; }
-        step(lo, cnt, pos_n);
         pos_update(idx);
         if (idx != 0u) return idx < 64u ? W::readlane(pval, idx) : W::read_uni(pos_val_p(), idx);
         uint32_t b3 = pos_alpha_dec(0u), b2 = pos_alpha_dec(1u), b1 = pos_alpha_dec(2u), b0 = pos_alpha_dec(3u);
@@ -664,11 +721,11 @@ struct CbcDec {
             CbcDec &D = *this;
             const V32 ln = W::lane();
             const V32 bo = ln * 4u;
-            uint32_t nSnp = D.dense_dec(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
+            uint32_t nSnp = D.dense_dec_low(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
             if (D.status == CBC_ST_OK && nSnp == 0u) {
-                nSnp = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-                nDel = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-                nIns = D.dense_dec(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nSnp = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nDel = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+                nIns = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
             }
             if (D.status != CBC_ST_OK) return false;
             if (nIns > rl) { D.fail(CBC_ST_ASSERT); return false; }

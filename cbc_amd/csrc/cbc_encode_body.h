@@ -227,6 +227,9 @@ struct CbcEnc {
      * the previous batch when no step of this batch has emitted yet. */
     CBC_MFN void pack(const V32 &rec_a, const V32 &rec_k3, uint32_t m)
     {
+#ifdef CBC_ABLATE_PACK            /* timing experiments only (tools/README.md): the stream is wrong */
+        bitpos += m; return;
+#endif
         const V32 ln = W::lane();
         const Mask in = ln < m;
         const V32 k1 = rec_a >> 26, bits = (rec_a & CBC_M26) >> ((W::splat(26u) - k1) & 31u);   /* k1 = 0: l >> 26 = 0 */
@@ -359,8 +362,12 @@ struct CbcEnc {
     {
         Uv rec, k3;
         code1_lazy(flo, fhi, lo_of, hi_of, n_of, rec, k3);
+#ifdef CBC_ABLATE_SETLANE         /* timing experiments only */
+        rec_a ^= rec; rec_s ^= k3;
+#else
         W::set_lane_uv(rec_a, rec_n, rec);
         W::set_lane_uv(rec_s, rec_n, k3);
+#endif
         nsym++; rec_n++;
     }
     /* the symbols queued by this wavefront itself (fused form; in the coder wave: its own few queued ones).
@@ -520,6 +527,9 @@ struct CbcEnc {
     template <class FHI, class FN>
     CBC_MFN void step_known0(FHI hi_of, FN n_of, uint32_t fhi)
     {
+#ifdef CBC_ABLATE_CODER
+        rng ^= fhi; nsym++; return;
+#endif
         Uv qh, th;
         W::mul64(rng, fhi, qh, th);
         if (W::uv_ge(th, 0xfc000000u)) {
@@ -596,6 +606,13 @@ struct CbcEnc {
     CBC_MFN void dense_lookup(const uint32_t *exc, uint32_t x, uint32_t &lo, uint32_t &cnt)
     {
         V32 ln = W::lane();
+        if (x < 64u) {                                       /* one load holds everything; the usual symbols (0..3: edit counts) need no wave sum */
+            const V32 e = W::load32(exc, ln, ln <= x, 0u);
+            cnt = 1u + W::readlane(e, x);
+            if (x < 4u) { lo = x; for (uint32_t s = 0; s < x; s++) lo += W::readlane(e, s); }
+            else lo = x + W::reduce_add(W::select(ln < x, e, W::splat(0u)));
+            return;
+        }
         V32 a = W::splat(0u);
         const uint32_t xb = W::uni(x);                       /* opaque loop bound: see CBC_LOOP note */
         for (uint32_t b = 0; b < xb; b += 64u) { V32 i = ln + b; a = a + W::load32(exc, i, i < x, 0u); }
@@ -615,19 +632,15 @@ struct CbcEnc {
         }
         n = card + W::reduce_add(a);
     }
-    CBC_MFN void dense_update(uint32_t *exc, uint32_t card, uint32_t step, uint32_t x, uint32_t &n)
-    {
-        W::write_uni(exc, x, W::read_uni(exc, x) + step);
-        n += step;
-        if (n >= CBC_RESCALE) dense_rescale(exc, card, n);
-    }
     CBC_MFN void dense_code(uint32_t *exc, uint32_t card, uint32_t step, uint32_t x, uint32_t &n)
     {
         if (x >= card) { fail(CBC_ST_ASSERT); return; }       /* assert(x < alphabetCard) stream_model.c:62 */
         uint32_t lo, cnt;
         dense_lookup(exc, x, lo, cnt);
         encode(lo, cnt, n);
-        dense_update(exc, card, step, x, n);
+        W::write_uni(exc, x, cnt - 1u + step);                /* update_model with the count already at hand */
+        n += step;
+        if (n >= CBC_RESCALE) dense_rescale(exc, card, n);
     }
 
     /* ---- lane-table literal-count models (match, same_ref, chars); step/rescale literal ---- */
@@ -1438,6 +1451,9 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
 
     /* ========================== coder wavefront / fused emulation =========================== */
     const bool fused = ROLE == CBC_ROLE_FUSED;
+    /* the coder wavefront carries the block's serial chain: it goes first at the SIMD's issue port (s_setprio), the
+     * model wavefronts that share the SIMD fill the gaps (cfg2 10.26 -> 9.91 ms, profiles/r02_ab_kernels.log run 9) */
+    if (!fused) W::prio(3);
     if (E.status == CBC_ST_OK) { if (fused) { gen_header(); E.seg_end(); } else E.seg_consume(); }
     for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
         V32 r_pos, r_fl, r_seq, r_tok;

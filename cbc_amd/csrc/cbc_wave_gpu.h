@@ -125,6 +125,7 @@ struct WaveGPU {
         if (lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     static CBC_FN void nap() { __builtin_amdgcn_s_sleep(2); }
+    static CBC_FN void prio(int p) { if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
     /* emulation-only cross-check hook */
     static CBC_FN void expect_eq(uint32_t, uint32_t, const char *) {}
 
@@ -203,6 +204,19 @@ struct WaveGPU {
         uint32_t q = q0 + (uint32_t)q1 - (uint32_t)(r1 < 0) + (uint32_t)(r1 >= (int32_t)n);
         qh = (uint32_t)__builtin_amdgcn_readlane((int)q, 0);
         ql = (uint32_t)__builtin_amdgcn_readlane((int)q, 1);
+    }
+    /* the same division in every lane: floor(range * c / n) for a count per lane, c <= n < 2^21, range <= 2^26
+     * (CbcDec::scaled(): the decoder searches by scaled bounds, the quotients stay in vector registers) */
+    static CBC_FN V32 muldiv_v(uint32_t range, V32 c, uint32_t n)
+    {
+        const float inv = __builtin_amdgcn_rcpf((float)n);
+        uint32_t plo = range * c, phi = __umulhi(range, c);
+        float pf = (float)((phi << 16) | (plo >> 16)) * 65536.0f;
+        uint32_t q0 = (uint32_t)(pf * inv);
+        int32_t r0 = (int32_t)(plo - q0 * n);
+        int32_t q1 = (int32_t)__builtin_floorf((float)r0 * inv);
+        int32_t r1 = r0 - q1 * (int32_t)n;
+        return q0 + (uint32_t)q1 - (uint32_t)(r1 < 0) + (uint32_t)(r1 >= (int32_t)n);
     }
     /* floor(p / d) for p < 2^47, 2^24 < d <= 2^26 and a quotient < 2^21 (the decoder's target,
      * Arithmetic_stream.c:373-381), exact: same two-estimate scheme as muldiv2 with the divisor d.

@@ -89,6 +89,7 @@ struct WaveEmu {
     static uint32_t ctl_load(const uint32_t *) { emu_oob("hand-off counter read in the fused emulation"); return 0; }
     static void ctl_store(uint32_t *, uint32_t) { emu_oob("hand-off counter write in the fused emulation"); }
     static void nap() {}
+    static void prio(int) {}
     typedef uint32_t Uv;
     static Uv uv(uint32_t x) { return x; }
     static uint32_t uv_scalar(Uv x) { return x; }
@@ -170,6 +171,15 @@ struct WaveEmu {
             static unsigned tick = 0;
             if (n.v[i]) bits += (uint32_t)((int)(tick++ % 5u) - 2);          /* -2..+2 ulp */
             r.v[i] = bits;
+        }
+        return r;
+    }
+    static V32 muldiv_v(uint32_t range, const V32 &c, uint32_t n)
+    {
+        V32 r; const V32 iv = recip_v(splat(n));
+        for (int i = 0; i < 64; i++) {
+            if (c.v[i] > n || n >= (1u << 21) || range > (1u << 26)) emu_oob("muldiv_v operand range");
+            float f; memcpy(&f, &iv.v[i], 4); r.v[i] = muldiv1(range, c.v[i], n, f);
         }
         return r;
     }
