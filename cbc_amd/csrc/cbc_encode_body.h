@@ -95,7 +95,7 @@ struct cbc_enc_args {
 #define CBC_TS(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); E.t_sum[k] += t_ - E.t_last; E.t_last = t_; } while (0)
 #define CBC_TSM(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); t_sum[k] += t_ - t_last; t_last = t_; } while (0)
 #elif defined(CBC_MARKS) && defined(__HIP_DEVICE_COMPILE__)   /* diagnostic: section markers in the ISA listing */
-#define CBC_TSM(k) do {} while (0)
+#define CBC_TSM(k) asm volatile("; ==== CBC_MARK M" #k)
 #define CBC_T0() asm volatile("; ==== CBC_MARK start")
 #define CBC_TS(k) asm volatile("; ==== CBC_MARK " #k)
 #else
@@ -1139,6 +1139,7 @@ struct CbcEnc {
             if (tok_off + 2u + n_cig + n_md > n_tok_blk || nSnp >= 1024u || nDel >= 1024u || nIns >= 1024u) {
                 E.fail(CBC_ST_ASSERT); return;
             }
+            CBC_TSM(11);                                      /* window slide, token header (waits for the prefetched loads) */
 #define CBC_TOK(i) ((i) < 64u ? W::readlane(tokv, (i)) : W::read_uni(tokb + tok_off, (i)))
 #define CBC_READ_BYTE(i) ((i) < rl ? ((W::readlane(seqv, (i) >> 2) >> (((i) & 3u) * 8u)) & 0xffu) : 0u)
 #define CBC_SNP(gap_, letter_, cum_, p_) do {                                                              \
@@ -1156,6 +1157,7 @@ struct CbcEnc {
                 /* SNP-only read (:557-558, :573-593): no insertion can interleave, so the MD tokens are
                  * the SNP list in order -- one loop, no CIGAR walk */
                 E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
+                CBC_TSM(12);                                  /* edit counts */
                 uint32_t cum = 0, p = 0;
                 for (uint32_t k = 0; k < n_md && E.status == CBC_ST_OK; k++) {
                     if (E.q_len >= 56u) E.drain();
@@ -1173,6 +1175,7 @@ struct CbcEnc {
                 E.dense_code(E.indels_exc, L0, 16u, nSnp & 0xffu, E.indels_n);
                 E.dense_code(E.indels_exc, L0, 16u, nDel & 0xffu, E.indels_n);
                 E.dense_code(E.indels_exc, L0, 16u, nIns & 0xffu, E.indels_n);
+                CBC_TSM(12);
                 /* three walks over the CIGAR, in the emission order of :568-600: deletions, SNPs
                  * (interleaved with the insertions through add_snps_to_array's early return), insertions */
                 for (int pass = 1; pass < 4 && E.status == CBC_ST_OK; pass++) {
@@ -1225,6 +1228,7 @@ struct CbcEnc {
                     }
                 }
             }
+            CBC_TSM(13);                                      /* rest of edits(): loop ends, the indel walks */
 #undef CBC_SNP
 #undef CBC_TOK
 #undef CBC_READ_BYTE

@@ -2,17 +2,19 @@
 # usage: tools/profile_round.sh <tag>   -> gpurun_out/<tag>_{bench.json,bench_under_rocprof.json,kernel_stats.csv,pmc_hbm.json,...}
 set -e
 tag=$1
+leg=${2:-all}          # encode | decode | all  (one gpurun call holds 1200 s: run the two legs in separate calls)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+if [ "$leg" != decode ]; then
 python3 $R/bench.py > $O/${tag}_bench.log 2>&1; tail -1 $O/${tag}_bench.log > $O/${tag}_bench.json
 rm -rf $O/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -o p -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${tag}_rp.log 2>&1
 tail -1 $O/${tag}_rp.log > $O/${tag}_bench_under_rocprof.json
 cp $(find $O/prof_$tag -name '*kernel_stats.csv' | head -1) $O/${tag}_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU"; do
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   d=$O/pmc_${tag}_$(echo $c | tr ' ' '_' | cut -c1-20)
   rm -rf $d
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $d.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $d.log 2>&1 || echo "counter pass '$c' failed (see $d.log)"
 done
 python3 - "$tag" <<'PY'
 import csv, glob, sys, os, json, collections
@@ -38,6 +40,8 @@ json.dump(res, open(O + "/%s_pmc_hbm.json" % tag, "w"), indent=1)
 print(json.dumps(res, indent=1)[:1500])
 PY
 cat $O/${tag}_bench.json | cut -c1-400; head -3 $O/${tag}_kernel_stats.csv
+fi
+[ "$leg" = encode ] && exit 0
 # decode leg
 cd /tmp
 python3 $R/bench.py --mode decode --no-cpu-baseline > $O/${tag}_bench_decode.log 2>&1; tail -1 $O/${tag}_bench_decode.log > $O/${tag}_bench_decode.json

@@ -20,7 +20,7 @@ sums=np.zeros(16)
 for b in range(pb.n_blocks):
     o=int(blocks[b]['out_off'])+int(blocks[b]['out_cap'])-128; sums+=out[o:o+128].view(np.uint64).astype(np.float64)
     o=int(blocks[b]['out_off']); sums+=out[o:o+128].view(np.uint64).astype(np.float64)
-names=['M: grp loads+match','M: edits (per imperfect rec incl. below)','-','M: snp pre','M: win_first','M: until publish','M: at barrier','M: var_code','M: win_set+chars','C: coding','C: waiting','-','-','-','-','-']
+names=['M: grp loads+match','M: seg_end','-','M: to the first win_first of a record / between SNPs','M: win_first','M: until publish','M: at barrier','M: var_code','M: win_set+chars','C: coding','C: waiting','M: publish, next-record prefetch, window slide, token header','M: edit counts','M: rest of edits()','-','-']
 tot=sums.sum()
 for n,v in zip(names,sums): print('%-12s %8.0f cycles/read  %5.1f%%'%(n, v/pb.n_recs, 100*v/tot))
 print('total stamped cycles/read', tot/pb.n_recs)
