@@ -112,6 +112,13 @@ def issue_picture(root, tag_glob, kernel_ms, n_recs):
     (the number that binds here; the HBM fraction does not).  Counter values are per launch, summed over the chip."""
     import glob
     cands = sorted(glob.glob(os.path.join(root, "profiles", tag_glob)))
+    try:                                                     # profiles/CURRENT.json names the passes of the committed kernels
+        cur = json.load(open(os.path.join(root, "profiles", "CURRENT.json")))
+        named = os.path.join(root, "profiles", cur["decode_pmc" if "decode" in tag_glob else "encode_pmc"])
+        if os.path.exists(named):
+            cands = [named]
+    except Exception:
+        pass
     if not cands:
         return None, None, None
     try:
@@ -138,6 +145,12 @@ def issue_picture(root, tag_glob, kernel_ms, n_recs):
             issue["inst_per_cycle_per_simd"] = round((salu + valu) / (kcyc * n_cu * simd_per_cu), 3)
             if sq.get("SQ_WAVE_CYCLES"):
                 issue["mean_waves_per_simd"] = round(sq["SQ_WAVE_CYCLES"] * 4 / (kcyc * n_cu * simd_per_cu), 2)
+                # where a resident wavefront's cycles go (MI355X_MICROARCH.md, SQ counters): parked on s_waitcnt / s_sleep,
+                # ready but not issued, issuing
+                for key, name in (("SQ_WAIT_ANY", "wave_parked_frac"), ("SQ_WAIT_INST_ANY", "wave_issue_stall_frac"),
+                                  ("SQ_ACTIVE_INST_ANY", "wave_issuing_frac")):
+                    if sq.get(key):
+                        issue[name] = round(sq[key] / sq["SQ_WAVE_CYCLES"], 3)
     return pm.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], root), issue
 
 

@@ -68,7 +68,7 @@ struct CbcDec {
     typedef typename W::Mask Mask;
 
     /* ---- range decoder + bit reader ---- */
-    uint32_t l, u, t;
+    uint32_t l, rng, d;                       /* lower bound, range = u - l + 1, tag - l */
     uint64_t acc; uint32_t navail;
     V32 wordv; uint32_t widx, nwords_in, tail_valid; const uint8_t *inb;
     uint32_t status, nsym, fail_read, cur_read;
@@ -116,31 +116,27 @@ struct CbcDec {
     /* arithmetic_get_symbol_range, Arithmetic_stream.c:373-381 */
     CBC_MFN uint32_t target(uint32_t n)
     {
-        uint32_t range = u - l + 1u, gap = t - l + 1u;
-        if (n == 0u || gap == 0u || gap > range) { fail(CBC_ST_ASSERT); return 0u; }
-        uint64_t p = (uint64_t)gap * n - 1u;
-        return W::divq(p, range);
+        if (n == 0u || d >= rng) { fail(CBC_ST_ASSERT); return 0u; }       /* gap = t - l + 1: 0 or beyond the range */
+        uint64_t p = ((uint64_t)d + 1u) * n - 1u;
+        return W::divq(p, rng);
     }
-    /* the E1/E2 and E3 shifts of arithmetic_decoder_step (Arithmetic_stream.c:401-454) in closed form.
-     * (The merged single shift of CbcEnc::code1 was tried here and is slower on the scalar unit: the two
-     * branches below skip more work than the merge saves.) */
+    /* the E1/E2 and E3 shifts of arithmetic_decoder_step (Arithmetic_stream.c:401-454) in closed form and merged into one
+     * shift, as in CbcEnc::code_tail.  The state is (l, range, d = tag - l) instead of the reference's (l, u, t): each of
+     * the three scalings maps the interval with slope 2 and appends the next stream bit to the tag (E1: x -> 2x, E2:
+     * x -> 2(x - 2^25), E3: x -> 2(x - 2^24), for l, u and t alike), so range' = range << sh and d' = d << sh | the next
+     * sh bits -- one bit-reader call per step, and the models below read d and range as they are. */
     CBC_MFN void renorm()
     {
-        uint32_t x = l ^ u;
-        uint32_t k1 = x ? (W::clz32(x) - 6u) : 26u;
-        if (k1) {
-            uint32_t bits = take(k1);
-            l = (uint32_t)(((uint64_t)l << k1) & CBC_M26);
-            u = (uint32_t)((((uint64_t)u << k1) & CBC_M26) | ((1ull << k1) - 1ull));
-            t = (uint32_t)((((uint64_t)t << k1) & CBC_M26) | bits);
-        }
-        uint32_t y = ((l & ~u) & CBC_M25) << 7;
-        uint32_t k3 = W::clz32(~y);
-        if (k3) {
-            uint32_t bits = take(k3);
-            l = (l << k3) & CBC_M25;
-            u = ((u << k3) & CBC_M25) | (1u << 25) | ((1u << k3) - 1u);
-            t = (uint32_t)(((((uint64_t)t << k3) & CBC_M26) ^ (1u << 25)) | bits);
+        const uint32_t uu = l + rng - 1u;
+        const uint32_t x = l ^ uu;
+        const uint32_t k1 = W::clz32((x << 6) | 32u);               /* leading zeros of the 26-bit x; 26 when x = 0 */
+        const uint32_t k3 = W::clz32((((~l | uu) << 7) | 127u) << k1);   /* leading ones of ((l & ~u) << 7) << k1 */
+        const uint32_t sh = k1 + k3;
+        if (sh) {
+            const uint32_t bits = take(sh);
+            l = (l << sh) & CBC_M25;
+            rng = rng << sh;
+            d = (d << sh) | bits;
         }
     }
     /* A symbol that can only be symbol 0 of its model (same_ref after record 0, rlength[1..3]; their
@@ -151,18 +147,17 @@ struct CbcDec {
     CBC_MFN void step_known0(uint32_t cnt0, uint32_t n, uint32_t f)
     {
         nsym++;
-        const uint32_t range = u - l + 1u;
-        const uint64_t p = (uint64_t)range * f;
+        const uint64_t p = (uint64_t)rng * f;
         uint32_t q = (uint32_t)(p >> 32);
-        if ((uint32_t)p >= 0xfc000000u) q += (range * cnt0 - q * n >= n) ? 1u : 0u;
-        W::expect_eq(q, (uint32_t)((uint64_t)range * cnt0 / n), "step_known0 quotient");
-        if (q == 0u || t - l >= q) { fail(CBC_ST_ASSERT); return; }        /* another symbol was coded here */
-        u = l + q - 1u;
+        if ((uint32_t)p >= 0xfc000000u) q += (rng * cnt0 - q * n >= n) ? 1u : 0u;
+        W::expect_eq(q, (uint32_t)((uint64_t)rng * cnt0 / n), "step_known0 quotient");
+        if (q == 0u || d >= q) { fail(CBC_ST_ASSERT); return; }            /* another symbol was coded here */
+        rng = q;
         /* mostly nothing shifts after a symbol this probable: l < 2^25 between steps, so E1/E2 need u < 2^25 and E3
          * needs l >= 2^24 and u < 3 * 2^24 -- neither when q exceeds the bound below (cf. CbcEnc::step_known0) */
         if (q > (((l & (1u << 24)) | (1u << 25)) - l)) {
-            W::expect_eq(((l ^ u) >> 25) & 1u, 1u, "step_known0: E1/E2 would shift");
-            W::expect_eq((l >> 24) & (~u >> 24) & 1u, 0u, "step_known0: E3 would shift");
+            W::expect_eq(((l ^ (l + q - 1u)) >> 25) & 1u, 1u, "step_known0: E1/E2 would shift");
+            W::expect_eq((l >> 24) & (~(l + q - 1u) >> 24) & 1u, 0u, "step_known0: E3 would shift");
             return;
         }
         renorm();
@@ -172,12 +167,10 @@ struct CbcDec {
     {
         if (cnt == 0u || n == 0u || lo + cnt > n) { fail(CBC_ST_ASSERT); return; }
         nsym++;
-        uint32_t range = u - l + 1u, qh, ql;
+        uint32_t qh, ql;
         float inv = W::lane_float(W::recip_v(W::splat(n)), 0u);
-        W::muldiv2(range, lo, lo + cnt, n, inv, ql, qh);
-        u = l + qh - 1u;
-        l = l + ql;
-        renorm();
+        W::muldiv2(rng, lo, lo + cnt, n, inv, ql, qh);
+        step_q0(ql, qh);
     }
 
     /* ---- search by scaled bounds ------------------------------------------------------------------------------
@@ -190,15 +183,16 @@ struct CbcDec {
      * back to target() + search when the tag lies outside the lanes they hold. */
     CBC_MFN bool tag_ok(uint32_t n)                       /* the checks of target() */
     {
-        if (n == 0u || t - l > u - l) { fail(CBC_ST_ASSERT); return false; }
+        if (n == 0u || d >= rng) { fail(CBC_ST_ASSERT); return false; }
         return true;
     }
-    CBC_MFN void step_q(uint32_t ql, uint32_t qh) { nsym++; u = l + qh - 1u; l = l + ql; renorm(); }
+    CBC_MFN void step_q0(uint32_t ql, uint32_t qh) { l += ql; d -= ql; rng = qh - ql; renorm(); }
+    CBC_MFN void step_q(uint32_t ql, uint32_t qh) { nsym++; step_q0(ql, qh); }
     /* cum_incl: inclusive cumulative count per lane, non-decreasing over the live lanes [first, first + m), 0 elsewhere */
     CBC_MFN bool prefix_find(V32 cum_incl, Mask live, uint32_t first, uint32_t n, uint32_t &idx, uint32_t &ql, uint32_t &qh)
     {
-        const V32 qv = W::muldiv_v(u - l + 1u, cum_incl, n);
-        const uint64_t hb = W::ballot(live & (W::splat(t - l) < qv));
+        const V32 qv = W::muldiv_v(rng, cum_incl, n);
+        const uint64_t hb = W::ballot(live & (W::splat(d) < qv));
         if (!hb) return false;
         const uint32_t hl = W::ctz64(hb);
         qh = W::readlane(qv, hl); ql = hl != first ? W::readlane(qv, hl - 1u) : 0u;
@@ -216,12 +210,11 @@ struct CbcDec {
         const uint32_t c0 = W::readlane(small, base), c1 = W::readlane(small, base + 1u), n = c0 + c1;
         if (c0 == 0u || c1 == 0u) { fail(CBC_ST_ASSERT); return 0u; }
         nsym++;
-        const uint32_t range = u - l + 1u;
         uint32_t q0, qn;
         float inv = W::lane_float(W::recip_v(W::splat(n)), 0u);
-        W::muldiv2(range, c0, n, n, inv, q0, qn);
-        const uint32_t x = (t - l >= q0) ? 1u : 0u;
-        if (x == 0u) u = l + q0 - 1u; else l = l + q0;
+        W::muldiv2(rng, c0, n, n, inv, q0, qn);
+        const uint32_t x = (d >= q0) ? 1u : 0u;
+        if (x == 0u) rng = q0; else { l += q0; d -= q0; rng -= q0; }      /* symbol 1 keeps the old upper bound */
         renorm();
         V32 ln = W::lane();
         small = W::select(ln == base + x, small + stp, small);
@@ -282,7 +275,7 @@ struct CbcDec {
             uint32_t kj = W::readlane(key, base + j), ej = W::readlane(exc, base + j);
             A = A + W::select(key > kj, W::splat(ej), W::splat(0u));
         }
-        const uint32_t range = u - l + 1u, d = t - l;
+        const uint32_t range = rng;
         const V32 qlv = W::muldiv_v(range, W::select(live, A, W::splat(0u)), n);
         const V32 qhv = W::muldiv_v(range, W::select(live, A + 1u + exc, W::splat(0u)), n);
         const uint64_t hb = W::ballot(live & (qlv <= d) & (W::splat(d) < qhv));
@@ -363,14 +356,11 @@ struct CbcDec {
     {
         uint32_t *exc = tab(CBC_LDS_RLEN);
         if (rl_memo_x != CBC_NOMEMO) {
-            const uint32_t range = u - l + 1u;
             uint32_t ql, qh;
             float inv = W::lane_float(W::recip_v(W::splat(rlen_n)), 0u);
-            W::muldiv2(range, rl_memo_lo, rl_memo_lo + rl_memo_cnt, rlen_n, inv, ql, qh);
-            if (t - l >= ql && t - l < qh) {
-                nsym++;
-                u = l + qh - 1u; l = l + ql;
-                renorm();
+            W::muldiv2(rng, rl_memo_lo, rl_memo_lo + rl_memo_cnt, rlen_n, inv, ql, qh);
+            if (d >= ql && d < qh) {
+                step_q(ql, qh);
                 rl_memo_cnt += 10u; rlen_n += 10u;
                 if (rlen_n >= CBC_RESCALE) {                   /* through the table: unreachable below CBC_MAX_BLOCK_READS */
                     W::write_uni(exc, rl_memo_x, rl_memo_cnt - 1u);
@@ -831,7 +821,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     const uint32_t in_bytes = bd->in_bytes, n_reads = bd->n_reads, L0 = bd->read_length, stride = bd->seq_stride;
 
     D.status = CBC_ST_OK; D.nsym = 0; D.fail_read = 0; D.cur_read = 0;
-    D.l = 0; D.u = CBC_M26; D.t = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
+    D.l = 0; D.rng = CBC_M26 + 1u; D.d = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
     D.inb = A.in + in_off;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = A.cap_var; D.L0 = L0;
     D.evp = A.var_scratch + (uint64_t)blk * A.cap_var;
@@ -871,7 +861,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     D.p0cnt = W::splat(0u); D.p0over = 0;
 
     /* the tag: first 26 bits (alloc_arithmetic_stream, Arithmetic_stream.c:260-263) */
-    if (D.status == CBC_ST_OK) D.t = D.take(26u);
+    if (D.status == CBC_ST_OK) D.d = D.take(26u);
 
     /* stream header: int(L0), 32 x int(WELL), int(8) */
     for (uint32_t k = 0; k < 34u && D.status == CBC_ST_OK; k++) {

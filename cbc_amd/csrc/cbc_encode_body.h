@@ -37,6 +37,10 @@
 #include "../../include/cbc_gpu.h"
 #include "cbc_plan.h"
 
+#ifndef CBC_PRIO_CODER
+#define CBC_PRIO_CODER 3                  /* s_setprio of the two wavefronts of a block (A/B: profiles/r02_ab_kernels.log) */
+#define CBC_PRIO_MODEL 0
+#endif
 #define CBC_REC_PACK_AT 56u    /* CbcEnc::step packs once this many steps are recorded (see room()) */
 #define CBC_AWORD     26u
 #define CBC_M26       ((1u << 26) - 1u)
@@ -1405,6 +1409,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
 
     /* ================================ model wavefront ======================================== */
     if (ROLE == CBC_ROLE_MODEL) {
+        if (CBC_PRIO_MODEL) W::prio(CBC_PRIO_MODEL);
         if (E.status == CBC_ST_OK) { gen_header(); E.seg_end(); }
         for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
             V32 r_pos, r_fl, r_seq, r_tok;
@@ -1457,7 +1462,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     const bool fused = ROLE == CBC_ROLE_FUSED;
     /* the coder wavefront carries the block's serial chain: it goes first at the SIMD's issue port (s_setprio), the
      * model wavefronts that share the SIMD fill the gaps (cfg2 10.26 -> 9.91 ms, profiles/r02_ab_kernels.log run 9) */
-    if (!fused) W::prio(3);
+    if (!fused) W::prio(CBC_PRIO_CODER);
     if (E.status == CBC_ST_OK) { if (fused) { gen_header(); E.seg_end(); } else E.seg_consume(); }
     for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
         V32 r_pos, r_fl, r_seq, r_tok;

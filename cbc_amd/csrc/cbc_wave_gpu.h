@@ -125,7 +125,7 @@ struct WaveGPU {
         if (lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     static CBC_FN void nap() { __builtin_amdgcn_s_sleep(2); }
-    static CBC_FN void prio(int p) { if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+    static CBC_FN void prio(int p) { if (p == 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
     /* emulation-only cross-check hook */
     static CBC_FN void expect_eq(uint32_t, uint32_t, const char *) {}
 
