@@ -34,6 +34,7 @@
 #define CBC_ENCODE_BODY_H
 
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/cbc_gpu.h"
 #include "cbc_plan.h"
 
@@ -1494,19 +1495,20 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         const V32 m_hi = F.m_lo + F.m_cnt;
         const V32 m_fl = CBC_FRAC(F.m_lo, F.m_n), m_fh = CBC_FRAC(m_hi, F.m_n);
 
-        for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
+        /* one record's symbols.  `first` = record 0 of the block (a compile-time flag: the loop body proper has no
+         * special case in it, and nothing leaves the loop from inside -- every early exit costs the structurised
+         * control flow a flag that is then tested at each join) */
+#define CBC_LZ(expr) [&]() -> uint32_t { return (expr); }
+        auto code_record = [&](uint32_t j, auto first) {
             const uint32_t r = c0 + j;
             E.cur_read = r;
-            if ((F.bad >> j) & 1ull) { E.fail(W::readlane(F.st, j)); break; }
             /* -- compress_rname (id_compression.c:39-65): same_ref is (1,1) until record 0 codes symbol 1,
              *    after which only symbol 0 is coded; the name itself is the model wave's segment -- */
             E.room(8u);                                       /* same_ref, rlength x 4, pos, flag, match */
-#define CBC_LZ(expr) [&]() -> uint32_t { return (expr); }
-            if (r != 0u) E.step_known0(CBC_LZ(W::readlane(sr_hi, j)), CBC_LZ(10u * r + 2u), W::readlane(sr_fh, j));
+            if constexpr (!decltype(first)::value) E.step_known0(CBC_LZ(W::readlane(sr_hi, j)), CBC_LZ(10u * r + 2u), W::readlane(sr_fh, j));
             else {
                 E.encode(1u, 1u, 2u); E.drain_q();
                 if (fused) { gen_rname(); E.seg_end(); } else E.seg_consume();
-                if (E.status != CBC_ST_OK) break;
             }
             /* -- read length, 4 "bytes" (read_compression.c:29-33, quirk Q1): rlength[0] from the group
              *    pass; contexts 1..3 only ever code symbol 0, each once per record -- */
@@ -1527,7 +1529,6 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             /* -- compress_flag (read_compression.c:50-70), then the match flag -- */
             E.step_fixed(CBC_LZ(W::readlane(F.fl_lo, j)), CBC_LZ(W::readlane(fl_hi, j)), CBC_LZ(65536u + 8u * r), W::readlane(fl_fl, j), W::readlane(fl_fh, j));
             E.step_fixed(CBC_LZ(W::readlane(F.m_lo, j)), CBC_LZ(W::readlane(m_hi, j)), CBC_LZ(W::readlane(F.m_n, j)), W::readlane(m_fl, j), W::readlane(m_fh, j));
-#undef CBC_LZ
             if ((neq >> j) & 1ull) {
                 if (fused) {
                     const uint32_t so = W::readlane(r_seq, j), to = W::readlane(r_tok, j), flw = W::readlane(r_fl, j);
@@ -1538,7 +1539,15 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                     E.seg_end();
                 } else E.seg_consume();
             }
-        }
+        };
+#undef CBC_LZ
+        /* records up to the first one fixed_group() refused; that one reports its status after the loop */
+        uint32_t jn = cn;
+        if (F.bad) { const uint32_t fb = W::ctz64(F.bad); if (fb < cn) jn = fb; }
+        uint32_t j = 0;
+        if (c0 == 0u && jn != 0u) { code_record(0u, std::true_type()); j = 1u; }
+        for (; j < jn && E.status == CBC_ST_OK; j++) code_record(j, std::false_type());
+        if (jn < cn && E.status == CBC_ST_OK) { E.cur_read = c0 + jn; E.fail(W::readlane(F.st, jn)); }
     }
     /* ---- end-of-stream sentinel (compression.c:152): same_ref symbol 1 at counts (1 + 10 (n - 1), 11),
      *      then the model wave's two name symbols; flush ---- */
