@@ -22,6 +22,7 @@
 #define CBC_DECODE_BODY_H
 
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/cbc_gpu.h"
 #include "cbc_encode_body.h"      /* constants, lane-table map, cbc_basepair, cbc_le64 */
 
@@ -726,8 +727,7 @@ struct CbcDec {
                 uint32_t p = 0;
                 for (uint32_t sidx = 0; sidx < nSnp && D.status == CBC_ST_OK; sidx++) {
                     uint32_t dl = D.win_first(p, rl);
-                    uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
-                    if (D.status != CBC_ST_OK) return false;
+                    uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));        /* failed: 0, and the loop header ends it */
                     uint32_t at = p + g;
                     p += g + 1u;
                     D.win_set(p - 1u);
@@ -762,7 +762,6 @@ struct CbcDec {
             for (uint32_t s = 0; s < nSnp && D.status == CBC_ST_OK; s++) {
                 uint32_t dl = D.win_first(p, rl);
                 uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));
-                if (D.status != CBC_ST_OK) return false;
                 uint32_t at = p + g;
                 p += g + 1u;
                 D.win_set(p - 1u);
@@ -891,7 +890,9 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     for (int i = 0; i < 16; i++) dt_sum[i] = 0;
     CBC_DT0();
 #endif
-    for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) {
+    /* one record.  `first` = record 0 (a compile-time flag); a failure sets D.status and returns -- the loop's only exit is
+     * its header (every exit from inside a loop costs the structurised control flow a flag tested at each join) */
+    auto dec_record = [&](uint32_t r, auto first) {
         D.cur_read = r;
         if (pend_rl) { W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl); pend_rl = 0; }   /* record r - 1 was perfect */
         if ((r & 63u) == 0u) {                               /* scaled fractions of the closed-form symbols of 64 records */
@@ -901,11 +902,11 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         }
         /* -- decompress_rname (id_compression.c:67-94): same_ref is (1,1) until record 0 takes symbol 1,
          *    after which every record of the block must take symbol 0 (one contig per block) -- */
-        if (r != 0u) D.step_known0(10u * r - 9u, 10u * r + 2u, W::readlane(sr_fh, r & 63u));
+        if constexpr (!decltype(first)::value) D.step_known0(10u * r - 9u, 10u * r + 2u, W::readlane(sr_fh, r & 63u));
         else {
             uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
-            if (D.status != CBC_ST_OK) break;
-            if (sr != 1u) { D.fail(CBC_ST_ASSERT); break; }
+            if (D.status != CBC_ST_OK) return;
+            if (sr != 1u) { D.fail(CBC_ST_ASSERT); return; }
             for (uint32_t q = 0; q < CBC_CAP_NAME && D.status == CBC_ST_OK; q++) {
                 uint32_t ch = D.rname_dec(D.prevChar);
                 if (ch == 0u) break;
@@ -914,32 +915,32 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             }
             D.prevPos = 0; D.win_clear();
         }
-        if (D.status != CBC_ST_OK) break;
+        if (D.status != CBC_ST_OK) return;
 
         CBC_DT(0);                                            /* same_ref (+ name) */
         /* -- read length (read_decompression.c:68-74): only the low byte carries information (Q1) -- */
         uint32_t rl = D.rlen_dec();
         {   /* contexts 1..3 only ever hold symbol 0 (quirk Q1), each coded once per record */
             const uint32_t tf = W::readlane(t_fh, r & 63u);
-            for (int k = 1; k < 4 && D.status == CBC_ST_OK; k++) D.step_known0(10u * r + 1u, 10u * r + 255u, tf);
+            for (int k = 1; k < 4; k++) D.step_known0(10u * r + 1u, 10u * r + 255u, tf);      /* a failed one leaves the state alone */
         }
-        if (D.status != CBC_ST_OK) break;
-        if (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride) { D.fail(CBC_ST_ASSERT); break; }
+        if (D.status != CBC_ST_OK) return;
+        if (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride) { D.fail(CBC_ST_ASSERT); return; }
 
         CBC_DT(1);                                            /* rlength x 4 */
         /* -- pos, flag -- */
         uint32_t x = D.pos_dec();
-        if (D.status != CBC_ST_OK) break;
-        if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); break; }
+        if (D.status != CBC_ST_OK) return;
+        if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); return; }
         uint32_t pos = D.prevPos + x - 1u;
-        if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); break; }     /* the 32-bit sum wrapped: not a position of this window */
-        D.win_shift(r == 0u ? 256u : x - 1u);
+        if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); return; }     /* the 32-bit sum wrapped: not a position of this window */
+        D.win_shift(decltype(first)::value ? 256u : x - 1u);
         D.prevPos = pos;
         CBC_DT(2);                                            /* pos */
         uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
-        if (D.status != CBC_ST_OK) break;
+        if (D.status != CBC_ST_OK) return;
         const uint32_t strand = (flag >> 4) & 1u;
-        if (pos == 0u || pos > ref_lim || ref_lim - pos < rl + 3u + 256u) { D.fail(CBC_ST_ASSERT); break; }
+        if (pos == 0u || pos > ref_lim || ref_lim - pos < rl + 3u + 256u) { D.fail(CBC_ST_ASSERT); return; }
         /* the reference window of the read, 4 bases per lane: issued now, needed after the match flag
          * (perfect read: it IS the read) or after the edits (SNP-only read: patched in place) */
         refw = W::load32_bytes(refb + (pos - 1u), ln * 4u, (ln * 4u) < rl);
@@ -947,21 +948,23 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         CBC_DT(3);                                            /* flag */
         /* -- match -- */
         uint32_t match = D.small_dec(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | D.prevM) * 2u, 2u, 1u);
-        if (D.status != CBC_ST_OK) break;
+        if (D.status != CBC_ST_OK) return;
         D.prevM = match;
         uint8_t *dst = seqo + (uint64_t)r * stride;
         CBC_DT(4);                                            /* match */
         if (match) {
             pend_dst = dst; pend_rl = rl;                          /* stored at the top of the next record; stride >= rl rounded to 4 */
         } else {
-            if (!D.edits_dec(pos, rl, strand, refw, dst, refb, tmpb, lds + CBC_DLDS_TMP, dels, insl)) break;
+            if (!D.edits_dec(pos, rl, strand, refw, dst, refb, tmpb, lds + CBC_DLDS_TMP, dels, insl)) return;
         }
         CBC_DT(5);                                            /* copy / edits + reconstruction */
         /* record */
         V32 rv0 = W::splat(pos), rv1 = W::splat(flag | (rl << 16)), rv2 = W::splat(r * stride), rv3 = W::splat(0u);
         W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
         CBC_DT(6);                                            /* record store */
-    }
+    };
+    if (n_reads && D.status == CBC_ST_OK) dec_record(0u, std::true_type());
+    for (uint32_t r = 1; r < n_reads && D.status == CBC_ST_OK; r++) dec_record(r, std::false_type());
 
     if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl);
 

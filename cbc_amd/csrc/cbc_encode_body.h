@@ -422,18 +422,25 @@ struct CbcEnc {
     /* coder wave: code the model wave's symbols up to the next END */
     CBC_MFN void seg_consume()
     {
-        while (status == CBC_ST_OK) {
+        /* the entries of the current batch up to its END (found by one ballot) are a counted loop with no way out of
+         * its middle; what ends the segment, asks for the next batch or fails is decided between such runs */
+        const V32 ln = W::lane();
+        bool done = false;
+        while (!done && status == CBC_ST_OK) {
             if (b_pos == b_len) {
-                if (seen_last) { fail(CBC_ST_ASSERT); return; }                /* stream ended inside a segment */
-                pull();
-                if (b_flags & CBC_BF_GROUP) fail(CBC_ST_ASSERT);               /* protocol: group mark inside a segment */
-                continue;
+                if (seen_last) fail(CBC_ST_ASSERT);                            /* stream ended inside a segment */
+                else { pull(); if (b_flags & CBC_BF_GROUP) fail(CBC_ST_ASSERT); }   /* protocol: group mark inside a segment */
+            } else {
+                const uint64_t em = W::ballot((b_n == CBC_END_N) & (ln >= b_pos) & (ln < b_len));
+                uint32_t kend = em ? W::ctz64(em) : b_len;
+                const bool bad = b_stop < kend;                                /* zero count / total: stream_model.c:71 */
+                if (bad) kend = b_stop;
+                for (uint32_t k = b_pos; k < kend; k++)
+                    step(W::readlane(b_lo, k), W::readlane(b_hi, k), W::readlane(b_n, k), W::readlane(b_fl, k), W::readlane(b_fh, k));
+                if (bad) fail(CBC_ST_ASSERT);
+                else if (em) { b_pos = kend + 1u; done = true; }
+                else b_pos = kend;
             }
-            const uint32_t k = b_pos++;
-            const uint32_t n = W::readlane(b_n, k);
-            if (n == CBC_END_N) return;
-            if (k == b_stop) { fail(CBC_ST_ASSERT); return; }                  /* zero count / total: stream_model.c:71 */
-            step(W::readlane(b_lo, k), W::readlane(b_hi, k), n, W::readlane(b_fl, k), W::readlane(b_fh, k));
         }
     }
     /* coder wave: the next group's match mask (an empty batch flagged GROUP) */
