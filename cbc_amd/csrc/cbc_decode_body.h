@@ -890,7 +890,13 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     for (int i = 0; i < 16; i++) dt_sum[i] = 0;
     CBC_DT0();
 #endif
-    /* one record.  `first` = record 0 (a compile-time flag); a failure sets D.status and returns -- the loop's only exit is
+#ifndef CBC_DEC_NO_PEEL      /* record 0 is its own instantiation of the body: its rare, branchy code stays out of the loop
+                             * (cfg2 encode 10.15 -> 9.06 ms, decode 30.4 -> 29.85 ms: profiles/r02_ab_kernels.log run 13) */
+#define CBC_DEC_FIRST(first, r) (decltype(first)::value)
+#else
+#define CBC_DEC_FIRST(first, r) ((r) == 0u)
+#endif
+    /* one record; a failure sets D.status and returns -- the loop's only exit is
      * its header (every exit from inside a loop costs the structurised control flow a flag tested at each join) */
     auto dec_record = [&](uint32_t r, auto first) {
         D.cur_read = r;
@@ -902,11 +908,9 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         }
         /* -- decompress_rname (id_compression.c:67-94): same_ref is (1,1) until record 0 takes symbol 1,
          *    after which every record of the block must take symbol 0 (one contig per block) -- */
-        if constexpr (!decltype(first)::value) D.step_known0(10u * r - 9u, 10u * r + 2u, W::readlane(sr_fh, r & 63u));
-        else {
+        if (CBC_DEC_FIRST(first, r)) {
             uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
-            if (D.status != CBC_ST_OK) return;
-            if (sr != 1u) { D.fail(CBC_ST_ASSERT); return; }
+            if (D.status == CBC_ST_OK && sr != 1u) D.fail(CBC_ST_ASSERT);
             for (uint32_t q = 0; q < CBC_CAP_NAME && D.status == CBC_ST_OK; q++) {
                 uint32_t ch = D.rname_dec(D.prevChar);
                 if (ch == 0u) break;
@@ -914,7 +918,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
                 D.prevChar = ch;
             }
             D.prevPos = 0; D.win_clear();
-        }
+        } else D.step_known0(10u * r - 9u, 10u * r + 2u, W::readlane(sr_fh, r & 63u));
         if (D.status != CBC_ST_OK) return;
 
         CBC_DT(0);                                            /* same_ref (+ name) */
@@ -934,7 +938,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); return; }
         uint32_t pos = D.prevPos + x - 1u;
         if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); return; }     /* the 32-bit sum wrapped: not a position of this window */
-        D.win_shift(decltype(first)::value ? 256u : x - 1u);
+        D.win_shift(CBC_DEC_FIRST(first, r) ? 256u : x - 1u);
         D.prevPos = pos;
         CBC_DT(2);                                            /* pos */
         uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
@@ -963,8 +967,13 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
         CBC_DT(6);                                            /* record store */
     };
+#ifndef CBC_DEC_NO_PEEL
     if (n_reads && D.status == CBC_ST_OK) dec_record(0u, std::true_type());
     for (uint32_t r = 1; r < n_reads && D.status == CBC_ST_OK; r++) dec_record(r, std::false_type());
+#else
+    for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) dec_record(r, 0);
+#endif
+#undef CBC_DEC_FIRST
 
     if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl);
 

@@ -1134,6 +1134,9 @@ struct CbcEnc {
     /* compress_edits for an imperfect read (read_compression.c:308-600).
      * The packer has already counted the edits (token word 1) and checked that the MD string is
      * consistent with the read, so every MD token becomes exactly one SNP: numSnps = n_md. */
+    /* MODE 0: any record.  MODE 1 / 2: the caller has looked at token word 1 -- a read without (1) / with (2) indels; the
+     * model wavefront codes runs of SNP-only records in a loop that does not contain the CIGAR walks. */
+    template <int MODE = 0>
     CBC_MFN void edits(uint32_t pos, uint32_t flw, uint32_t tok_off, const V32 &seqv, const V32 &tokv,
                        const uint32_t *tokb, uint32_t n_tok_blk)
     {
@@ -1165,7 +1168,8 @@ struct CbcEnc {
                 E.small_code(CBC_LT_CHARS + cbc_basepair(letter_) * 8u, 5u, 8u, cbc_basepair(CBC_READ_BYTE(cum_))); \
                 CBC_TS(8);                                                                                  \
             } while (0)
-            if ((nDel | nIns) == 0u) {
+            const bool snp_only = MODE == 1 ? true : MODE == 2 ? false : (nDel | nIns) == 0u;
+            if (MODE != 2 && snp_only) {
                 /* SNP-only read (:557-558, :573-593): no insertion can interleave, so the MD tokens are
                  * the SNP list in order -- one loop, no CIGAR walk */
                 E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
@@ -1182,7 +1186,7 @@ struct CbcEnc {
                 /* a leading soft clip / '*' is rejected by the packer; refuse it here as well */
                 { const uint32_t t0 = CBC_TOK(2u); const uint32_t op0 = t0 & 15u;
                   if (n_cig && (op0 == CBC_OP_STAR || op0 == CBC_OP_S)) E.fail(CBC_ST_UNSUPPORTED); }
-            } else {
+            } else if (MODE != 1) {
                 E.dense_code(E.snps_exc, L0, 10u, 0u, E.snps_n);                 /* :561-564 */
                 E.dense_code(E.indels_exc, L0, 16u, nSnp & 0xffu, E.indels_n);
                 E.dense_code(E.indels_exc, L0, 16u, nDel & 0xffu, E.indels_n);
@@ -1439,7 +1443,8 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                 nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
                 nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
             }
-            while (todo && E.status == CBC_ST_OK) {
+            /* the record at the head of `todo` (its bases and tokens are in nx_seq / nx_tok), and the next one's loads */
+            auto one = [&](auto mode) {
                 const uint32_t j = W::ctz64(todo);
                 todo &= todo - 1ull;
                 E.cur_read = c0 + j;
@@ -1451,10 +1456,16 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                     nx_seq = W::load32_bytes(seqb + so, bo, bo < nrl);
                     nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
                 }
-                E.edits(W::readlane(r_pos, j), W::readlane(r_fl, j), W::readlane(r_tok, j), seqv, tokv, tokb, n_tok_blk);
+                E.template edits<decltype(mode)::value>(W::readlane(r_pos, j), W::readlane(r_fl, j), W::readlane(r_tok, j), seqv, tokv, tokb, n_tok_blk);
                 E.seg_end();
                 CBC_TS(1);                                    /* edits of one record */
                 if (E.q_len >= CBC_BATCH_MIN) E.drain();      /* hand over once a few records' symbols are pending */
+            };
+            /* runs of SNP-only records (token word 1 = deletions | insertions << 16 is zero) go through a loop whose body
+             * holds no CIGAR walk; a read with indels is coded between two such runs */
+            while (todo && E.status == CBC_ST_OK) {
+                while (todo && E.status == CBC_ST_OK && W::readlane(nx_tok, 1u) == 0u) one(std::integral_constant<int, 1>());
+                if (todo && E.status == CBC_ST_OK) one(std::integral_constant<int, 2>());
             }
         }
         if (E.status == CBC_ST_OK) { gen_sentinel(); E.seg_end(); }
@@ -1502,6 +1513,12 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         const V32 m_hi = F.m_lo + F.m_cnt;
         const V32 m_fl = CBC_FRAC(F.m_lo, F.m_n), m_fh = CBC_FRAC(m_hi, F.m_n);
 
+#ifndef CBC_ENC_NO_PEEL      /* record 0 is its own instantiation of the body: its rare, branchy code stays out of the loop
+                             * (cfg2 encode 10.15 -> 9.06 ms, decode 30.4 -> 29.85 ms: profiles/r02_ab_kernels.log run 13) */
+#define CBC_ENC_FIRST(first, r) (decltype(first)::value)
+#else
+#define CBC_ENC_FIRST(first, r) ((r) == 0u)
+#endif
         /* one record's symbols.  `first` = record 0 of the block (a compile-time flag: the loop body proper has no
          * special case in it, and nothing leaves the loop from inside -- every early exit costs the structurised
          * control flow a flag that is then tested at each join) */
@@ -1512,7 +1529,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             /* -- compress_rname (id_compression.c:39-65): same_ref is (1,1) until record 0 codes symbol 1,
              *    after which only symbol 0 is coded; the name itself is the model wave's segment -- */
             E.room(8u);                                       /* same_ref, rlength x 4, pos, flag, match */
-            if constexpr (!decltype(first)::value) E.step_known0(CBC_LZ(W::readlane(sr_hi, j)), CBC_LZ(10u * r + 2u), W::readlane(sr_fh, j));
+            if (!CBC_ENC_FIRST(first, r)) E.step_known0(CBC_LZ(W::readlane(sr_hi, j)), CBC_LZ(10u * r + 2u), W::readlane(sr_fh, j));
             else {
                 E.encode(1u, 1u, 2u); E.drain_q();
                 if (fused) { gen_rname(); E.seg_end(); } else E.seg_consume();
@@ -1551,9 +1568,14 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         /* records up to the first one fixed_group() refused; that one reports its status after the loop */
         uint32_t jn = cn;
         if (F.bad) { const uint32_t fb = W::ctz64(F.bad); if (fb < cn) jn = fb; }
+#ifndef CBC_ENC_NO_PEEL
         uint32_t j = 0;
         if (c0 == 0u && jn != 0u) { code_record(0u, std::true_type()); j = 1u; }
         for (; j < jn && E.status == CBC_ST_OK; j++) code_record(j, std::false_type());
+#else
+        for (uint32_t j = 0; j < jn && E.status == CBC_ST_OK; j++) code_record(j, 0);
+#endif
+#undef CBC_ENC_FIRST
         if (jn < cn && E.status == CBC_ST_OK) { E.cur_read = c0 + jn; E.fail(W::readlane(F.st, jn)); }
     }
     /* ---- end-of-stream sentinel (compression.c:152): same_ref symbol 1 at counts (1 + 10 (n - 1), 11),
