@@ -494,10 +494,11 @@ struct CbcDec {
         uint32_t *h = histp + 128u * k;
         W::write_uni(h, b >> 1, W::read_uni(h, b >> 1) + (1u << ((b & 1u) * 16u)));
     }
-    CBC_MFN uint32_t pos_dec()                           /* returns x = delta + 1 */
+    /* the POS symbol: its alphabet index (0 = escape), model updated; CBC_NOMEMO when the decode failed */
+    CBC_MFN uint32_t pos_sym()
     {
         V32 ln = W::lane();
-        if (!tag_ok(pos_n)) return 0u;
+        if (!tag_ok(pos_n)) return CBC_NOMEMO;
         Mask m0 = ln < (pos_card < 64u ? pos_card : 64u);
         V32 c = W::select(m0, pcnt, W::splat(0u));
         V32 inc = W::scan_incl_add(c);
@@ -516,11 +517,17 @@ struct CbcDec {
                 if (h2) { uint32_t hl = W::ctz64(h2); idx = b + hl; lo = W::readlane(ic, hl) - W::readlane(cc, hl); cnt = W::readlane(cc, hl); found = 1; }
                 base_sum = W::readlane(ic, 63u);
             }
-            if (!found) { fail(CBC_ST_ASSERT); return 0u; }
+            if (!found) { fail(CBC_ST_ASSERT); return CBC_NOMEMO; }
             step(lo, cnt, pos_n);
         }
         pos_update(idx);
-        if (idx != 0u) return idx < 64u ? W::readlane(pval, idx) : W::read_uni(pos_val_p(), idx);
+        return idx;
+    }
+    CBC_MFN uint32_t pos_value(uint32_t idx) { return idx < 64u ? W::readlane(pval, idx) : W::read_uni(pos_val_p(), idx); }
+    /* after an escape: the four bytes of the new delta, which joins the alphabet (decompress_pos :126-141) */
+    CBC_MFN uint32_t pos_escape()
+    {
+        V32 ln = W::lane();
         uint32_t b3 = pos_alpha_dec(0u), b2 = pos_alpha_dec(1u), b1 = pos_alpha_dec(2u), b0 = pos_alpha_dec(3u);
         uint32_t x = (b3 << 24) | (b2 << 16) | (b1 << 8) | b0;
         if (status != CBC_ST_OK) return 0u;
@@ -536,6 +543,12 @@ struct CbcDec {
         pos_card++;
         pos_update(pos_card - 1u);
         return x;
+    }
+    CBC_MFN uint32_t pos_dec()                           /* returns x = delta + 1 */
+    {
+        const uint32_t idx = pos_sym();
+        if (idx == CBC_NOMEMO) return 0u;
+        return idx != 0u ? pos_value(idx) : pos_escape();
     }
 
     /* ---- var: Bloom filter, then gather the context's events (each worth 10) into lanes ---- */
@@ -706,21 +719,24 @@ struct CbcDec {
     /* the edits of an imperfect read and the read itself (read_decompression.c:404-529): counts, deletions, SNPs
      * (the reference-derived base is the chars context, :454-455), insertions.  `refw` = the read's reference window,
      * 4 bases per lane; tmpb / tmpw = 320 bytes of LDS scratch, dels / insl = 256 words each.  false = failed. */
-    CBC_MFN bool edits_dec(uint32_t pos, uint32_t rl, uint32_t strand, const V32 &refw, uint8_t *dst, const uint8_t *refb,
-                           uint8_t *tmpb, uint32_t *tmpw, uint32_t *dels, uint32_t *insl)
+    /* the edit counts of an imperfect read (read_decompression.c:404-438) */
+    CBC_MFN void edit_counts(uint32_t rl, uint32_t &nSnp, uint32_t &nDel, uint32_t &nIns)
     {
             CbcDec &D = *this;
-            const V32 ln = W::lane();
-            const V32 bo = ln * 4u;
-            uint32_t nSnp = D.dense_dec_low(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n), nDel = 0, nIns = 0;
+            nSnp = D.dense_dec_low(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n); nDel = 0; nIns = 0;
             if (D.status == CBC_ST_OK && nSnp == 0u) {
                 nSnp = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
                 nDel = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
                 nIns = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
             }
-            if (D.status != CBC_ST_OK) return false;
-            if (nIns > rl) { D.fail(CBC_ST_ASSERT); return false; }
-            if ((nDel | nIns) == 0u) {
+            if (D.status == CBC_ST_OK && nIns > rl) D.fail(CBC_ST_ASSERT);
+    }
+    /* a read with SNPs only */
+    CBC_MFN void edits_snp(uint32_t rl, uint32_t strand, uint32_t nSnp, const V32 &refw, uint8_t *dst)
+    {
+            CbcDec &D = *this;
+            const V32 ln = W::lane();
+            const V32 bo = ln * 4u;
                 /* SNPs only (read_decompression.c:440-458): the read is the reference window with a few
                  * bytes replaced -- patched in the register that holds 4 bases per lane, no LDS scratch read */
                 V32 w = refw;
@@ -737,9 +753,15 @@ struct CbcDec {
                     if (at < rl)
                         w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w);
                 }
-                if (D.status != CBC_ST_OK) return false;
+                if (D.status != CBC_ST_OK) return;
                 W::store32_bytes(dst, bo, w, bo < rl);
-            } else {
+    }
+    /* a read with deletions and / or insertions (and SNPs): tmpb / tmpw = 320 bytes of LDS scratch, dels / insl = 256 words each */
+    CBC_MFN void edits_indel(uint32_t pos, uint32_t rl, uint32_t strand, uint32_t nSnp, uint32_t nDel, uint32_t nIns, uint8_t *dst,
+                             const uint8_t *refb, uint8_t *tmpb, uint32_t *tmpw, uint32_t *dels, uint32_t *insl)
+    {
+            CbcDec &D = *this;
+            const V32 ln = W::lane();
             const uint32_t T = rl - nIns;                          /* insertion-free length */
             /* deletions: cumulative matched coordinate of each deleted base */
             uint32_t p = 0;
@@ -748,7 +770,7 @@ struct CbcDec {
                 p += g;
                 W::write_uni(dels, d, p);
             }
-            if (D.status != CBC_ST_OK) return false;
+            if (D.status != CBC_ST_OK) return;
             /* insertion-free read from the reference: base m comes from ref[pos-1 + m + #{dels at <= m}] */
             for (uint32_t b = 0; b < T; b += 64u) {
                 V32 m = ln + b;
@@ -772,7 +794,7 @@ struct CbcDec {
                     W::write_uni(tmpw, at >> 2, (wv & ~(0xffu << shf)) | (cbc_basechar(alt) << shf));
                 }
             }
-            if (D.status != CBC_ST_OK) return false;
+            if (D.status != CBC_ST_OK) return;
             /* insertions: output index = matched coordinate + number of earlier insertions */
             p = 0;
             for (uint32_t i = 0; i < nIns && D.status == CBC_ST_OK; i++) {
@@ -781,7 +803,7 @@ struct CbcDec {
                 uint32_t base = D.small_dec(CBC_LT_CHARS + 5u * 8u, 5u, 8u);
                 W::write_uni(insl, i, ((p + i) << 8) | cbc_basechar(base));
             }
-            if (D.status != CBC_ST_OK) return false;
+            if (D.status != CBC_ST_OK) return;
             for (uint32_t b = 0; b < rl; b += 64u) {
                 V32 q = ln + b;
                 V32 nb = W::splat(0u), isins = W::splat(0u), ich = W::splat(0u);
@@ -797,9 +819,19 @@ struct CbcDec {
                 ch = W::select(isins != 0u, ich, ch);
                 W::store8(dst, q, ch, q < rl);
             }
-            }
-        
-            return true;
+    }
+    /* the edits of an imperfect read and the read itself (read_decompression.c:404-529): counts, deletions, SNPs
+     * (the reference-derived base is the chars context, :454-455), insertions.  `refw` = the read's reference window,
+     * 4 bases per lane.  false = failed. */
+    CBC_MFN bool edits_dec(uint32_t pos, uint32_t rl, uint32_t strand, const V32 &refw, uint8_t *dst, const uint8_t *refb,
+                           uint8_t *tmpb, uint32_t *tmpw, uint32_t *dels, uint32_t *insl)
+    {
+        uint32_t nSnp, nDel, nIns;
+        edit_counts(rl, nSnp, nDel, nIns);
+        if (status != CBC_ST_OK) return false;
+        if ((nDel | nIns) == 0u) edits_snp(rl, strand, nSnp, refw, dst);
+        else edits_indel(pos, rl, strand, nSnp, nDel, nIns, dst, refb, tmpb, tmpw, dels, insl);
+        return status == CBC_ST_OK;
     }
 };
 
@@ -890,15 +922,21 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     for (int i = 0; i < 16; i++) dt_sum[i] = 0;
     CBC_DT0();
 #endif
-#ifndef CBC_DEC_NO_PEEL      /* record 0 is its own instantiation of the body: its rare, branchy code stays out of the loop
-                             * (cfg2 encode 10.15 -> 9.06 ms, decode 30.4 -> 29.85 ms: profiles/r02_ab_kernels.log run 13) */
-#define CBC_DEC_FIRST(first, r) (decltype(first)::value)
-#else
-#define CBC_DEC_FIRST(first, r) ((r) == 0u)
-#endif
-    /* one record; a failure sets D.status and returns -- the loop's only exit is
-     * its header (every exit from inside a loop costs the structurised control flow a flag tested at each join) */
-    auto dec_record = [&](uint32_t r, auto first) {
+    /* ---- the record loop ------------------------------------------------------------------------------------------
+     * Control flow is paid for in scalar instructions, so the loop that runs for every record holds only
+     * what nearly every record needs, and leaves only through its header:
+     *   - record 0 (contig name) is coded before the loop;
+     *   - a record that turns out to need rare, bulky code -- a POS escape (four byte symbols, a new alphabet entry), a
+     *     read with indels (LDS scratch read, three edit lists) -- notes where it stands in `defer`, the loop ends at
+     *     its header, the record is finished by the general code below, and the loop is entered again;
+     *   - a failed check sets D.status, the rest of the record is skipped, and the header ends the loop.
+     * The phases of a record are lambdas over the variables just below (one set per wavefront, in scalar registers). */
+    uint32_t rl = 0, x = 0, pos = 0, flag = 0, strand = 0, match = 0, nSnp = 0, nDel = 0, nIns = 0;
+    uint32_t defer = 0;                                   /* 1: the POS escape symbol is taken; 2: the edit counts are taken, indels */
+    uint8_t *dst = seqo;
+    auto ok = [&]() { return D.status == CBC_ST_OK; };
+    /* same_ref (or, for record 0, the contig name), the four rlength symbols */
+    auto ph_head = [&](uint32_t r, auto first) {
         D.cur_read = r;
         if (pend_rl) { W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl); pend_rl = 0; }   /* record r - 1 was perfect */
         if ((r & 63u) == 0u) {                               /* scaled fractions of the closed-form symbols of 64 records */
@@ -908,10 +946,10 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         }
         /* -- decompress_rname (id_compression.c:67-94): same_ref is (1,1) until record 0 takes symbol 1,
          *    after which every record of the block must take symbol 0 (one contig per block) -- */
-        if (CBC_DEC_FIRST(first, r)) {
+        if constexpr (decltype(first)::value) {
             uint32_t sr = D.small_dec(CBC_LT_SAMEREF, 2u, 10u);
-            if (D.status == CBC_ST_OK && sr != 1u) D.fail(CBC_ST_ASSERT);
-            for (uint32_t q = 0; q < CBC_CAP_NAME && D.status == CBC_ST_OK; q++) {
+            if (ok() && sr != 1u) D.fail(CBC_ST_ASSERT);
+            for (uint32_t q = 0; q < CBC_CAP_NAME && ok(); q++) {
                 uint32_t ch = D.rname_dec(D.prevChar);
                 if (ch == 0u) break;
                 if (ch == (uint32_t)'\n' && q == 0u) { D.fail(CBC_ST_ASSERT); break; }   /* empty block */
@@ -919,61 +957,93 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             }
             D.prevPos = 0; D.win_clear();
         } else D.step_known0(10u * r - 9u, 10u * r + 2u, W::readlane(sr_fh, r & 63u));
-        if (D.status != CBC_ST_OK) return;
-
         CBC_DT(0);                                            /* same_ref (+ name) */
+        if (!ok()) return;
         /* -- read length (read_decompression.c:68-74): only the low byte carries information (Q1) -- */
-        uint32_t rl = D.rlen_dec();
+        rl = D.rlen_dec();
         {   /* contexts 1..3 only ever hold symbol 0 (quirk Q1), each coded once per record */
             const uint32_t tf = W::readlane(t_fh, r & 63u);
             for (int k = 1; k < 4; k++) D.step_known0(10u * r + 1u, 10u * r + 255u, tf);      /* a failed one leaves the state alone */
         }
-        if (D.status != CBC_ST_OK) return;
-        if (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride) { D.fail(CBC_ST_ASSERT); return; }
-
+        if (ok() && (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride)) D.fail(CBC_ST_ASSERT);
         CBC_DT(1);                                            /* rlength x 4 */
-        /* -- pos, flag -- */
-        uint32_t x = D.pos_dec();
-        if (D.status != CBC_ST_OK) return;
+    };
+    /* from the POS delta x to the match flag: position, window slide, FLAG, the reference window load, match */
+    auto ph_mid = [&](uint32_t r, auto first) {
         if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); return; }
-        uint32_t pos = D.prevPos + x - 1u;
+        pos = D.prevPos + x - 1u;
         if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); return; }     /* the 32-bit sum wrapped: not a position of this window */
-        D.win_shift(CBC_DEC_FIRST(first, r) ? 256u : x - 1u);
+        D.win_shift(decltype(first)::value ? 256u : x - 1u);
         D.prevPos = pos;
         CBC_DT(2);                                            /* pos */
-        uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
-        if (D.status != CBC_ST_OK) return;
-        const uint32_t strand = (flag >> 4) & 1u;
+        flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
+        if (!ok()) return;
+        strand = (flag >> 4) & 1u;
         if (pos == 0u || pos > ref_lim || ref_lim - pos < rl + 3u + 256u) { D.fail(CBC_ST_ASSERT); return; }
         /* the reference window of the read, 4 bases per lane: issued now, needed after the match flag
          * (perfect read: it IS the read) or after the edits (SNP-only read: patched in place) */
         refw = W::load32_bytes(refb + (pos - 1u), ln * 4u, (ln * 4u) < rl);
-
         CBC_DT(3);                                            /* flag */
-        /* -- match -- */
-        uint32_t match = D.small_dec(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | D.prevM) * 2u, 2u, 1u);
-        if (D.status != CBC_ST_OK) return;
+        match = D.small_dec(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | D.prevM) * 2u, 2u, 1u);
+        if (!ok()) return;
         D.prevM = match;
-        uint8_t *dst = seqo + (uint64_t)r * stride;
+        dst = seqo + (uint64_t)r * stride;
         CBC_DT(4);                                            /* match */
-        if (match) {
-            pend_dst = dst; pend_rl = rl;                          /* stored at the top of the next record; stride >= rl rounded to 4 */
-        } else {
-            if (!D.edits_dec(pos, rl, strand, refw, dst, refb, tmpb, lds + CBC_DLDS_TMP, dels, insl)) return;
-        }
+    };
+    auto ph_store = [&](uint32_t r) {
         CBC_DT(5);                                            /* copy / edits + reconstruction */
-        /* record */
         V32 rv0 = W::splat(pos), rv1 = W::splat(flag | (rl << 16)), rv2 = W::splat(r * stride), rv3 = W::splat(0u);
         W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
         CBC_DT(6);                                            /* record store */
     };
-#ifndef CBC_DEC_NO_PEEL
-    if (n_reads && D.status == CBC_ST_OK) dec_record(0u, std::true_type());
-    for (uint32_t r = 1; r < n_reads && D.status == CBC_ST_OK; r++) dec_record(r, std::false_type());
-#else
-    for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) dec_record(r, 0);
-#endif
-#undef CBC_DEC_FIRST
+    /* a record from the POS delta on, everything inline (record 0, and what the loop deferred) */
+    auto ph_rest_general = [&](uint32_t r, auto first, bool counts_taken) {
+        if (!counts_taken) {
+            ph_mid(r, first);
+            if (!ok()) return;
+            if (match) { pend_dst = dst; pend_rl = rl; }       /* stored at the top of the next record; stride >= rl rounded to 4 */
+            else D.edit_counts(rl, nSnp, nDel, nIns);
+        }
+        if (!match && ok()) {
+            if ((nDel | nIns) == 0u) D.edits_snp(rl, strand, nSnp, refw, dst);
+            else D.edits_indel(pos, rl, strand, nSnp, nDel, nIns, dst, refb, tmpb, lds + CBC_DLDS_TMP, dels, insl);
+        }
+        if (ok()) ph_store(r);
+    };
+    uint32_t r = 0;
+    if (n_reads && ok()) {                                   /* record 0 */
+        ph_head(0u, std::true_type());
+        if (ok()) { x = D.pos_dec(); if (ok()) ph_rest_general(0u, std::true_type(), false); }
+        r = 1u;
+    }
+    while (r < n_reads && ok()) {
+        for (; r < n_reads && ok() && defer == 0u; r++) {     /* the loop proper */
+            ph_head(r, std::false_type());
+            if (!ok()) continue;
+            const uint32_t idx = D.pos_sym();
+            if (idx == CBC_NOMEMO) continue;                 /* failed */
+            if (idx == 0u) { defer = 1u; continue; }
+            x = D.pos_value(idx);
+            ph_mid(r, std::false_type());
+            if (!ok()) continue;
+            if (match) { pend_dst = dst; pend_rl = rl; }
+            else {
+                D.edit_counts(rl, nSnp, nDel, nIns);
+                if (!ok()) continue;
+                if ((nDel | nIns) != 0u) { defer = 2u; continue; }
+                D.edits_snp(rl, strand, nSnp, refw, dst);
+                if (!ok()) continue;
+            }
+            ph_store(r);
+        }
+        if (defer != 0u && ok()) {                            /* finish record r - 1 */
+            const uint32_t rd = r - 1u;
+            D.cur_read = rd;
+            if (defer == 1u) { x = D.pos_escape(); if (ok()) ph_rest_general(rd, std::false_type(), false); }
+            else ph_rest_general(rd, std::false_type(), true);
+        }
+        defer = 0u;
+    }
 
     if (pend_rl) W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl);
 

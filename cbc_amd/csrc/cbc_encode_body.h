@@ -999,6 +999,15 @@ struct CbcEnc {
             }
         }
     }
+    /* true when the context's events all live in its LDS bucket and one more fits: var_code<true> applies (the model
+     * wavefront's SNP loop holds only that form; any other context is coded between two runs of the loop) */
+    CBC_MFN bool var_is_fast(uint32_t ctx)
+    {
+        if (GEN) return false;
+        const uint32_t bkt = (ctx & 1u) * 8u + ((ctx >> 8) & 7u);
+        return ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) < 255u && W::readlane(p0cnt, bkt) < CBC_P0_CAP && !((p0over >> bkt) & 1u);
+    }
+    template <bool FAST = false>
     CBC_MFN void var_code(uint32_t ctx, uint32_t sym)
     {
         if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
@@ -1017,10 +1026,10 @@ struct CbcEnc {
         uint32_t cn = 0, clo = 0, ceq = 0;
         const uint32_t key = (ctx << 8) | sym, strand1 = ctx & 1u;
         const bool p0class = ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u;   /* 255 is the unused-half marker */
-        bool to_global = !p0class;
+        bool to_global = FAST ? false : !p0class;
         const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);   /* the context's bucket: strand, d & 7 */
         uint32_t have = 0;
-        if (p0class) {
+        if (FAST || p0class) {
             const uint32_t d = ctx >> 8, key16 = (d << 8) | sym;
             const uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
             have = W::readlane(p0cnt, bkt);
@@ -1034,10 +1043,10 @@ struct CbcEnc {
                                                        W::select(e1 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u));
             const uint32_t tot = W::reduce_add(acc);
             cn = tot & 1023u; clo = (tot >> 10) & 1023u; ceq = tot >> 20;
-            if (have >= CBC_P0_CAP) to_global = true;
+            if (!FAST && have >= CBC_P0_CAP) to_global = true;
         }
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
-        if (to_global || ((p0over >> bkt) & 1u)) {
+        if (!FAST && (to_global || ((p0over >> bkt) & 1u))) {
             /* two hash functions, both words fetched by one LDS instruction (lanes 0 and 1) */
             h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
             const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
@@ -1066,7 +1075,7 @@ struct CbcEnc {
             }
         }
         encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
-        if (!to_global) {                                        /* p = 0 context with room in its bucket */
+        if (FAST || !to_global) {                                /* p = 0 context with room in its bucket */
             uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
             const uint32_t k16 = ((ctx >> 8) << 8) | sym;
             if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
@@ -1175,6 +1184,44 @@ struct CbcEnc {
                 E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
                 CBC_TSM(12);                                  /* edit counts */
                 uint32_t cum = 0, p = 0;
+                if (MODE == 1) {
+                    /* the loop proper holds the short form of an SNP (var context with all its events in LDS, room in the
+                     * symbol queue); anything else -- another context class, a full bucket, a full queue -- ends the run at
+                     * the loop header and is dealt with between two runs (control flow) */
+                    uint32_t k = 0;
+                    while (k < n_md && E.status == CBC_ST_OK) {
+                        bool other = false;
+                        while (k < n_md && E.status == CBC_ST_OK && !other && E.q_len < 56u) {
+                            const uint32_t t = CBC_TOK(2u + n_cig + k);
+                            const uint32_t g = t >> 8;
+                            CBC_TS(3);
+                            const uint32_t d_ = E.win_first(p, rl);
+                            CBC_TS(4);
+                            const uint32_t ctx = (((d_ << 7) + p) << 1) | strand;
+                            if (!E.var_is_fast(ctx)) other = true;          /* nothing has been touched yet */
+                            else {
+                                cum += g;
+                                E.template var_code<true>(ctx, g);
+                                CBC_TS(7);
+                                p += g + 1u;
+                                E.win_set(p - 1u);
+                                E.small_code(CBC_LT_CHARS + cbc_basepair(t & 0xffu) * 8u, 5u, 8u, cbc_basepair(CBC_READ_BYTE(cum)));
+                                CBC_TS(8);
+                                cum++; k++;
+                            }
+                        }
+                        if (k < n_md && E.status == CBC_ST_OK) {
+                            if (E.q_len >= 56u) E.drain();
+                            if (other) {
+                                const uint32_t t = CBC_TOK(2u + n_cig + k);
+                                const uint32_t g = t >> 8;
+                                cum += g;
+                                CBC_SNP(g, t & 0xffu, cum, p);
+                                cum++; k++;
+                            }
+                        }
+                    }
+                } else
                 for (uint32_t k = 0; k < n_md && E.status == CBC_ST_OK; k++) {
                     if (E.q_len >= 56u) E.drain();
                     const uint32_t t = CBC_TOK(2u + n_cig + k);
@@ -1523,7 +1570,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
          * special case in it, and nothing leaves the loop from inside -- every early exit costs the structurised
          * control flow a flag that is then tested at each join) */
 #define CBC_LZ(expr) [&]() -> uint32_t { return (expr); }
-        auto code_record = [&](uint32_t j, auto first) {
+        auto code_record = [&](uint32_t j, auto first, auto esc) {          /* esc: 0 = no escape, 1 = escape, 2 = look */
             const uint32_t r = c0 + j;
             E.cur_read = r;
             /* -- compress_rname (id_compression.c:39-65): same_ref is (1,1) until record 0 codes symbol 1,
@@ -1545,7 +1592,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             }
             /* -- compress_pos: hit, or escape + the four bytes of the new delta -- */
             E.step_fixed(CBC_LZ(W::readlane(F.p_lo, j)), CBC_LZ(W::readlane(p_hi, j)), CBC_LZ(W::readlane(p_n, j)), W::readlane(p_fl, j), W::readlane(p_fh, j));
-            if ((F.esc >> j) & 1ull) {
+            if (decltype(esc)::value == 1 || (decltype(esc)::value == 2 && ((F.esc >> j) & 1ull))) {
                 const uint32_t card = W::readlane(F.p_card, j);
                 E.pos_alpha(W::read_uni(E.pos_val, card), card);
                 E.drain_q();
@@ -1569,11 +1616,20 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
         uint32_t jn = cn;
         if (F.bad) { const uint32_t fb = W::ctz64(F.bad); if (fb < cn) jn = fb; }
 #ifndef CBC_ENC_NO_PEEL
+        /* ... and so is a record whose POS delta is new (escape + four byte symbols + a drain of the symbol queue, one
+         * record in ~16): the records between two of them run through a body without that branch */
+        typedef std::integral_constant<int, 0> Plain; typedef std::integral_constant<int, 1> Esc; typedef std::integral_constant<int, 2> Look;
         uint32_t j = 0;
-        if (c0 == 0u && jn != 0u) { code_record(0u, std::true_type()); j = 1u; }
-        for (; j < jn && E.status == CBC_ST_OK; j++) code_record(j, std::false_type());
+        if (c0 == 0u && jn != 0u) { code_record(0u, std::true_type(), Look()); j = 1u; }
+        while (j < jn && E.status == CBC_ST_OK) {
+            const uint64_t ahead = F.esc >> j;                            /* j < 64 */
+            uint32_t run_end = ahead ? j + W::ctz64(ahead) : jn;
+            if (run_end > jn) run_end = jn;
+            for (; j < run_end && E.status == CBC_ST_OK; j++) code_record(j, std::false_type(), Plain());
+            if (j < jn && E.status == CBC_ST_OK) { code_record(j, std::false_type(), Esc()); j++; }
+        }
 #else
-        for (uint32_t j = 0; j < jn && E.status == CBC_ST_OK; j++) code_record(j, 0);
+        for (uint32_t j = 0; j < jn && E.status == CBC_ST_OK; j++) code_record(j, 0, std::integral_constant<int, 2>());
 #endif
 #undef CBC_ENC_FIRST
         if (jn < cn && E.status == CBC_ST_OK) { E.cur_read = c0 + jn; E.fail(W::readlane(F.st, jn)); }
