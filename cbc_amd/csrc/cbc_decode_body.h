@@ -264,6 +264,29 @@ struct CbcDec {
     }
 
     /* ---- register-resident sparse model (flag, codebook) ---- */
+    /* a key seen before, alone: true and the symbol in `x`; on false nothing has changed and regsparse_dec() decides */
+    CBC_MFN bool regsparse_fast(const V32 &key, V32 &exc, uint32_t base, uint32_t count, uint32_t &n, uint32_t card, uint32_t stp, uint32_t &x)
+    {
+        if (n == 0u || d >= rng || n + stp >= CBC_RESCALE) return false;
+        V32 ln = W::lane();
+        const Mask live = (ln >= base) & (ln < base + count);
+        V32 A = key;
+        for (uint32_t j = 0; j < count; j++) {
+            uint32_t kj = W::readlane(key, base + j), ej = W::readlane(exc, base + j);
+            A = A + W::select(key > kj, W::splat(ej), W::splat(0u));
+        }
+        const V32 qlv = W::muldiv_v(rng, W::select(live, A, W::splat(0u)), n);
+        const V32 qhv = W::muldiv_v(rng, W::select(live, A + 1u + exc, W::splat(0u)), n);
+        const uint64_t hb = W::ballot(live & (qlv <= d) & (W::splat(d) < qhv));
+        if (!hb) return false;
+        const uint32_t hl = W::ctz64(hb);
+        x = W::readlane(key, hl);
+        if (x >= card) return false;
+        step_q(W::readlane(qlv, hl), W::readlane(qhv, hl));
+        exc = W::select(ln == hl, exc + stp, exc);
+        n += stp;
+        return true;
+    }
     CBC_MFN uint32_t regsparse_dec(V32 &key, V32 &exc, uint32_t base, uint32_t cap, uint32_t &count, uint32_t &n,
                                    uint32_t card, uint32_t stp, uint32_t cap_status)
     {
@@ -353,6 +376,20 @@ struct CbcDec {
      * scalars; the guess is verified with the two divisions the step needs anyway (the tag must lie in
      * [l + floor(range cum / n), l + floor(range (cum + count) / n))), which replaces the target division
      * and the table search.  On a miss the count is written back and the generic decode runs. */
+    /* the verified guess alone: true and the length in `x` when the tag lies in the remembered symbol's interval; the
+     * state is untouched otherwise and the caller goes through rlen_dec() (outside the record loop) */
+    CBC_MFN bool rlen_fast(uint32_t &x)
+    {
+        if (rl_memo_x == CBC_NOMEMO || rlen_n + 10u >= CBC_RESCALE) return false;
+        uint32_t ql, qh;
+        float inv = W::lane_float(W::recip_v(W::splat(rlen_n)), 0u);
+        W::muldiv2(rng, rl_memo_lo, rl_memo_lo + rl_memo_cnt, rlen_n, inv, ql, qh);
+        if (!(d >= ql && d < qh)) return false;
+        step_q(ql, qh);
+        rl_memo_cnt += 10u; rlen_n += 10u;
+        x = rl_memo_x;
+        return true;
+    }
     CBC_MFN uint32_t rlen_dec()
     {
         uint32_t *exc = tab(CBC_LDS_RLEN);
@@ -932,11 +969,13 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
      *   - a failed check sets D.status, the rest of the record is skipped, and the header ends the loop.
      * The phases of a record are lambdas over the variables just below (one set per wavefront, in scalar registers). */
     uint32_t rl = 0, x = 0, pos = 0, flag = 0, strand = 0, match = 0, nSnp = 0, nDel = 0, nIns = 0;
-    uint32_t defer = 0;                                   /* 1: the POS escape symbol is taken; 2: the edit counts are taken, indels */
+    /* where the deferred record stands: 3 = rlength[0] is next (the verified guess missed), 1 = the POS escape symbol is
+     * taken, 4 = FLAG is next (not a value seen before), 2 = the edit counts are taken and the read has indels */
+    uint32_t defer = 0;
     uint8_t *dst = seqo;
     auto ok = [&]() { return D.status == CBC_ST_OK; };
-    /* same_ref (or, for record 0, the contig name), the four rlength symbols */
-    auto ph_head = [&](uint32_t r, auto first) {
+    /* S1: same_ref, or for record 0 the contig name */
+    auto ph_same_ref = [&](uint32_t r, auto first) {
         D.cur_read = r;
         if (pend_rl) { W::store32_bytes(pend_dst, ln * 4u, refw, (ln * 4u) < pend_rl); pend_rl = 0; }   /* record r - 1 was perfect */
         if ((r & 63u) == 0u) {                               /* scaled fractions of the closed-form symbols of 64 records */
@@ -958,26 +997,25 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             D.prevPos = 0; D.win_clear();
         } else D.step_known0(10u * r - 9u, 10u * r + 2u, W::readlane(sr_fh, r & 63u));
         CBC_DT(0);                                            /* same_ref (+ name) */
-        if (!ok()) return;
-        /* -- read length (read_decompression.c:68-74): only the low byte carries information (Q1) -- */
-        rl = D.rlen_dec();
-        {   /* contexts 1..3 only ever hold symbol 0 (quirk Q1), each coded once per record */
-            const uint32_t tf = W::readlane(t_fh, r & 63u);
-            for (int k = 1; k < 4; k++) D.step_known0(10u * r + 1u, 10u * r + 255u, tf);      /* a failed one leaves the state alone */
-        }
+    };
+    /* S3: rlength[1..3] (read_decompression.c:68-74: only the low byte carries information, quirk Q1) and the length check */
+    auto ph_rl_tail = [&](uint32_t r) {
+        const uint32_t tf = W::readlane(t_fh, r & 63u);
+        for (int k = 1; k < 4; k++) D.step_known0(10u * r + 1u, 10u * r + 255u, tf);      /* a failed one leaves the state alone */
         if (ok() && (rl == 0u || rl > CBC_MAX_READ_LEN || rl > stride)) D.fail(CBC_ST_ASSERT);
         CBC_DT(1);                                            /* rlength x 4 */
     };
-    /* from the POS delta x to the match flag: position, window slide, FLAG, the reference window load, match */
-    auto ph_mid = [&](uint32_t r, auto first) {
+    /* S5: from the POS delta x to the position; the snpInRef window slides */
+    auto ph_pos = [&](auto first) {
         if (x < 1u || x >= 5000000u) { D.fail(CBC_ST_ASSERT); return; }
         pos = D.prevPos + x - 1u;
         if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); return; }     /* the 32-bit sum wrapped: not a position of this window */
         D.win_shift(decltype(first)::value ? 256u : x - 1u);
         D.prevPos = pos;
         CBC_DT(2);                                            /* pos */
-        flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
-        if (!ok()) return;
+    };
+    /* S7: after FLAG: strand, the reference window load, the match flag */
+    auto ph_flag_tail = [&](uint32_t r) {
         strand = (flag >> 4) & 1u;
         if (pos == 0u || pos > ref_lim || ref_lim - pos < rl + 3u + 256u) { D.fail(CBC_ST_ASSERT); return; }
         /* the reference window of the read, 4 bases per lane: issued now, needed after the match flag
@@ -996,15 +1034,25 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         W::store_rec(recs4, W::splat(r), ln == 0u, rv0, rv1, rv2, rv3);
         CBC_DT(6);                                            /* record store */
     };
-    /* a record from the POS delta on, everything inline (record 0, and what the loop deferred) */
-    auto ph_rest_general = [&](uint32_t r, auto first, bool counts_taken) {
-        if (!counts_taken) {
-            ph_mid(r, first);
-            if (!ok()) return;
-            if (match) { pend_dst = dst; pend_rl = rl; }       /* stored at the top of the next record; stride >= rl rounded to 4 */
-            else D.edit_counts(rl, nSnp, nDel, nIns);
+    /* a record from step `from` on with every model in its complete form (record 0, and what the loop deferred) */
+    auto general = [&](uint32_t r, auto first, uint32_t from) {
+        D.cur_read = r;
+        if (from == 3u) {
+            rl = D.rlen_dec();
+            if (ok()) ph_rl_tail(r);
+            if (ok()) x = D.pos_dec();
         }
-        if (!match && ok()) {
+        if (from == 1u) x = D.pos_escape();
+        if ((from == 1u || from == 3u) && ok()) ph_pos(first);
+        if (from != 2u && ok()) {
+            flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
+            if (ok()) ph_flag_tail(r);
+            if (ok()) {
+                if (match) { pend_dst = dst; pend_rl = rl; }   /* stored at the top of the next record; stride >= rl rounded to 4 */
+                else D.edit_counts(rl, nSnp, nDel, nIns);
+            }
+        }
+        if (ok() && !match) {
             if ((nDel | nIns) == 0u) D.edits_snp(rl, strand, nSnp, refw, dst);
             else D.edits_indel(pos, rl, strand, nSnp, nDel, nIns, dst, refb, tmpb, lds + CBC_DLDS_TMP, dels, insl);
         }
@@ -1012,19 +1060,25 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     };
     uint32_t r = 0;
     if (n_reads && ok()) {                                   /* record 0 */
-        ph_head(0u, std::true_type());
-        if (ok()) { x = D.pos_dec(); if (ok()) ph_rest_general(0u, std::true_type(), false); }
+        ph_same_ref(0u, std::true_type());
+        if (ok()) general(0u, std::true_type(), 3u);
         r = 1u;
     }
     while (r < n_reads && ok()) {
-        for (; r < n_reads && ok() && defer == 0u; r++) {     /* the loop proper */
-            ph_head(r, std::false_type());
+        for (; r < n_reads && ok() && defer == 0u; r++) {     /* the loop proper: every model in its usual-case form */
+            ph_same_ref(r, std::false_type());
+            if (!ok()) continue;
+            if (!D.rlen_fast(rl)) { defer = 3u; continue; }
+            ph_rl_tail(r);
             if (!ok()) continue;
             const uint32_t idx = D.pos_sym();
             if (idx == CBC_NOMEMO) continue;                 /* failed */
             if (idx == 0u) { defer = 1u; continue; }
             x = D.pos_value(idx);
-            ph_mid(r, std::false_type());
+            ph_pos(std::false_type());
+            if (!ok()) continue;
+            if (!D.regsparse_fast(D.fkey, D.fexc, 0u, D.fcount, D.fn, 65536u, 8u, flag)) { defer = 4u; continue; }
+            ph_flag_tail(r);
             if (!ok()) continue;
             if (match) { pend_dst = dst; pend_rl = rl; }
             else {
@@ -1036,12 +1090,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             }
             ph_store(r);
         }
-        if (defer != 0u && ok()) {                            /* finish record r - 1 */
-            const uint32_t rd = r - 1u;
-            D.cur_read = rd;
-            if (defer == 1u) { x = D.pos_escape(); if (ok()) ph_rest_general(rd, std::false_type(), false); }
-            else ph_rest_general(rd, std::false_type(), true);
-        }
+        if (defer != 0u && ok()) general(r - 1u, std::false_type(), defer);   /* finish the record the loop left */
         defer = 0u;
     }
 

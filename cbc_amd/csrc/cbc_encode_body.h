@@ -328,6 +328,17 @@ struct CbcEnc {
         q_n = W::select(here, W::splat(CBC_END_N), q_n);
         q_len++;
     }
+    /* seg_end() of the model wavefront where the caller knows the END entry fits (edits() drains at 56 entries and adds at
+     * most two per check): no hand-off code at this call site */
+    CBC_MFN void seg_end_fits()
+    {
+        W::expect_eq(q_len < 64u ? 1u : 0u, 1u, "seg_end_fits: queue full");
+        V32 ln = W::lane();
+        Mask here = ln == q_len;
+        q_lo = W::select(here, W::splat(0u), q_lo); q_cnt = W::select(here, W::splat(1u), q_cnt);
+        q_n = W::select(here, W::splat(CBC_END_N), q_n);
+        q_len++;
+    }
     CBC_MFN void publish(uint32_t flags, uint64_t neq)
     {
         V32 ln = W::lane();
@@ -999,15 +1010,6 @@ struct CbcEnc {
             }
         }
     }
-    /* true when the context's events all live in its LDS bucket and one more fits: var_code<true> applies (the model
-     * wavefront's SNP loop holds only that form; any other context is coded between two runs of the loop) */
-    CBC_MFN bool var_is_fast(uint32_t ctx)
-    {
-        if (GEN) return false;
-        const uint32_t bkt = (ctx & 1u) * 8u + ((ctx >> 8) & 7u);
-        return ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) < 255u && W::readlane(p0cnt, bkt) < CBC_P0_CAP && !((p0over >> bkt) & 1u);
-    }
-    template <bool FAST = false>
     CBC_MFN void var_code(uint32_t ctx, uint32_t sym)
     {
         if (ctx >= CBC_NVARCTX || sym >= L0) { fail(CBC_ST_ASSERT); return; }
@@ -1026,10 +1028,10 @@ struct CbcEnc {
         uint32_t cn = 0, clo = 0, ceq = 0;
         const uint32_t key = (ctx << 8) | sym, strand1 = ctx & 1u;
         const bool p0class = ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u;   /* 255 is the unused-half marker */
-        bool to_global = FAST ? false : !p0class;
+        bool to_global = !p0class;
         const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);   /* the context's bucket: strand, d & 7 */
         uint32_t have = 0;
-        if (FAST || p0class) {
+        if (p0class) {
             const uint32_t d = ctx >> 8, key16 = (d << 8) | sym;
             const uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
             have = W::readlane(p0cnt, bkt);
@@ -1043,10 +1045,10 @@ struct CbcEnc {
                                                        W::select(e1 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u));
             const uint32_t tot = W::reduce_add(acc);
             cn = tot & 1023u; clo = (tot >> 10) & 1023u; ceq = tot >> 20;
-            if (!FAST && have >= CBC_P0_CAP) to_global = true;
+            if (have >= CBC_P0_CAP) to_global = true;
         }
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
-        if (!FAST && (to_global || ((p0over >> bkt) & 1u))) {
+        if (to_global || ((p0over >> bkt) & 1u)) {
             /* two hash functions, both words fetched by one LDS instruction (lanes 0 and 1) */
             h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
             const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
@@ -1075,7 +1077,7 @@ struct CbcEnc {
             }
         }
         encode(sym + 10u * clo, 1u + 10u * ceq, L0 + 10u * cn);
-        if (FAST || !to_global) {                                /* p = 0 context with room in its bucket */
+        if (!to_global) {                                        /* p = 0 context with room in its bucket */
             uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
             const uint32_t k16 = ((ctx >> 8) << 8) | sym;
             if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
@@ -1183,52 +1185,16 @@ struct CbcEnc {
                  * the SNP list in order -- one loop, no CIGAR walk */
                 E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
                 CBC_TSM(12);                                  /* edit counts */
-                uint32_t cum = 0, p = 0;
-                if (MODE == 1) {
-                    /* the loop proper holds the short form of an SNP (var context with all its events in LDS, room in the
-                     * symbol queue); anything else -- another context class, a full bucket, a full queue -- ends the run at
-                     * the loop header and is dealt with between two runs (control flow) */
-                    uint32_t k = 0;
-                    while (k < n_md && E.status == CBC_ST_OK) {
-                        bool other = false;
-                        while (k < n_md && E.status == CBC_ST_OK && !other && E.q_len < 56u) {
-                            const uint32_t t = CBC_TOK(2u + n_cig + k);
-                            const uint32_t g = t >> 8;
-                            CBC_TS(3);
-                            const uint32_t d_ = E.win_first(p, rl);
-                            CBC_TS(4);
-                            const uint32_t ctx = (((d_ << 7) + p) << 1) | strand;
-                            if (!E.var_is_fast(ctx)) other = true;          /* nothing has been touched yet */
-                            else {
-                                cum += g;
-                                E.template var_code<true>(ctx, g);
-                                CBC_TS(7);
-                                p += g + 1u;
-                                E.win_set(p - 1u);
-                                E.small_code(CBC_LT_CHARS + cbc_basepair(t & 0xffu) * 8u, 5u, 8u, cbc_basepair(CBC_READ_BYTE(cum)));
-                                CBC_TS(8);
-                                cum++; k++;
-                            }
-                        }
-                        if (k < n_md && E.status == CBC_ST_OK) {
-                            if (E.q_len >= 56u) E.drain();
-                            if (other) {
-                                const uint32_t t = CBC_TOK(2u + n_cig + k);
-                                const uint32_t g = t >> 8;
-                                cum += g;
-                                CBC_SNP(g, t & 0xffu, cum, p);
-                                cum++; k++;
-                            }
-                        }
+                uint32_t cum = 0, p = 0, k = 0;
+                while (k < n_md && E.status == CBC_ST_OK) {   /* a full symbol queue (a read with dozens of SNPs) ends the run at its header */
+                    for (; k < n_md && E.status == CBC_ST_OK && E.q_len < 56u; k++) {
+                        const uint32_t t = CBC_TOK(2u + n_cig + k);
+                        const uint32_t g = t >> 8;
+                        cum += g;
+                        CBC_SNP(g, t & 0xffu, cum, p);
+                        cum++;
                     }
-                } else
-                for (uint32_t k = 0; k < n_md && E.status == CBC_ST_OK; k++) {
-                    if (E.q_len >= 56u) E.drain();
-                    const uint32_t t = CBC_TOK(2u + n_cig + k);
-                    const uint32_t g = t >> 8;
-                    cum += g;
-                    CBC_SNP(g, t & 0xffu, cum, p);
-                    cum++;
+                    if (k < n_md && E.status == CBC_ST_OK) E.drain();
                 }
                 /* a leading soft clip / '*' is rejected by the packer; refuse it here as well */
                 { const uint32_t t0 = CBC_TOK(2u); const uint32_t op0 = t0 & 15u;
@@ -1504,7 +1470,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                     nx_tok = W::load32(tokb + to, ln, (ln + to) < n_tok_blk, 0u);
                 }
                 E.template edits<decltype(mode)::value>(W::readlane(r_pos, j), W::readlane(r_fl, j), W::readlane(r_tok, j), seqv, tokv, tokb, n_tok_blk);
-                E.seg_end();
+                E.seg_end_fits();
                 CBC_TS(1);                                    /* edits of one record */
                 if (E.q_len >= CBC_BATCH_MIN) E.drain();      /* hand over once a few records' symbols are pending */
             };

@@ -56,8 +56,9 @@ def emu_lib():
     return _emu
 
 
-def emu_encode(pb):
-    """Run the kernel body on the CPU wave emulation.  Returns (payload list, results array)."""
+def emu_encode(pb, two_wave=False):
+    """Run the kernel body on the CPU wave emulation.  Returns (payload list, results array).
+    two_wave: the model and coder roles of a block as two host threads with the LDS hand-off ring between them."""
     L = emu_lib()
     blocks = pb.blocks.copy()
     total = L.emu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data)
@@ -66,7 +67,7 @@ def emu_encode(pb):
     db = DeviceBatch(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data,
                      blocks.ctypes.data, pb.n_blocks, pb.ref.ctypes.data, len(pb.ref), out.ctypes.data, int(total),
                      res.ctypes.data, len(pb.seq), pb.n_tok, pb.n_recs, host.LdsCaps(pb.cap_pos, pb.cap_var))
-    rc = L.emu_encode_blocks(ctypes.byref(db))
+    rc = (L.emu_encode_blocks_two_wave if two_wave else L.emu_encode_blocks)(ctypes.byref(db))
     if rc != 0:
         raise RuntimeError("emulation reported an invariant violation (rc=%d)" % rc)
     payloads = []

@@ -41,6 +41,42 @@ int emu_encode_blocks(const cbc_device_batch *b)
     }
     return g_emu_errors ? -100 : 0;
 }
+/* The two wavefronts of a block as two host threads: the model / coder roles with their LDS hand-off ring (publish, pull,
+ * seg_consume, the group batches), which the fused emulation above never enters.  The counters are acquire / release
+ * atomics on the shared table memory, exactly the ordering the kernel asks of LDS. */
+#include <thread>
+#include <atomic>
+struct WaveEmu2 : WaveEmu {
+    static uint32_t ctl_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+    static void ctl_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+    static void nap() { std::this_thread::yield(); }
+    static void barrier()
+    {
+        static std::atomic<unsigned> arrived{0};
+        const unsigned ticket = arrived.fetch_add(1, std::memory_order_acq_rel);
+        const unsigned target = (ticket / 2u + 1u) * 2u;         /* two threads per block, blocks run one after the other */
+        while (arrived.load(std::memory_order_acquire) < target) std::this_thread::yield();
+    }
+};
+extern "C" __attribute__((visibility("default")))
+int emu_encode_blocks_two_wave(const cbc_device_batch *b)
+{
+    cbc_enc_args A;
+    A.recs = b->d_recs; A.seq = b->d_seq; A.tok = b->d_tok; A.names = b->d_names; A.blocks = b->d_blocks;
+    A.ref = b->d_ref; A.out = b->d_out; A.results = b->d_results;
+    A.ref_bytes = b->ref_bytes; A.out_bytes = b->out_bytes; A.seq_bytes = b->seq_bytes; A.n_tok = b->n_tok;
+    A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
+    A.names_bytes = 0x7fffffffu;
+    g_emu_errors = 0;
+    uint32_t words = cbc_plan_lds_bytes(&b->caps) / 4;
+    for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
+        std::vector<uint32_t> lds(words, 0xdeadbeefu);
+        std::thread model([&]() { cbc_encode_stream<WaveEmu2, CBC_ROLE_MODEL>(A, blk, lds.data()); });
+        cbc_encode_stream<WaveEmu2, CBC_ROLE_CODER>(A, blk, lds.data());
+        model.join();
+    }
+    return g_emu_errors ? -100 : 0;
+}
 extern "C" __attribute__((visibility("default")))
 uint64_t emu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_read_rec *recs, const uint32_t *tok)
 { return cbc_plan_output(blocks, n_blocks, recs, tok); }

@@ -110,7 +110,7 @@ struct WaveEmu {
     static uint32_t divq(uint64_t p, uint32_t d)
     {
         float inv = 1.0f / (float)d;
-        static unsigned tick = 0;
+        static thread_local unsigned tick = 0;
         uint32_t bits; memcpy(&bits, &inv, 4); bits += (uint32_t)((int)(tick++ % 5u) - 2); memcpy(&inv, &bits, 4);
         uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
         float pf = (float)((phi << 16) | (plo >> 16)) * 65536.0f;
@@ -168,7 +168,7 @@ struct WaveEmu {
         for (int i = 0; i < 64; i++) {
             float f = n.v[i] ? 1.0f / (float)n.v[i] : 0.0f;
             uint32_t bits; memcpy(&bits, &f, 4);
-            static unsigned tick = 0;
+            static thread_local unsigned tick = 0;
             if (n.v[i]) bits += (uint32_t)((int)(tick++ % 5u) - 2);          /* -2..+2 ulp */
             r.v[i] = bits;
         }

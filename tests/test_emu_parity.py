@@ -54,6 +54,26 @@ def test_blocks_match_oracle(built, kw, L, br):
     _check(pb, sam)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kw,L,br", [
+    (dict(), 150, 1024),
+    (dict(sub_rate=0.02, indel_frac=0.5, trailing_s_frac=0.2, dup_pos_frac=0.1), 100, 512),
+    (dict(sub_rate=0.45, indel_frac=0.3), 150, 256),              # dozens of edits per read: the queue drains inside a record
+    (dict(sub_rate=0.003, indel_frac=0.02), 100, 1000),
+])
+def test_two_wavefront_hand_off_equals_fused(built, kw, L, br):
+    """The kernel as it runs on the GPU: the model and coder roles of a block as two host threads with the LDS hand-off
+    ring between them (publish / pull / seg_consume, group batches, the runs of SNP-only records, the record loop split at
+    POS escapes).  Same payload bytes, status and symbol count as the fused emulation -- and no hang."""
+    contigs = [300000, 120000] if L != 100 or br != 1000 else [40_000_000]
+    fa, sam, _, _ = synth.dataset(5, contigs, [3000, 1200][:len(contigs)], L, **kw)
+    pb = host.pack_sam(sam, fa, block_reads=br)
+    p1, r1 = blockref.emu_encode(pb)
+    p2, r2 = blockref.emu_encode(pb, two_wave=True)
+    assert p1 == p2
+    assert (r1["status"] == r2["status"]).all() and (r1["n_symbols"] == r2["n_symbols"]).all()
+
+
 def test_md_last_column_quirk(built):
     """Q2: the '\\n' letter token -> phantom N->N SNP, same bytes as the oracle."""
     fa, _, rbc, _ = synth.dataset(9, [100000], [600], 100, sub_rate=0.02, indel_frac=0.0)
