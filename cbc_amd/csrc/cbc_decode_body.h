@@ -83,7 +83,7 @@ struct CbcDec {
     uint32_t prevPos, prevM, prevChar;
     uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
     V32 p0cnt; uint32_t p0over;
-    uint64_t w0, w1, w2, w3;
+    CbcWin<W> win;
 
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
     CBC_MFN uint32_t *tab(uint32_t off) { return lds + off; }
@@ -714,48 +714,11 @@ struct CbcDec {
     }
 
     /* ---- snpInRef window (same as the encoder's) ---- */
-    CBC_MFN void win_clear() { w0 = w1 = w2 = w3 = 0; }
-    CBC_MFN void win_shift(uint32_t d)
-    {
-        if (d == 0u) return;
-        if (d >= 256u) { win_clear(); return; }
-        uint32_t wsh = d >> 6, bsh = d & 63u;
-        if (wsh == 1u) { w0 = w1; w1 = w2; w2 = w3; w3 = 0; }
-        else if (wsh == 2u) { w0 = w2; w1 = w3; w2 = 0; w3 = 0; }
-        else if (wsh == 3u) { w0 = w3; w1 = 0; w2 = 0; w3 = 0; }
-        if (bsh) {
-            uint32_t inv = 64u - bsh;
-            w0 = (w0 >> bsh) | (w1 << inv); w1 = (w1 >> bsh) | (w2 << inv);
-            w2 = (w2 >> bsh) | (w3 << inv); w3 = w3 >> bsh;
-        }
-    }
-    CBC_MFN uint32_t win_first(uint32_t p, uint32_t rl)
-    {
-        uint32_t out = rl + 2u;
-        if (p >= rl) return out;
-        uint32_t pw = p >> 6; uint64_t pm = ~0ull << (p & 63u);
-        uint64_t a0 = pw == 0u ? (w0 & pm) : 0ull;
-        uint64_t a1 = pw == 1u ? (w1 & pm) : (pw < 1u ? w1 : 0ull);
-        uint64_t a2 = pw == 2u ? (w2 & pm) : (pw < 2u ? w2 : 0ull);
-        uint64_t a3 = pw == 3u ? (w3 & pm) : w3;
-        uint32_t pos = 0xffffffffu;
-        if (a0) pos = W::ctz64(a0);
-        else if (a1) pos = 64u + W::ctz64(a1);
-        else if (a2) pos = 128u + W::ctz64(a2);
-        else if (a3) pos = 192u + W::ctz64(a3);
-        if (pos < rl) out = pos - p;
-        return out;
-    }
-    CBC_MFN void win_set(uint32_t k)
-    {
-        uint64_t bit = 1ull << (k & 63u); uint32_t kw = k >> 6;
-        w0 |= (kw == 0u) ? bit : 0ull; w1 |= (kw == 1u) ? bit : 0ull;
-        w2 |= (kw == 2u) ? bit : 0ull; w3 |= (kw == 3u) ? bit : 0ull;
-    }
+    CBC_MFN void win_clear() { win.clear(); }
+    CBC_MFN void win_shift(uint32_t d) { win.shift(d); }
+    CBC_MFN uint32_t win_first(uint32_t p, uint32_t rl) { return win.first(p, rl); }
+    CBC_MFN void win_set(uint32_t k) { win.set(k); }
 
-    /* the edits of an imperfect read and the read itself (read_decompression.c:404-529): counts, deletions, SNPs
-     * (the reference-derived base is the chars context, :454-455), insertions.  `refw` = the read's reference window,
-     * 4 bases per lane; tmpb / tmpw = 320 bytes of LDS scratch, dels / insl = 256 words each.  false = failed. */
     /* the edit counts of an imperfect read (read_decompression.c:404-438) */
     CBC_MFN void edit_counts(uint32_t rl, uint32_t &nSnp, uint32_t &nDel, uint32_t &nIns)
     {

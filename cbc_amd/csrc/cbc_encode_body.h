@@ -137,6 +137,95 @@ CBC_FN uint32_t cbc_basepair(uint32_t c)            /* char2basepair sam_models.
 /* GEN = false: the block kernels (LDS-resident sparse tables, counting-model closed forms for the per-record
  * models).  GEN = true: the whole-file stream kernel of cbc_stream_body.h -- the same coder, bit packer and edit
  * walk, with the general (rescaling) form of every model and the var table dense in global memory. */
+/* ---- snpInRef[cumsumP - 1 .. + 255] (read_compression.c:589, 703-718): a 256-bit window ---------------------------------
+ * Kept in ONE vector register, 32 bits in each of lanes 0..7 (the other lanes hold 0): sliding it is two lane gathers and a
+ * funnel shift, the first mark at or after p is one ballot and two count-trailing-zeros, setting a mark is a compare and an
+ * OR.  (Round 1 kept it in four 64-bit scalars: ~30 scalar instructions per slide or search, on the unit that is these
+ * kernels' busiest port; -DCBC_WIN_SCALAR restores that form for A/B.) */
+template <class W>
+struct CbcWin {
+    typedef typename W::V32 V32;
+#ifndef CBC_WIN_SCALAR
+    V32 w;
+    CBC_MFN void clear() { w = W::splat(0u); }
+    CBC_MFN void shift(uint32_t d)                      /* drop the d lowest positions */
+    {
+        if (d == 0u) return;
+        if (d >= 256u) { clear(); return; }
+        const V32 ln = W::lane();
+        const V32 src = ln + (d >> 5);
+        const V32 lo = W::lane_gather(w, src), hi = W::lane_gather(w, src + 1u);      /* lanes 8.. hold 0 */
+        w = W::select(ln < 8u, W::funnel_shr(hi, lo, d & 31u), W::splat(0u));
+    }
+    /* compute_delta_to_first_snp, read_compression.c:703-718 */
+    CBC_MFN uint32_t first(uint32_t p, uint32_t rl)
+    {
+        uint32_t out = rl + 2u;
+        if (p >= rl) return out;
+        const V32 ln = W::lane();
+        const uint32_t pw = p >> 5;
+        const V32 a = W::select(ln == pw, w & (0xffffffffu << (p & 31u)), W::select(ln > pw, w, W::splat(0u)));
+        const uint64_t hb = W::ballot(a != 0u);
+        if (hb) {
+            const uint32_t hl = W::ctz64(hb);
+            const uint32_t pos = hl * 32u + W::ctz64((uint64_t)W::readlane(a, hl));
+            if (pos < rl) out = pos - p;
+        }
+        return out;
+    }
+    CBC_MFN void set(uint32_t k)                        /* k >= 256: outside the window, ignored */
+    {
+        if (k < 256u) w = w | W::select(W::lane() == (k >> 5), W::splat(1u << (k & 31u)), W::splat(0u));
+    }
+#else
+    uint64_t w0, w1, w2, w3;
+    CBC_MFN void clear() { w0 = w1 = w2 = w3 = 0; }
+    CBC_MFN void shift(uint32_t d)
+    {
+        if (d == 0u) return;
+        if (d >= 256u) { clear(); return; }
+        uint32_t wsh = d >> 6, bsh = d & 63u;
+        if (wsh == 1u) { w0 = w1; w1 = w2; w2 = w3; w3 = 0; }
+        else if (wsh == 2u) { w0 = w2; w1 = w3; w2 = 0; w3 = 0; }
+        else if (wsh == 3u) { w0 = w3; w1 = 0; w2 = 0; w3 = 0; }
+        if (bsh) {
+            uint32_t inv = 64u - bsh;
+            w0 = (w0 >> bsh) | (w1 << inv);
+            w1 = (w1 >> bsh) | (w2 << inv);
+            w2 = (w2 >> bsh) | (w3 << inv);
+            w3 = w3 >> bsh;
+        }
+    }
+    CBC_MFN uint32_t first(uint32_t p, uint32_t rl)
+    {
+        uint32_t out = rl + 2u;
+        if (p >= rl) return out;
+        uint32_t pw = p >> 6; uint64_t pm = ~0ull << (p & 63u);
+        uint64_t a0 = pw == 0u ? (w0 & pm) : 0ull;
+        uint64_t a1 = pw == 1u ? (w1 & pm) : (pw < 1u ? w1 : 0ull);
+        uint64_t a2 = pw == 2u ? (w2 & pm) : (pw < 2u ? w2 : 0ull);
+        uint64_t a3 = pw == 3u ? (w3 & pm) : w3;
+        uint32_t pos = 0xffffffffu;
+        if (a0) pos = W::ctz64(a0);
+        else if (a1) pos = 64u + W::ctz64(a1);
+        else if (a2) pos = 128u + W::ctz64(a2);
+        else if (a3) pos = 192u + W::ctz64(a3);
+        if (pos < rl) out = pos - p;
+        return out;
+    }
+    CBC_MFN void set(uint32_t k)
+    {
+        /* selects, not an if-chain: an if-chain over adjacent members is turned back into a
+         * runtime-indexed access by the optimiser, which forces the window into scratch memory */
+        uint64_t bit = 1ull << (k & 63u); uint32_t kw = k >> 6;
+        w0 |= (kw == 0u) ? bit : 0ull;
+        w1 |= (kw == 1u) ? bit : 0ull;
+        w2 |= (kw == 2u) ? bit : 0ull;
+        w3 |= (kw == 3u) ? bit : 0ull;
+    }
+#endif
+};
+
 template <class W, bool GEN = false>
 struct CbcEnc {
     typedef typename W::V32 V32;
@@ -181,7 +270,7 @@ struct CbcEnc {
 
     /* ---- cross-read state (T7/T8 of SURVEY.md) ---- */
     uint32_t prevPos, prevM, prevChar, win_pos;
-    uint64_t w0, w1, w2, w3;                /* snpInRef[cumsumP-1 .. +255] as a 256-bit bitmap   */
+    CbcWin<W> win;                           /* snpInRef[cumsumP-1 .. +255]                       */
 
     /* ======================================================================================= */
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
@@ -1095,52 +1184,10 @@ struct CbcEnc {
         else { W::append_list(var_ev, nev, key); nev++; }
     }
 
-    /* ---- snpInRef window: 256 bits in four scalars, no runtime-indexed arrays ---- */
-    CBC_MFN void win_clear() { w0 = w1 = w2 = w3 = 0; }
-    CBC_MFN void win_shift(uint32_t d)
-    {
-        if (d == 0u) return;
-        if (d >= 256u) { win_clear(); return; }
-        uint32_t wsh = d >> 6, bsh = d & 63u;
-        if (wsh == 1u) { w0 = w1; w1 = w2; w2 = w3; w3 = 0; }
-        else if (wsh == 2u) { w0 = w2; w1 = w3; w2 = 0; w3 = 0; }
-        else if (wsh == 3u) { w0 = w3; w1 = 0; w2 = 0; w3 = 0; }
-        if (bsh) {
-            uint32_t inv = 64u - bsh;
-            w0 = (w0 >> bsh) | (w1 << inv);
-            w1 = (w1 >> bsh) | (w2 << inv);
-            w2 = (w2 >> bsh) | (w3 << inv);
-            w3 = w3 >> bsh;
-        }
-    }
-    /* compute_delta_to_first_snp, read_compression.c:703-718 */
-    CBC_MFN uint32_t win_first(uint32_t p, uint32_t rl)
-    {
-        uint32_t out = rl + 2u;
-        if (p >= rl) return out;
-        uint32_t pw = p >> 6; uint64_t pm = ~0ull << (p & 63u);
-        uint64_t a0 = pw == 0u ? (w0 & pm) : 0ull;
-        uint64_t a1 = pw == 1u ? (w1 & pm) : (pw < 1u ? w1 : 0ull);
-        uint64_t a2 = pw == 2u ? (w2 & pm) : (pw < 2u ? w2 : 0ull);
-        uint64_t a3 = pw == 3u ? (w3 & pm) : w3;
-        uint32_t pos = 0xffffffffu;
-        if (a0) pos = W::ctz64(a0);
-        else if (a1) pos = 64u + W::ctz64(a1);
-        else if (a2) pos = 128u + W::ctz64(a2);
-        else if (a3) pos = 192u + W::ctz64(a3);
-        if (pos < rl) out = pos - p;
-        return out;
-    }
-    CBC_MFN void win_set(uint32_t k)
-    {
-        /* selects, not an if-chain: an if-chain over adjacent members is turned back into a
-         * runtime-indexed access by the optimiser, which forces the window into scratch memory */
-        uint64_t bit = 1ull << (k & 63u); uint32_t kw = k >> 6;
-        w0 |= (kw == 0u) ? bit : 0ull;
-        w1 |= (kw == 1u) ? bit : 0ull;
-        w2 |= (kw == 2u) ? bit : 0ull;
-        w3 |= (kw == 3u) ? bit : 0ull;
-    }
+    CBC_MFN void win_clear() { win.clear(); }
+    CBC_MFN void win_shift(uint32_t d) { win.shift(d); }
+    CBC_MFN uint32_t win_first(uint32_t p, uint32_t rl) { return win.first(p, rl); }
+    CBC_MFN void win_set(uint32_t k) { win.set(k); }
 
     /* compress_edits for an imperfect read (read_compression.c:308-600).
      * The packer has already counted the edits (token word 1) and checked that the MD string is

@@ -78,6 +78,9 @@ struct WaveGPU {
         uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l - 1u) << 2), (int)v);
         return l == 0u ? fill : t;
     }
+    /* lane i takes the value of lane idx[i] (ds_bpermute); ({hi, lo} >> sh) low word, sh < 32 (v_alignbit) */
+    static CBC_FN V32 lane_gather(V32 v, V32 idx) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)v); }
+    static CBC_FN V32 funnel_shr(V32 hi, V32 lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
     /* bit `lane` of a wave-uniform 64-bit mask */
     static CBC_FN Mask lane_bit(uint64_t m)
     {

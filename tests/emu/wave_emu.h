@@ -67,6 +67,9 @@ struct WaveEmu {
     static uint32_t reduce_add(const V32 &v) { uint32_t s = 0; for (int i = 0; i < 64; i++) s += v.v[i]; return s; }
 
     static V32 prefix_popc(uint64_t m) { V32 r; uint32_t c = 0; for (int i = 0; i < 64; i++) { r.v[i] = c; c += (uint32_t)((m >> i) & 1u); } return r; }
+    static V32 lane_gather(const V32 &v, const V32 &idx) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = v.v[idx.v[i] & 63u]; return r; }
+    static V32 funnel_shr(const V32 &hi, const V32 &lo, uint32_t sh)
+    { V32 r; if (sh >= 32u) emu_oob("funnel_shr shift"); for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)((((uint64_t)hi.v[i] << 32) | lo.v[i]) >> sh); return r; }
     static V32 shift_up1(const V32 &v, uint32_t fill) { V32 r; r.v[0] = fill; for (int i = 1; i < 64; i++) r.v[i] = v.v[i - 1]; return r; }
     static Mask lane_bit(uint64_t m) { Mask r; for (int i = 0; i < 64; i++) r.b[i] = ((m >> i) & 1u) != 0; return r; }
     static V32 frac32(const V32 &c, const V32 &n)
