@@ -69,7 +69,8 @@ struct CbcDec {
     typedef typename W::Mask Mask;
 
     /* ---- range decoder + bit reader ---- */
-    uint32_t l, rng, d;                       /* lower bound, range = u - l + 1, tag - l */
+    typedef typename W::Uv Uv;
+    Uv l, rng, d;                             /* lower bound, range = u - l + 1, tag - l: wave-uniform, see W::dv */
     uint64_t acc; uint32_t navail;
     V32 wordv; uint32_t widx, nwords_in, tail_valid; const uint8_t *inb;
     uint32_t status, nsym, fail_read, cur_read;
@@ -117,7 +118,7 @@ struct CbcDec {
     /* arithmetic_get_symbol_range, Arithmetic_stream.c:373-381 */
     CBC_MFN uint32_t target(uint32_t n)
     {
-        if (n == 0u || d >= rng) { fail(CBC_ST_ASSERT); return 0u; }       /* gap = t - l + 1: 0 or beyond the range */
+        if (n == 0u || W::dv_ge(d, rng)) { fail(CBC_ST_ASSERT); return 0u; }   /* gap = t - l + 1: 0 or beyond the range */
         uint64_t p = ((uint64_t)d + 1u) * n - 1u;
         return W::divq(p, rng);
     }
@@ -128,13 +129,13 @@ struct CbcDec {
      * sh bits -- one bit-reader call per step, and the models below read d and range as they are. */
     CBC_MFN void renorm()
     {
-        const uint32_t uu = l + rng - 1u;
-        const uint32_t x = l ^ uu;
-        const uint32_t k1 = W::clz32((x << 6) | 32u);               /* leading zeros of the 26-bit x; 26 when x = 0 */
-        const uint32_t k3 = W::clz32((((~l | uu) << 7) | 127u) << k1);   /* leading ones of ((l & ~u) << 7) << k1 */
-        const uint32_t sh = k1 + k3;
-        if (sh) {
-            const uint32_t bits = take(sh);
+        const Uv uu = l + rng - 1u;
+        const Uv x = l ^ uu;
+        const Uv k1 = W::clz_uv((x << 6) | 32u);                    /* leading zeros of the 26-bit x; 26 when x = 0 */
+        const Uv k3 = W::clz_uv((((~l | uu) << 7) | 127u) << k1);   /* leading ones of ((l & ~u) << 7) << k1 */
+        const Uv sh = k1 + k3;
+        if (W::dv_nz(sh)) {
+            const uint32_t bits = take(W::dv_scalar(sh));
             l = (l << sh) & CBC_M25;
             rng = rng << sh;
             d = (d << sh) | bits;
@@ -148,17 +149,17 @@ struct CbcDec {
     CBC_MFN void step_known0(uint32_t cnt0, uint32_t n, uint32_t f)
     {
         nsym++;
-        const uint64_t p = (uint64_t)rng * f;
-        uint32_t q = (uint32_t)(p >> 32);
-        if ((uint32_t)p >= 0xfc000000u) q += (rng * cnt0 - q * n >= n) ? 1u : 0u;
-        W::expect_eq(q, (uint32_t)((uint64_t)rng * cnt0 / n), "step_known0 quotient");
-        if (q == 0u || d >= q) { fail(CBC_ST_ASSERT); return; }            /* another symbol was coded here */
+        Uv q, plo;
+        W::mul64(rng, f, q, plo);
+        if (W::uv_ge(plo, 0xfc000000u)) q += (rng * cnt0 - q * n >= n) ? 1u : 0u;
+        W::expect_eq(W::dv_scalar(q), (uint32_t)((uint64_t)W::dv_scalar(rng) * cnt0 / n), "step_known0 quotient");
+        if (!W::dv_nz(q) || W::dv_ge(d, q)) { fail(CBC_ST_ASSERT); return; }   /* another symbol was coded here */
         rng = q;
         /* mostly nothing shifts after a symbol this probable: l < 2^25 between steps, so E1/E2 need u < 2^25 and E3
          * needs l >= 2^24 and u < 3 * 2^24 -- neither when q exceeds the bound below (cf. CbcEnc::step_known0) */
-        if (q > (((l & (1u << 24)) | (1u << 25)) - l)) {
-            W::expect_eq(((l ^ (l + q - 1u)) >> 25) & 1u, 1u, "step_known0: E1/E2 would shift");
-            W::expect_eq((l >> 24) & (~(l + q - 1u) >> 24) & 1u, 0u, "step_known0: E3 would shift");
+        if (W::dv_gt(q, ((l & (1u << 24)) | (1u << 25)) - l)) {
+            W::expect_eq(((W::dv_scalar(l) ^ (W::dv_scalar(l) + W::dv_scalar(q) - 1u)) >> 25) & 1u, 1u, "step_known0: E1/E2 would shift");
+            W::expect_eq((W::dv_scalar(l) >> 24) & (~(W::dv_scalar(l) + W::dv_scalar(q) - 1u) >> 24) & 1u, 0u, "step_known0: E3 would shift");
             return;
         }
         renorm();
@@ -184,16 +185,16 @@ struct CbcDec {
      * back to target() + search when the tag lies outside the lanes they hold. */
     CBC_MFN bool tag_ok(uint32_t n)                       /* the checks of target() */
     {
-        if (n == 0u || d >= rng) { fail(CBC_ST_ASSERT); return false; }
+        if (n == 0u || W::dv_ge(d, rng)) { fail(CBC_ST_ASSERT); return false; }
         return true;
     }
-    CBC_MFN void step_q0(uint32_t ql, uint32_t qh) { l += ql; d -= ql; rng = qh - ql; renorm(); }
+    CBC_MFN void step_q0(uint32_t ql, uint32_t qh) { l += ql; d -= ql; rng = W::dv(qh - ql); renorm(); }
     CBC_MFN void step_q(uint32_t ql, uint32_t qh) { nsym++; step_q0(ql, qh); }
     /* cum_incl: inclusive cumulative count per lane, non-decreasing over the live lanes [first, first + m), 0 elsewhere */
     CBC_MFN bool prefix_find(V32 cum_incl, Mask live, uint32_t first, uint32_t n, uint32_t &idx, uint32_t &ql, uint32_t &qh)
     {
         const V32 qv = W::muldiv_v(rng, cum_incl, n);
-        const uint64_t hb = W::ballot(live & (W::splat(d) < qv));
+        const uint64_t hb = W::ballot(live & (W::dvv(d) < qv));
         if (!hb) return false;
         const uint32_t hl = W::ctz64(hb);
         qh = W::readlane(qv, hl); ql = hl != first ? W::readlane(qv, hl - 1u) : 0u;
@@ -214,8 +215,8 @@ struct CbcDec {
         uint32_t q0, qn;
         float inv = W::lane_float(W::recip_v(W::splat(n)), 0u);
         W::muldiv2(rng, c0, n, n, inv, q0, qn);
-        const uint32_t x = (d >= q0) ? 1u : 0u;
-        if (x == 0u) rng = q0; else { l += q0; d -= q0; rng -= q0; }      /* symbol 1 keeps the old upper bound */
+        const uint32_t x = W::dv_ge(d, q0) ? 1u : 0u;
+        if (x == 0u) rng = W::dv(q0); else { l += q0; d -= q0; rng -= q0; }      /* symbol 1 keeps the old upper bound */
         renorm();
         V32 ln = W::lane();
         small = W::select(ln == base + x, small + stp, small);
@@ -267,7 +268,7 @@ struct CbcDec {
     /* a key seen before, alone: true and the symbol in `x`; on false nothing has changed and regsparse_dec() decides */
     CBC_MFN bool regsparse_fast(const V32 &key, V32 &exc, uint32_t base, uint32_t count, uint32_t &n, uint32_t card, uint32_t stp, uint32_t &x)
     {
-        if (n == 0u || d >= rng || n + stp >= CBC_RESCALE) return false;
+        if (n == 0u || W::dv_ge(d, rng) || n + stp >= CBC_RESCALE) return false;
         V32 ln = W::lane();
         const Mask live = (ln >= base) & (ln < base + count);
         V32 A = key;
@@ -277,7 +278,7 @@ struct CbcDec {
         }
         const V32 qlv = W::muldiv_v(rng, W::select(live, A, W::splat(0u)), n);
         const V32 qhv = W::muldiv_v(rng, W::select(live, A + 1u + exc, W::splat(0u)), n);
-        const uint64_t hb = W::ballot(live & (qlv <= d) & (W::splat(d) < qhv));
+        const uint64_t hb = W::ballot(live & (qlv <= W::dvv(d)) & (W::dvv(d) < qhv));
         if (!hb) return false;
         const uint32_t hl = W::ctz64(hb);
         x = W::readlane(key, hl);
@@ -302,7 +303,7 @@ struct CbcDec {
         const uint32_t range = rng;
         const V32 qlv = W::muldiv_v(range, W::select(live, A, W::splat(0u)), n);
         const V32 qhv = W::muldiv_v(range, W::select(live, A + 1u + exc, W::splat(0u)), n);
-        const uint64_t hb = W::ballot(live & (qlv <= d) & (W::splat(d) < qhv));
+        const uint64_t hb = W::ballot(live & (qlv <= W::dvv(d)) & (W::dvv(d) < qhv));
         uint32_t x, hl = 0; const bool hit = hb != 0ull;
         if (hit) {
             hl = W::ctz64(hb); x = W::readlane(key, hl);
@@ -384,7 +385,7 @@ struct CbcDec {
         uint32_t ql, qh;
         float inv = W::lane_float(W::recip_v(W::splat(rlen_n)), 0u);
         W::muldiv2(rng, rl_memo_lo, rl_memo_lo + rl_memo_cnt, rlen_n, inv, ql, qh);
-        if (!(d >= ql && d < qh)) return false;
+        if (!(W::dv_ge(d, ql) && W::dv_gt(qh, d))) return false;
         step_q(ql, qh);
         rl_memo_cnt += 10u; rlen_n += 10u;
         x = rl_memo_x;
@@ -397,7 +398,7 @@ struct CbcDec {
             uint32_t ql, qh;
             float inv = W::lane_float(W::recip_v(W::splat(rlen_n)), 0u);
             W::muldiv2(rng, rl_memo_lo, rl_memo_lo + rl_memo_cnt, rlen_n, inv, ql, qh);
-            if (d >= ql && d < qh) {
+            if (W::dv_ge(d, ql) && W::dv_gt(qh, d)) {
                 step_q(ql, qh);
                 rl_memo_cnt += 10u; rlen_n += 10u;
                 if (rlen_n >= CBC_RESCALE) {                   /* through the table: unreachable below CBC_MAX_BLOCK_READS */
@@ -722,14 +723,20 @@ struct CbcDec {
     /* the edit counts of an imperfect read (read_decompression.c:404-438) */
     CBC_MFN void edit_counts(uint32_t rl, uint32_t &nSnp, uint32_t &nDel, uint32_t &nIns)
     {
-            CbcDec &D = *this;
-            nSnp = D.dense_dec_low(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n); nDel = 0; nIns = 0;
-            if (D.status == CBC_ST_OK && nSnp == 0u) {
-                nSnp = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-                nDel = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
-                nIns = D.dense_dec_low(D.tab(CBC_LDS_INDELS), L0, 16u, D.indels_n);
+            nSnp = dense_dec_low(tab(CBC_LDS_SNPS), L0, 10u, snps_n); nDel = 0; nIns = 0;
+            if (status == CBC_ST_OK && nSnp == 0u) indel_counts(rl, nSnp, nDel, nIns);
+    }
+    /* after an SNP count of 0: the three counts of a read with indels (:420-438) */
+    CBC_MFN void indel_counts(uint32_t rl, uint32_t &nSnp, uint32_t &nDel, uint32_t &nIns)
+    {
+            uint32_t c0 = 0, c1 = 0, c2 = 0;
+            for (int k = 0; k < 3 && status == CBC_ST_OK; k++) {
+                const uint32_t c = dense_dec_low(tab(CBC_LDS_INDELS), L0, 16u, indels_n);
+                c0 = k == 0 ? c : c0; c1 = k == 1 ? c : c1; c2 = k == 2 ? c : c2;
             }
-            if (D.status == CBC_ST_OK && nIns > rl) D.fail(CBC_ST_ASSERT);
+            if (status != CBC_ST_OK) return;
+            nSnp = c0; nDel = c1; nIns = c2;
+            if (nIns > rl) fail(CBC_ST_ASSERT);
     }
     /* a read with SNPs only */
     CBC_MFN void edits_snp(uint32_t rl, uint32_t strand, uint32_t nSnp, const V32 &refw, uint8_t *dst)
@@ -852,7 +859,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     const uint32_t in_bytes = bd->in_bytes, n_reads = bd->n_reads, L0 = bd->read_length, stride = bd->seq_stride;
 
     D.status = CBC_ST_OK; D.nsym = 0; D.fail_read = 0; D.cur_read = 0;
-    D.l = 0; D.rng = CBC_M26 + 1u; D.d = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
+    D.l = W::dv(0u); D.rng = W::dv(CBC_M26 + 1u); D.d = W::dv(0u); D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
     D.inb = A.in + in_off;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = A.cap_var; D.L0 = L0;
     D.evp = A.var_scratch + (uint64_t)blk * A.cap_var;
@@ -892,7 +899,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     D.p0cnt = W::splat(0u); D.p0over = 0;
 
     /* the tag: first 26 bits (alloc_arithmetic_stream, Arithmetic_stream.c:260-263) */
-    if (D.status == CBC_ST_OK) D.d = D.take(26u);
+    if (D.status == CBC_ST_OK) D.d = W::dv(D.take(26u));
 
     /* stream header: int(L0), 32 x int(WELL), int(8) */
     for (uint32_t k = 0; k < 34u && D.status == CBC_ST_OK; k++) {
@@ -933,7 +940,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
      * The phases of a record are lambdas over the variables just below (one set per wavefront, in scalar registers). */
     uint32_t rl = 0, x = 0, pos = 0, flag = 0, strand = 0, match = 0, nSnp = 0, nDel = 0, nIns = 0;
     /* where the deferred record stands: 3 = rlength[0] is next (the verified guess missed), 1 = the POS escape symbol is
-     * taken, 4 = FLAG is next (not a value seen before), 2 = the edit counts are taken and the read has indels */
+     * taken, 4 = FLAG is next (not a value seen before), 2 = the SNP count is taken and is 0 (the counts of a read with indels follow) */
     uint32_t defer = 0;
     uint8_t *dst = seqo;
     auto ok = [&]() { return D.status == CBC_ST_OK; };
@@ -1015,6 +1022,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
                 else D.edit_counts(rl, nSnp, nDel, nIns);
             }
         }
+        if (from == 2u) { nDel = 0; nIns = 0; D.indel_counts(rl, nSnp, nDel, nIns); }
         if (ok() && !match) {
             if ((nDel | nIns) == 0u) D.edits_snp(rl, strand, nSnp, refw, dst);
             else D.edits_indel(pos, rl, strand, nSnp, nDel, nIns, dst, refb, tmpb, lds + CBC_DLDS_TMP, dels, insl);
@@ -1045,9 +1053,9 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
             if (!ok()) continue;
             if (match) { pend_dst = dst; pend_rl = rl; }
             else {
-                D.edit_counts(rl, nSnp, nDel, nIns);
+                nSnp = D.dense_dec_low(D.tab(CBC_LDS_SNPS), L0, 10u, D.snps_n);
                 if (!ok()) continue;
-                if ((nDel | nIns) != 0u) { defer = 2u; continue; }
+                if (nSnp == 0u) { defer = 2u; continue; }        /* three more counts follow: a read with indels */
                 D.edits_snp(rl, strand, nSnp, refw, dst);
                 if (!ok()) continue;
             }

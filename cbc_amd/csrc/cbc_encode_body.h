@@ -744,6 +744,20 @@ struct CbcEnc {
         }
         n = card + W::reduce_add(a);
     }
+    /* dense_code() for a caller that has checked x < 64 and n + step < CBC_RESCALE (the SNP count of an ordinary read): no
+     * table sweep, no rescale at this call site */
+    CBC_MFN void dense_code_low(uint32_t *exc, uint32_t step, uint32_t x, uint32_t &n)
+    {
+        const V32 ln = W::lane();
+        const V32 e = W::load32(exc, ln, ln <= x, 0u);
+        const uint32_t cnt = 1u + W::readlane(e, x);
+        uint32_t lo = x;
+        if (x < 4u) { for (uint32_t s = 0; s < x; s++) lo += W::readlane(e, s); }
+        else lo += W::reduce_add(W::select(ln < x, e, W::splat(0u)));
+        encode(lo, cnt, n);
+        W::write_uni(exc, x, cnt - 1u + step);
+        n += step;
+    }
     CBC_MFN void dense_code(uint32_t *exc, uint32_t card, uint32_t step, uint32_t x, uint32_t &n)
     {
         if (x >= card) { fail(CBC_ST_ASSERT); return; }       /* assert(x < alphabetCard) stream_model.c:62 */
@@ -1192,8 +1206,9 @@ struct CbcEnc {
     /* compress_edits for an imperfect read (read_compression.c:308-600).
      * The packer has already counted the edits (token word 1) and checked that the MD string is
      * consistent with the read, so every MD token becomes exactly one SNP: numSnps = n_md. */
-    /* MODE 0: any record.  MODE 1 / 2: the caller has looked at token word 1 -- a read without (1) / with (2) indels; the
-     * model wavefront codes runs of SNP-only records in a loop that does not contain the CIGAR walks. */
+    /* MODE 0: any record.  MODE 1: the caller has looked at the token header -- no indels, fewer than 64 SNPs, no rescale of
+     * the SNP-count model due; the model wavefront codes runs of such records in a loop that holds neither the CIGAR walks nor
+     * a table sweep.  (MODE 2: indels only.) */
     template <int MODE = 0>
     CBC_MFN void edits(uint32_t pos, uint32_t flw, uint32_t tok_off, const V32 &seqv, const V32 &tokv,
                        const uint32_t *tokb, uint32_t n_tok_blk)
@@ -1230,7 +1245,8 @@ struct CbcEnc {
             if (MODE != 2 && snp_only) {
                 /* SNP-only read (:557-558, :573-593): no insertion can interleave, so the MD tokens are
                  * the SNP list in order -- one loop, no CIGAR walk */
-                E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
+                if (MODE == 1) E.dense_code_low(E.snps_exc, 10u, nSnp, E.snps_n);     /* the caller checked: nSnp < 64 <= L0, no rescale */
+                else E.dense_code(E.snps_exc, L0, 10u, nSnp & 0xffu, E.snps_n);
                 CBC_TSM(12);                                  /* edit counts */
                 uint32_t cum = 0, p = 0, k = 0;
                 while (k < n_md && E.status == CBC_ST_OK) {   /* a full symbol queue (a read with dozens of SNPs) ends the run at its header */
@@ -1521,11 +1537,13 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
                 CBC_TS(1);                                    /* edits of one record */
                 if (E.q_len >= CBC_BATCH_MIN) E.drain();      /* hand over once a few records' symbols are pending */
             };
-            /* runs of SNP-only records (token word 1 = deletions | insertions << 16 is zero) go through a loop whose body
-             * holds no CIGAR walk; a read with indels is coded between two such runs */
+            /* runs of ordinary records -- SNPs only (token word 1 = deletions | insertions << 16 is zero), fewer than 64 of
+             * them, the SNP-count model not about to rescale -- go through a loop whose body holds no CIGAR walk and no table
+             * sweep; any other record is coded between two such runs by the general form */
+            auto ordinary = [&]() { return W::readlane(nx_tok, 1u) == 0u && (W::readlane(nx_tok, 0u) >> 16) < 64u && L0 >= 64u && E.snps_n + 10u < CBC_RESCALE; };
             while (todo && E.status == CBC_ST_OK) {
-                while (todo && E.status == CBC_ST_OK && W::readlane(nx_tok, 1u) == 0u) one(std::integral_constant<int, 1>());
-                if (todo && E.status == CBC_ST_OK) one(std::integral_constant<int, 2>());
+                while (todo && E.status == CBC_ST_OK && ordinary()) one(std::integral_constant<int, 1>());
+                if (todo && E.status == CBC_ST_OK) one(std::integral_constant<int, 0>());
             }
         }
         if (E.status == CBC_ST_OK) { gen_sentinel(); E.seg_end(); }

@@ -258,7 +258,7 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     const uint32_t in_bytes = bd->in_bytes, n_reads = bd->n_reads, blk_bases = bd->reserved[0];
 
     D.status = CBC_ST_OK; D.nsym = 0; D.fail_read = 0; D.cur_read = 0;
-    D.l = 0; D.rng = CBC_M26 + 1u; D.d = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
+    D.l = W::dv(0u); D.rng = W::dv(CBC_M26 + 1u); D.d = W::dv(0u); D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
     D.inb = A.in + in_off;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = 0; D.L0 = 256u; D.evp = nullptr; D.vtab = nullptr;
     D.rname_key = lds + CBC_LLDS_RNKEY; D.rname_exc = lds + CBC_LLDS_RNEXC; D.rn_cap = CBC_CAP_NAME; D.histp = lds + CBC_LLDS_HIST;
@@ -302,7 +302,7 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
         v |= D.regsparse_dec(D.hkey, D.hexc, 24u, 8u, D.hc3, D.hn3, 256u, 1u, CBC_ST_ASSERT);
         return v;
     };
-    if (D.status == CBC_ST_OK) D.d = D.take(26u);
+    if (D.status == CBC_ST_OK) D.d = W::dv(D.take(26u));
     if (D.status == CBC_ST_OK && dec_int() != CBC_LONG_MAGIC) D.fail(CBC_ST_UNSUPPORTED);
     if (D.status == CBC_ST_OK && dec_int() != 8u) D.fail(CBC_ST_UNSUPPORTED);
 

@@ -274,7 +274,7 @@ CBC_FN void cbc_decode_whole(const cbc_dstream_args &A, uint32_t *lds)
     const uint32_t L0 = A.read_length, stride = A.seq_stride;
 
     D.status = CBC_ST_OK; D.nsym = 0; D.fail_read = 0; D.cur_read = 0;
-    D.l = 0; D.rng = CBC_M26 + 1u; D.d = 0; D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
+    D.l = W::dv(0u); D.rng = W::dv(CBC_M26 + 1u); D.d = W::dv(0u); D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
     D.inb = A.in;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = 0; D.L0 = L0; D.evp = nullptr;
     D.rname_key = lds + CBC_SLDS_FIXED; D.rname_exc = D.rname_key + A.cap_name; D.rn_cap = A.cap_name;
@@ -307,7 +307,7 @@ CBC_FN void cbc_decode_whole(const cbc_dstream_args &A, uint32_t *lds)
     D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
     D.p0cnt = W::splat(0u); D.p0over = 0;
 
-    if (D.status == CBC_ST_OK) D.d = D.take(26u);                 /* the tag (alloc_arithmetic_stream :260-263) */
+    if (D.status == CBC_ST_OK) D.d = W::dv(D.take(26u));                 /* the tag (alloc_arithmetic_stream :260-263) */
     for (uint32_t k = 0; k < 34u && D.status == CBC_ST_OK; k++) {  /* header: int(L0), 32 x int(WELL), int(8) */
         uint32_t v = D.regsparse_dec(D.hkey, D.hexc, 0u, 8u, D.hc0, D.hn0, 256u, 1u, CBC_ST_ASSERT) << 24;
         v |= D.regsparse_dec(D.hkey, D.hexc, 8u, 8u, D.hc1, D.hn1, 256u, 1u, CBC_ST_ASSERT) << 16;
@@ -361,8 +361,8 @@ CBC_FN void cbc_decode_whole(const cbc_dstream_args &A, uint32_t *lds)
             uint32_t q0, qn;
             float inv = W::lane_float(W::recip_v(W::splat(D.rl123_n)), 0u);
             W::muldiv2(D.rng, D.rl123_c0, D.rl123_n, D.rl123_n, inv, q0, qn);
-            if (q0 == 0u || D.d >= q0) { D.fail(CBC_ST_ASSERT); break; }        /* another symbol was coded here */
-            D.rng = q0;
+            if (q0 == 0u || W::dv_ge(D.d, q0)) { D.fail(CBC_ST_ASSERT); break; }   /* another symbol was coded here */
+            D.rng = W::dv(q0);
             D.renorm();
         }
         D.rl123_c0 += 10u; D.rl123_n += 10u;

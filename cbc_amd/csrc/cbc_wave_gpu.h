@@ -116,6 +116,25 @@ struct WaveGPU {
     static CBC_FN void mul64(Uv a, uint32_t b, Uv &hi, Uv &lo) { uint64_t p = (uint64_t)a * b; hi = (uint32_t)(p >> 32); lo = (uint32_t)p; }
     static CBC_FN Uv clz_uv(Uv x) { return (uint32_t)__builtin_clz(x); }                  /* x != 0 */
     static CBC_FN void set_lane_uv(V32 &v, uint32_t k, Uv val) { v = lane() == k ? val : v; }
+    /* The decoder's coder state (l, range, tag - l), wave-uniform like the encoder's: in vector registers by default -- the
+     * decode kernel issues 845 scalar against 502 vector instructions per record and the scalar unit is the port its
+     * wavefronts queue on -- or in scalar registers with -DCBC_DEC_STATE_SCALAR (A/B).  Conditions on it go through
+     * dv_ge / dv_gt so that they stay uniform branches (v_cmp -> vcc) instead of divergent control flow. */
+#ifndef CBC_DEC_STATE_SCALAR
+    static CBC_FN Uv dv(uint32_t x) { return uv(x); }
+    static CBC_FN bool dv_ge(Uv x, Uv y) { return __builtin_amdgcn_uicmp(x, y, 35) != 0ull; }              /* 35 = ICMP_UGE */
+    static CBC_FN bool dv_gt(Uv x, Uv y) { return __builtin_amdgcn_uicmp(x, y, 34) != 0ull; }
+    static CBC_FN bool dv_nz(Uv x) { return __builtin_amdgcn_uicmp(x, 0u, 33) != 0ull; }                   /* 33 = ICMP_NE */
+    static CBC_FN uint32_t dv_scalar(Uv x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    static CBC_FN V32 dvv(Uv x) { return x; }
+#else
+    static CBC_FN Uv dv(uint32_t x) { return x; }
+    static CBC_FN bool dv_ge(Uv x, Uv y) { return x >= y; }
+    static CBC_FN bool dv_gt(Uv x, Uv y) { return x > y; }
+    static CBC_FN bool dv_nz(Uv x) { return x != 0u; }
+    static CBC_FN uint32_t dv_scalar(Uv x) { return x; }
+    static CBC_FN V32 dvv(Uv x) { return x; }
+#endif
     /* the hand-off counters in LDS: a real ds_read per poll (acquire), a store ordered after the wave's
      * earlier LDS traffic (release), and a short sleep between polls so a waiting wave leaves the issue
      * slots to the others */

@@ -98,6 +98,12 @@ struct WaveEmu {
     static uint32_t uv_scalar(Uv x) { return x; }
     static Uv uv_opaque(Uv x) { return x; }
     static bool uv_ge(Uv x, uint32_t c) { return x >= c; }
+    static Uv dv(uint32_t x) { return x; }
+    static bool dv_ge(Uv x, Uv y) { return x >= y; }
+    static bool dv_gt(Uv x, Uv y) { return x > y; }
+    static bool dv_nz(Uv x) { return x != 0u; }
+    static uint32_t dv_scalar(Uv x) { return x; }
+    static V32 dvv(Uv x) { return splat(x); }
     static bool uv_gt(Uv x, Uv y) { return x > y; }
     static void mul64(Uv a, uint32_t b, Uv &hi, Uv &lo) { uint64_t p = (uint64_t)a * b; hi = (uint32_t)(p >> 32); lo = (uint32_t)p; }
     static Uv clz_uv(Uv x) { return clz32(x); }
