@@ -626,8 +626,9 @@ struct CbcDec {
         V32 ln = W::lane();
         uint32_t *bloom = tab(CBC_LDS_BLOOM), *ev = var_ev_p();
         const uint32_t strand1 = ctx & 1u;
-        const bool p0class = ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u;   /* 255 is the unused-half marker */
-        bool to_global = !p0class;
+        /* flags as 0 / 1 words, not bool: a bool that lives across blocks is kept as a 64-bit lane mask */
+        const uint32_t p0class = (((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u) ? 1u : 0u;   /* 255 is the unused-half marker */
+        uint32_t to_global = p0class ^ 1u;
         V32 e0 = W::splat(0u), e1 = W::splat(0u), e2 = W::splat(0u), e3 = W::splat(0u);
         uint32_t m = 0;
         const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);
@@ -653,10 +654,10 @@ struct CbcDec {
                     m++;
                 }
             }
-            if (have >= CBC_P0_CAP) to_global = true;
+            if (have >= CBC_P0_CAP) to_global = 1u;
         }
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
-        if (to_global || ((p0over >> bkt) & 1u)) {
+        if ((to_global | ((p0over >> bkt) & 1u)) != 0u) {
             /* the encoder's filter: two hash functions, both words fetched by one LDS instruction */
             h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
             const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);

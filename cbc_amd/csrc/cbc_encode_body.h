@@ -525,20 +525,20 @@ struct CbcEnc {
         /* the entries of the current batch up to its END (found by one ballot) are a counted loop with no way out of
          * its middle; what ends the segment, asks for the next batch or fails is decided between such runs */
         const V32 ln = W::lane();
-        bool done = false;
-        while (!done && status == CBC_ST_OK) {
+        uint32_t done = 0u;                                  /* a word, not a bool: see var_code */
+        while ((done | status) == 0u) {
             if (b_pos == b_len) {
                 if (seen_last) fail(CBC_ST_ASSERT);                            /* stream ended inside a segment */
                 else { pull(); if (b_flags & CBC_BF_GROUP) fail(CBC_ST_ASSERT); }   /* protocol: group mark inside a segment */
             } else {
                 const uint64_t em = W::ballot((b_n == CBC_END_N) & (ln >= b_pos) & (ln < b_len));
                 uint32_t kend = em ? W::ctz64(em) : b_len;
-                const bool bad = b_stop < kend;                                /* zero count / total: stream_model.c:71 */
+                const uint32_t bad = b_stop < kend ? 1u : 0u;                  /* zero count / total: stream_model.c:71 */
                 if (bad) kend = b_stop;
                 for (uint32_t k = b_pos; k < kend; k++)
                     step(W::readlane(b_lo, k), W::readlane(b_hi, k), W::readlane(b_n, k), W::readlane(b_fl, k), W::readlane(b_fh, k));
                 if (bad) fail(CBC_ST_ASSERT);
-                else if (em) { b_pos = kend + 1u; done = true; }
+                else if (em) { b_pos = kend + 1u; done = 1u; }
                 else b_pos = kend;
             }
         }
@@ -1130,8 +1130,9 @@ struct CbcEnc {
         V32 ln = W::lane();
         uint32_t cn = 0, clo = 0, ceq = 0;
         const uint32_t key = (ctx << 8) | sym, strand1 = ctx & 1u;
-        const bool p0class = ((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u;   /* 255 is the unused-half marker */
-        bool to_global = !p0class;
+        /* flags as 0 / 1 words, not bool: a bool that lives across blocks is kept as a 64-bit lane mask */
+        const uint32_t p0class = (((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u) ? 1u : 0u;   /* 255 is the unused-half marker */
+        uint32_t to_global = p0class ^ 1u;
         const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);   /* the context's bucket: strand, d & 7 */
         uint32_t have = 0;
         if (p0class) {
@@ -1148,10 +1149,10 @@ struct CbcEnc {
                                                        W::select(e1 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u));
             const uint32_t tot = W::reduce_add(acc);
             cn = tot & 1023u; clo = (tot >> 10) & 1023u; ceq = tot >> 20;
-            if (have >= CBC_P0_CAP) to_global = true;
+            if (have >= CBC_P0_CAP) to_global = 1u;
         }
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
-        if (to_global || ((p0over >> bkt) & 1u)) {
+        if ((to_global | ((p0over >> bkt) & 1u)) != 0u) {
             /* two hash functions, both words fetched by one LDS instruction (lanes 0 and 1) */
             h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
             const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
