@@ -543,6 +543,35 @@ struct CbcEnc {
             }
         }
     }
+    /* ---- the match test runs in the CODER wavefront (it has the idle time at cfg2: stamps in profiles/r02_final_stamps.log)
+     * one group ahead of its coding, and reaches the model wavefront through a mailbox in LDS: ctl[2] = groups posted
+     * (release / acquire like the batch counters), ctl[3] = 1 once the coder refused a group, ctl[4..7] = two slots of
+     * (mask lo, mask hi).  Two slots are enough: the mask of group g + 2 is posted when the coder begins group g + 1, i.e.
+     * after it has coded everything the model wavefront produced for group g, which the model wavefront did after reading
+     * mask g.  No wait cycle: the model wavefront hands over all pending symbols before it waits for a mask, and the coder
+     * posts mask g + 1 before it waits for anything of group g. */
+    CBC_MFN void post_group(uint32_t g, uint64_t neq, uint32_t refused)
+    {
+        W::write_uni(ctl, 4u + 2u * (g & 1u), (uint32_t)neq);
+        W::write_uni(ctl, 5u + 2u * (g & 1u), (uint32_t)(neq >> 32));
+        if (refused) W::write_uni(ctl, 3u, 1u);
+        W::ctl_store(ctl + 2, g + 1u);
+    }
+    /* the coder wavefront stops coding (a cap, a full output area, a refused record ...): no more masks will come, and the
+     * model wavefront must not wait for one -- it has to reach its LAST batch, which this wavefront waits for in pull_rest() */
+    CBC_MFN void abort_groups()
+    {
+        W::write_uni(ctl, 3u, 1u);
+        W::ctl_store(ctl + 2, 0xffffffffu);
+    }
+    CBC_MFN bool wait_group(uint32_t g, uint64_t &neq)       /* model wavefront; false: the coder refused the group */
+    {
+        CBC_TSM(5);
+        while (W::ctl_load(ctl + 2) < g + 1u) W::nap();
+        CBC_TSM(6);
+        neq = (uint64_t)W::read_uni(ctl, 4u + 2u * (g & 1u)) | ((uint64_t)W::read_uni(ctl, 5u + 2u * (g & 1u)) << 32);
+        return W::read_uni(ctl, 3u) == 0u;
+    }
     /* coder wave: the next group's match mask (an empty batch flagged GROUP) */
     CBC_MFN uint64_t pull_group()
     {
@@ -1357,7 +1386,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
     E.role = role; E.batch_i = 0; E.batch = lds + CBC_LDS_BATCH; E.ctl = lds + CBC_LDS_CTL;
     if (ROLE != CBC_ROLE_FUSED) {                            /* the only barrier: the counters start at zero for both waves */
-        if (ROLE == CBC_ROLE_MODEL) { W::write_uni(E.ctl, 0u, 0u); W::write_uni(E.ctl, 1u, 0u); }
+        if (ROLE == CBC_ROLE_MODEL) { W::write_uni(E.ctl, 0u, 0u); W::write_uni(E.ctl, 1u, 0u); W::write_uni(E.ctl, 2u, 0u); W::write_uni(E.ctl, 3u, 0u); }
         W::barrier();
     }
     /* the block's out area: [0, payload_cap) payload, [payload_cap, out_cap) its var-event list */
@@ -1504,11 +1533,21 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             V32 r_pos, r_fl, r_seq, r_tok;
             const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
             E.cur_read = c0;
+#ifndef CBC_MATCH_IN_MODEL
+            /* the coder wavefront has validated the group and run the match test (post_group); everything this
+             * wavefront still holds goes over first -- the coder may need it before it can post the next mask */
+            if (E.q_len) E.publish(0u, 0ull);
+            uint64_t neq;
+            if (!E.wait_group(c0 >> 6, neq)) { E.fail(CBC_ST_ASSERT); break; }   /* the coder reports the record */
+            load_group(c0, r_pos, r_fl, r_seq, r_tok, false);
+            CBC_TS(0);                                        /* group loads (+ match test) */
+#else
             if (!load_group(c0, r_pos, r_fl, r_seq, r_tok, true)) break;
             const uint64_t neq = match_group(cn, r_pos, r_fl, r_seq);
             CBC_TS(0);                                        /* group loads + match test */
             if (E.q_len) E.publish(0u, 0ull);                 /* a GROUP batch carries no symbols */
             E.publish(CBC_BF_GROUP, neq);
+#endif
             if (c0 == 0u) { gen_rname(); E.seg_end(); }
             /* software prefetch: bases and tokens of the next imperfect record */
             uint64_t todo = neq;
@@ -1561,6 +1600,21 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     /* the coder wavefront carries the block's serial chain: it goes first at the SIMD's issue port (s_setprio), the
      * model wavefronts that share the SIMD fill the gaps (cfg2 10.26 -> 9.91 ms, profiles/r02_ab_kernels.log run 9) */
     if (!fused) W::prio(CBC_PRIO_CODER);
+#ifndef CBC_MATCH_IN_MODEL
+    /* validate a group and run its match test for both wavefronts; a refused group is posted as such (the model
+     * wavefront then winds up) and fails this wavefront through load_group() */
+    uint64_t neq_ahead = 0;
+    auto look_ahead = [&](uint32_t g0) {
+        V32 a_pos, a_fl, a_seq, a_tok;
+        const uint32_t an = n_reads - g0 < 64u ? n_reads - g0 : 64u;
+        const uint32_t saved = E.cur_read;
+        const bool okg = load_group(g0, a_pos, a_fl, a_seq, a_tok, true);
+        neq_ahead = okg ? match_group(an, a_pos, a_fl, a_seq) : 0ull;
+        E.post_group(g0 >> 6, neq_ahead, okg ? 0u : 1u);
+        if (okg) E.cur_read = saved;
+    };
+    if (!fused && n_reads != 0u && E.status == CBC_ST_OK) look_ahead(0u);
+#endif
     if (E.status == CBC_ST_OK) { if (fused) { gen_header(); E.seg_end(); } else E.seg_consume(); }
     for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
         V32 r_pos, r_fl, r_seq, r_tok;
@@ -1571,8 +1625,14 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
             if (!load_group(c0, r_pos, r_fl, r_seq, r_tok, true)) break;
             neq = match_group(cn, r_pos, r_fl, r_seq);
         } else {
+#ifndef CBC_MATCH_IN_MODEL
+            neq = neq_ahead;                                  /* posted one group ago */
+            if (c0 + 64u < n_reads) look_ahead(c0 + 64u);     /* before anything of this group is waited for */
+            if (E.status != CBC_ST_OK) break;
+#else
             neq = E.pull_group();                             /* the model wave has validated the group */
             if (E.status != CBC_ST_OK) break;
+#endif
             load_group(c0, r_pos, r_fl, r_seq, r_tok, false);
         }
         typename CbcEnc<W>::Fixed F;
@@ -1678,6 +1738,11 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     }
     if (E.status == CBC_ST_OK) { E.flush_recs(); nbytes = E.finish(); }
     if (E.status != CBC_ST_OK) nbytes = 0;
+#ifndef CBC_MATCH_IN_MODEL
+#ifndef CBC_MATCH_NO_ABORT_FOR_TEST
+    if (!fused && E.status != CBC_ST_OK) E.abort_groups();
+#endif
+#endif
     if (!fused) E.pull_rest();
 #if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
     if (payload_cap >= 128u) for (int i = 0; i < 16; i++) {   /* diagnostic build: over the payload start */

@@ -56,12 +56,14 @@ def emu_lib():
     return _emu
 
 
-def emu_encode(pb, two_wave=False):
+def emu_encode(pb, two_wave=False, shrink_block=None):
     """Run the kernel body on the CPU wave emulation.  Returns (payload list, results array).
     two_wave: the model and coder roles of a block as two host threads with the LDS hand-off ring between them."""
     L = emu_lib()
     blocks = pb.blocks.copy()
     total = L.emu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data)
+    if shrink_block is not None:                     # a payload area far too small for the block: the coder stops with OUT_FULL
+        blocks[shrink_block]["reserved"] = 256
     out = np.full(int(total), 0xAA, dtype=np.uint8)
     res = np.zeros(pb.n_blocks, dtype=host.RESULT_DTYPE)
     db = DeviceBatch(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data,

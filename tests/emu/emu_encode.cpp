@@ -46,10 +46,26 @@ int emu_encode_blocks(const cbc_device_batch *b)
  * atomics on the shared table memory, exactly the ordering the kernel asks of LDS. */
 #include <thread>
 #include <atomic>
+#include <cstdlib>
+#include <chrono>
+/* CBC_EMU_JITTER=<seed>: random pauses around every hand-off operation, a different sequence per thread -- explores
+ * interleavings in which one wavefront runs far ahead of the other (tests/test_emu_parity.py) */
+static void emu_jitter()
+{
+    static const char *env = getenv("CBC_EMU_JITTER");
+    if (!env) return;
+    static std::atomic<unsigned> thread_ids{0};
+    static thread_local uint64_t st = 0;
+    if (!st) st = 0x9E3779B97F4A7C15ull * (strtoull(env, NULL, 10) + 1u) + 0xD1B54A32D192ED03ull * (thread_ids.fetch_add(1) + 1u);
+    st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+    const unsigned r = (unsigned)(st >> 40) & 1023u;
+    if (r < 32u) std::this_thread::sleep_for(std::chrono::microseconds(20u * r));      /* now and then a long pause */
+    else if (r < 256u) std::this_thread::yield();
+}
 struct WaveEmu2 : WaveEmu {
-    static uint32_t ctl_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-    static void ctl_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
-    static void nap() { std::this_thread::yield(); }
+    static uint32_t ctl_load(const uint32_t *p) { emu_jitter(); return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+    static void ctl_store(uint32_t *p, uint32_t v) { emu_jitter(); __atomic_store_n(p, v, __ATOMIC_RELEASE); emu_jitter(); }
+    static void nap() { emu_jitter(); std::this_thread::yield(); }
     static void barrier()
     {
         static std::atomic<unsigned> arrived{0};

@@ -145,6 +145,39 @@ def test_kernel_reports_reference_aborts(built):
         oracle.encode(sam2, fa)
 
 
+@pytest.mark.timeout(300)
+def test_two_wavefront_failures_wind_up(built):
+    """The two ways a block fails with both wavefronts running: a model-side assert in the middle of a segment (the model
+    wavefront reports it through its LAST batch) and a record the coder wavefront refuses in its look-ahead (posted through
+    the group mailbox; the model wavefront winds up).  Same status / record as the fused form, no hang, other blocks fine."""
+    fa, sam, rbc, _ = synth.dataset(15, [100000], [300], 100, sub_rate=0.0, indel_frac=0.0)
+    recs = rbc[0][2]
+    r = recs[150]
+    seq = bytearray(r["seq"])
+    seq[10] = ord("A") if seq[10] != ord("A") else ord("C")
+    r["seq"] = bytes(seq)
+    r["md"] = "10%s89" % chr(seq[10])                                  # MD names the READ base: zero-count chars symbol (Q4)
+    r["nm"] = 1
+    pb = host.pack_sam(synth.sam_text(rbc), fa, block_reads=100)
+    _, r1 = blockref.emu_encode(pb)
+    _, r2 = blockref.emu_encode(pb, two_wave=True)
+    assert [int(x) for x in r1["status"]] == [0, 2, 0] == [int(x) for x in r2["status"]]
+    assert int(r1[1]["fail_read"]) == int(r2[1]["fail_read"]) == 50
+    # a record the validation refuses (POS 0) in the second group of a block: found by the coder one group ahead
+    pb = host.pack_sam(sam, fa, block_reads=300)
+    pb.recs["pos"][100] = 0
+    _, r1 = blockref.emu_encode(pb)
+    _, r2 = blockref.emu_encode(pb, two_wave=True)
+    assert int(r1[0]["status"]) == int(r2[0]["status"]) == 2
+    assert int(r1[0]["fail_read"]) == int(r2[0]["fail_read"]) == 100
+    # the CODER wavefront fails on its own (payload area too small, a POS alphabet beyond its cap): it must release the model
+    # wavefront, which would otherwise wait for a match mask that never comes while the coder waits for its LAST batch
+    pb = host.pack_sam(sam, fa, block_reads=300)                       # five groups: the coder fails in the second
+    _, r1 = blockref.emu_encode(pb, shrink_block=0)
+    _, r2 = blockref.emu_encode(pb, two_wave=True, shrink_block=0)
+    assert int(r1[0]["status"]) == int(r2[0]["status"]) != 0
+
+
 def _variable_length_sam(seed, n=1500):
     """Reads of mixed lengths (trimmed reads): exercises the rlength[0] cache switch / write-back."""
     rng = np.random.default_rng(seed)
