@@ -535,8 +535,15 @@ struct CbcEnc {
                 uint32_t kend = em ? W::ctz64(em) : b_len;
                 const uint32_t bad = b_stop < kend ? 1u : 0u;                  /* zero count / total: stream_model.c:71 */
                 if (bad) kend = b_stop;
-                for (uint32_t k = b_pos; k < kend; k++)
-                    step(W::readlane(b_lo, k), W::readlane(b_hi, k), W::readlane(b_n, k), W::readlane(b_fl, k), W::readlane(b_fh, k));
+                for (uint32_t k = b_pos; k < kend; k++) {            /* cum / cum + count / total only in the rare remainder branch */
+                    Uv rec, k3;
+                    code1_lazy(W::readlane(b_fl, k), W::readlane(b_fh, k), [&]() -> uint32_t { return W::readlane(b_lo, k); },
+                               [&]() -> uint32_t { return W::readlane(b_hi, k); }, [&]() -> uint32_t { return W::readlane(b_n, k); }, rec, k3);
+                    W::set_lane_uv(rec_a, rec_n, rec);
+                    W::set_lane_uv(rec_s, rec_n, k3);
+                    nsym++;
+                    if (++rec_n >= CBC_REC_PACK_AT) { pack(rec_a, rec_s, rec_n); rec_n = 0; }
+                }
                 if (bad) fail(CBC_ST_ASSERT);
                 else if (em) { b_pos = kend + 1u; done = 1u; }
                 else b_pos = kend;
