@@ -632,13 +632,14 @@ struct CbcDec {
         V32 e0 = W::splat(0u), e1 = W::splat(0u), e2 = W::splat(0u), e3 = W::splat(0u);
         uint32_t m = 0;
         const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);
-        uint32_t have = 0;
+        uint32_t have = 0, half_word = 0;                      /* the bucket's last word when its upper half is free */
         if (p0class) {
             const uint32_t d = ctx >> 8;
             const uint32_t *arr = tab(CBC_LDS_P0) + bkt * CBC_P0_BUCKET_WORDS;
             have = W::readlane(p0cnt, bkt);
             const uint32_t nw = (have + 1u) >> 1;
             const V32 w = W::load32(arr, ln, ln < nw, 0xffffffffu);       /* the whole bucket in one load */
+            if (have & 1u) half_word = W::readlane(w, have >> 1);         /* saves the read of the read-modify-write below */
             for (uint32_t half = 0; half < 2u; half++) {
                 const V32 e = half ? (w >> 16) : (w & 0xffffu);
                 uint64_t bb = W::ballot((e >> 8) == d);
@@ -699,7 +700,7 @@ struct CbcDec {
         if (!to_global) {
             uint32_t *arr = tab(CBC_LDS_P0) + bkt * CBC_P0_BUCKET_WORDS;
             const uint32_t k16 = ((ctx >> 8) << 8) | x;
-            if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
+            if (have & 1u) W::write_uni(arr, have >> 1, (half_word & 0xffffu) | (k16 << 16));
             else W::write_uni(arr, have >> 1, 0xffff0000u | k16);
             p0cnt = W::select(ln == bkt, p0cnt + 1u, p0cnt);
             return x;

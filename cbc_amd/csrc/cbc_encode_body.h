@@ -1170,7 +1170,7 @@ struct CbcEnc {
         const uint32_t p0class = (((ctx >> 1) & 0x7fu) == 0u && (ctx >> 8) != 255u) ? 1u : 0u;   /* 255 is the unused-half marker */
         uint32_t to_global = p0class ^ 1u;
         const uint32_t bkt = strand1 * 8u + ((ctx >> 8) & 7u);   /* the context's bucket: strand, d & 7 */
-        uint32_t have = 0;
+        uint32_t have = 0, half_word = 0;                      /* the bucket's last word when its upper half is free */
         if (p0class) {
             const uint32_t d = ctx >> 8, key16 = (d << 8) | sym;
             const uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
@@ -1178,6 +1178,7 @@ struct CbcEnc {
             const uint32_t nw = (have + 1u) >> 1;
             /* the whole bucket in one load; an unused upper half holds 0xffff (d = 255 is not in the class) */
             const V32 w = W::load32(arr, ln, ln < nw, 0xffffffffu);
+            if (have & 1u) half_word = W::readlane(w, have >> 1);  /* saves the read of the read-modify-write below */
             const V32 e0 = w & 0xffffu, e1 = w >> 16;
             const V32 acc = W::select((e0 >> 8) == d, W::select((e0 & 0xffu) < sym, W::splat(1u + (1u << 10)), W::splat(1u)) +
                                                        W::select(e0 == key16, W::splat(1u << 20), W::splat(0u)), W::splat(0u)) +
@@ -1220,7 +1221,7 @@ struct CbcEnc {
         if (!to_global) {                                        /* p = 0 context with room in its bucket */
             uint32_t *arr = p0ev + bkt * CBC_P0_BUCKET_WORDS;
             const uint32_t k16 = ((ctx >> 8) << 8) | sym;
-            if (have & 1u) W::write_uni(arr, have >> 1, (W::read_uni(arr, have >> 1) & 0xffffu) | (k16 << 16));
+            if (have & 1u) W::write_uni(arr, have >> 1, (half_word & 0xffffu) | (k16 << 16));
             else W::write_uni(arr, have >> 1, 0xffff0000u | k16);
             p0cnt = W::select(ln == bkt, p0cnt + 1u, p0cnt);
             return;
