@@ -259,7 +259,7 @@ struct CbcEnc {
     V32 small;                              /* match / same_ref / chars lane table            */
     V32 fkey, fexc; uint32_t fcount;        /* flag: sparse, one entry per lane                */
     V32 hkey, hexc; uint32_t hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;   /* codebook ctx 0..3: sparse, 8 lanes each */
-    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_occ, *pos_pre, *var_ev, *bloom, *p0ev;
+    uint32_t *rlen_exc, *snps_exc, *indels_exc, *rname_key, *rname_exc, *pos_val, *pos_occ, *pos_pre, *pos_idx, *var_ev, *bloom, *p0ev;
     uint32_t snps_n, indels_n;
     uint32_t rn_count, rn_cap;               /* contig-name pairs in use / capacity (CBC_CAP_NAME in the block kernels) */
     uint32_t *vtab;                          /* GEN: var excess table in global memory, row = context, L0 words per row */
@@ -1044,13 +1044,17 @@ struct CbcEnc {
         /* -- pos: alphabet index of every delta (entry 0 = escape; pos_val[0] never matches) -- */
         const uint32_t card0 = pos_card;
         V32 kv = zero;
-        {
+        /* deltas below CBC_POS_IDX_WORDS (nearly all: they are gaps between neighbouring reads) find their alphabet index
+         * with one LDS load per lane; 0 there = not registered yet.  Only a group that holds a larger delta walks the alphabet. */
+        const Mask small_dx = live & (dxv < CBC_POS_IDX_WORDS);
+        if (CBC_POS_IDX_WORDS) kv = W::load32(pos_idx, dxv, small_dx, 0u);
+        if (!CBC_POS_IDX_WORDS || W::ballot(live & !small_dx) != 0ull) {
             const uint32_t cb = W::uni(card0);
             for (uint32_t b = 0; b < cb; b += 64u) {
                 const V32 av = W::load32(pos_val, ln + b, (ln + b) < card0, 0xffffffffu);
                 const uint32_t lim = card0 - b < 64u ? card0 - b : 64u;
                 for (uint32_t a = 0; a < lim; a++) kv = W::select(dxv == W::readlane(av, a), W::splat(b + a), kv);
-                if (W::ballot(live & (kv == 0u)) == 0ull) break;
+                if (W::ballot(live & !small_dx & (kv == 0u)) == 0ull) break;
             }
         }
         /* deltas not in the alphabet yet: the first record with each becomes an escape and registers it */
@@ -1068,6 +1072,7 @@ struct CbcEnc {
                 kv = W::select(mv, W::splat(card0 + t), kv);
                 esc |= 1ull << f;
                 W::write_uni(pos_val, card0 + t, v);
+                if (v < CBC_POS_IDX_WORDS) W::write_uni(pos_idx, v, card0 + t);
                 t++;
             }
             pos_card = card0 + t;
@@ -1420,8 +1425,10 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
     E.bloom = lds + CBC_LDS_BLOOM; E.p0ev = lds + CBC_LDS_P0;
     E.pos_val = lds + CBC_LDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = E.pos_occ + A.cap_pos;
+    E.pos_idx = E.pos_pre + A.cap_pos;
     E.cap_pos = A.cap_pos;
     if (ROLE != CBC_ROLE_MODEL) {
+        for (uint32_t b = 0; b < CBC_POS_IDX_WORDS; b += 64u) W::store32(E.pos_idx, ln + b, W::splat(0u), W::all());
         for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
         for (uint32_t b = 0; b < 256u; b += 64u) W::store32(E.rlen_exc, ln + b, W::splat(0u), W::all());
         W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 0u); W::write_uni(E.pos_pre, 0u, 0u);

@@ -22,6 +22,9 @@
 #define CBC_BATCH_SLOTS 2u                         /* encoder hand-off ring depth (power of two; 2 measured as good as 4) */
 #endif
 #define CBC_BATCH_WORDS 200u                       /* 64 lo + 64 cnt + 64 n + {len, flags, status, record, match mask x2} */
+#ifndef CBC_POS_IDX_WORDS
+#define CBC_POS_IDX_WORDS 256u                      /* 0: no index table (A/B) */
+#endif
 #define CBC_RING_WORDS  256u                       /* output bit ring of the coder wave (power of two) */
 /* encoder: tables, hand-off ring, its two counters (8 words), output ring; then 3 x cap_pos */
 #define CBC_PLAN_LDS_FIXED_WORDS (CBC_PLAN_TABLE_WORDS + CBC_BATCH_SLOTS * CBC_BATCH_WORDS + 8u + CBC_RING_WORDS)
@@ -31,7 +34,9 @@
  * only sizes those areas. */
 static inline uint32_t cbc_plan_lds_bytes(const cbc_lds_caps *caps)
 {
-    return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 3u * caps->cap_pos);   /* pos_val, pos_occ, pos_pre */
+    /* pos_val, pos_occ, pos_pre; + the alphabet index of every POS delta below CBC_POS_IDX_WORDS (one LDS load per lane
+     * instead of a walk over the alphabet in fixed_group()) */
+    return 4u * (CBC_PLAN_LDS_FIXED_WORDS + 3u * caps->cap_pos + CBC_POS_IDX_WORDS);
 }
 
 /* decoder: tables, 80 words scratch read + 256 deletion positions, 512 pos_alpha histograms, 256 insertions;
