@@ -37,8 +37,8 @@
 /* CBC_DSTAMP: diagnostic build only (cf. CBC_STAMP in cbc_encode_body.h): per-section s_memtime sums of the decode loop,
  * written over the start of the block's SEQ output -- outputs of such a build are garbage by design. */
 #if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
-#define CBC_DT0() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dt_last) :: "memory"); } while (0)
-#define CBC_DT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); dt_sum[k] += t_ - dt_last; dt_last = t_; } while (0)
+#define CBC_DT0() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(D.dt_last) :: "memory"); } while (0)
+#define CBC_DT(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); D.dt_sum[k] += t_ - D.dt_last; D.dt_last = t_; } while (0)
 #else
 #define CBC_DT0() do {} while (0)
 #define CBC_DT(k) do {} while (0)
@@ -85,6 +85,9 @@ struct CbcDec {
     uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
     V32 p0cnt; uint32_t p0over;
     CbcWin<W> win;
+#if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long dt_last, dt_sum[16];
+#endif
 
     CBC_MFN void fail(uint32_t st) { if (status == CBC_ST_OK) { status = st; fail_read = cur_read; } }
     CBC_MFN uint32_t *tab(uint32_t off) { return lds + off; }
@@ -120,7 +123,9 @@ struct CbcDec {
     {
         if (n == 0u || W::dv_ge(d, rng)) { fail(CBC_ST_ASSERT); return 0u; }   /* gap = t - l + 1: 0 or beyond the range */
         uint64_t p = ((uint64_t)d + 1u) * n - 1u;
-        return W::divq(p, rng);
+        /* back to a scalar register: the state lives in vector registers (W::dv), and a target left there would make the
+         * symbol, the next context and every branch on them divergent in the compiler's eyes */
+        return W::dv_scalar(W::divq(p, rng));
     }
     /* the E1/E2 and E3 shifts of arithmetic_decoder_step (Arithmetic_stream.c:401-454) in closed form and merged into one
      * shift, as in CbcEnc::code_tail.  The state is (l, range, d = tag - l) instead of the reference's (l, u, t): each of
@@ -618,6 +623,7 @@ struct CbcDec {
     }
     CBC_MFN uint32_t var_dec(uint32_t ctx)
     {
+        CbcDec &D = *this; (void)D;                          /* for the diagnostic stamps */
         if (ctx >= CBC_NVARCTX) { fail(CBC_ST_ASSERT); return 0u; }
         if (GEN) return var_dec_dense(ctx);
         /* the two context classes of CbcEnc::var_code: "p = 0" contexts (ctx = d << 8 | strand) keep their 16-bit
@@ -657,6 +663,7 @@ struct CbcDec {
             }
             if (have >= CBC_P0_CAP) to_global = 1u;
         }
+        CBC_DT(11);                                           /* var_dec: class, bucket load, its events */
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
         if ((to_global | ((p0over >> bkt) & 1u)) != 0u) {
             /* the encoder's filter: two hash functions, both words fetched by one LDS instruction */
@@ -690,13 +697,16 @@ struct CbcDec {
                 }
             }
         }
+        CBC_DT(12);                                           /* var_dec: filter, global list */
         uint32_t n = L0 + 10u * m;
         uint32_t tg = target(n), x, lo, cnt;
         if (m == 0u) { x = tg; lo = tg; cnt = 1u; }
         else x = search4(e0, e1, e2, e3, L0, tg, lo, cnt);
         if (status != CBC_ST_OK) return 0u;
         if (x >= L0) { fail(CBC_ST_ASSERT); return 0u; }
+        CBC_DT(13);                                           /* var_dec: target, search */
         step(lo, cnt, n);
+        CBC_DT(14);                                           /* var_dec: step */
         if (!to_global) {
             uint32_t *arr = tab(CBC_LDS_P0) + bkt * CBC_P0_BUCKET_WORDS;
             const uint32_t k16 = ((ctx >> 8) << 8) | x;
@@ -751,8 +761,11 @@ struct CbcDec {
                 V32 w = refw;
                 uint32_t p = 0;
                 for (uint32_t sidx = 0; sidx < nSnp && D.status == CBC_ST_OK; sidx++) {
+                    CBC_DT(7);                                     /* to the next SNP (first: the SNP count, loop entry) */
                     uint32_t dl = D.win_first(p, rl);
+                    CBC_DT(8);                                     /* win_first */
                     uint32_t g = D.var_dec(((((dl << 7) + p) << 1) | strand));        /* failed: 0, and the loop header ends it */
+                    CBC_DT(9);                                     /* var_dec */
                     uint32_t at = p + g;
                     p += g + 1u;
                     D.win_set(p - 1u);
@@ -761,6 +774,7 @@ struct CbcDec {
                     uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(refch) * 8u, 5u, 8u);
                     if (at < rl)
                         w = W::select(ln == (at >> 2), (w & ~(0xffu << shf)) | (cbc_basechar(alt) << shf), w);
+                    CBC_DT(10);                                    /* chars + patch */
                 }
                 if (D.status != CBC_ST_OK) return;
                 W::store32_bytes(dst, bo, w, bo < rl);
@@ -927,8 +941,8 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     V32 refw = W::splat(0u); uint8_t *pend_dst = seqo; uint32_t pend_rl = 0;
     V32 sr_fh = W::splat(0u), t_fh = W::splat(0u);
 #if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long dt_last = 0, dt_sum[16];
-    for (int i = 0; i < 16; i++) dt_sum[i] = 0;
+    D.dt_last = 0;
+    for (int i = 0; i < 16; i++) D.dt_sum[i] = 0;
     CBC_DT0();
 #endif
     /* ---- the record loop ------------------------------------------------------------------------------------------
@@ -1084,7 +1098,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
         }
     }
 #if defined(CBC_DSTAMP) && defined(__HIP_DEVICE_COMPILE__)
-    for (int i = 0; i < 16; i++) { W::write_uni((uint32_t *)seqo, 2 * i, (uint32_t)dt_sum[i]); W::write_uni((uint32_t *)seqo, 2 * i + 1, (uint32_t)(dt_sum[i] >> 32)); }
+    for (int i = 0; i < 16; i++) { W::write_uni((uint32_t *)seqo, 2 * i, (uint32_t)D.dt_sum[i]); W::write_uni((uint32_t *)seqo, 2 * i + 1, (uint32_t)(D.dt_sum[i] >> 32)); }
 #endif
     V32 resv = W::select(ln == 0u, W::splat(D.status == CBC_ST_OK ? n_reads : D.cur_read), W::select(ln == 1u, W::splat(D.status),
                W::select(ln == 2u, W::splat(D.nsym), W::splat(D.fail_read))));

@@ -31,7 +31,7 @@ if os.environ.get('DEC_STAMP'):
     sums=np.zeros(16)
     for b in range(pb.n_blocks):
         o=int(blocks[b]['seq_base']); sums+=allseq[o:o+128].view(np.uint64).astype(np.float64)
-    names=['same_ref(+name)','rlength x4','pos','flag','match','copy/edits rest','record store','snps count','win_first','var_dec','chars+patch']
+    names=['same_ref(+name)','rlength x4','pos','flag','match','edits: after the last SNP / perfect copy','record store','edits: SNP count, to each SNP','win_first','var_dec: events appended','chars+patch','var_dec: class, bucket, events','var_dec: filter, global list','var_dec: target, search','var_dec: step']
     for n_,v in zip(names,sums): print('%-16s %8.0f cycles/read %5.1f%%'%(n_, v/nrec, 100*v/sums.sum()))
     print('total', sums.sum()/nrec)
 else:
