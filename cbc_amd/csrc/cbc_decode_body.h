@@ -30,6 +30,11 @@
  * and the deletion list), then the 4 x 256 pos_alpha byte histograms as u16 pairs and the insertion list */
 #define CBC_DLDS_TMP     CBC_PLAN_TABLE_WORDS          /* 80 words: insertion-free read, bytes      */
 #define CBC_DLDS_DELS    (CBC_PLAN_TABLE_WORDS + 80u)  /* 256: deletion positions (matched coords)  */
+/* The decoder's Bloom filter is its own (a filter only decides whether the list is scanned, never what is decoded): it uses
+ * half of the table's words, the other half holds var_dec's symbol histogram -- the decoder's LDS must stay at 15 KB, a tenth
+ * wavefront does not fit on a CU above that (profiles/r02_ab_kernels.log runs 28-29) */
+#define CBC_DBLOOM_LOG2  (CBC_BLOOM_LOG2 - 1u)
+#define CBC_DLDS_VHIST   (CBC_LDS_BLOOM + CBC_BLOOM_WORDS / 2u)   /* 128: histogram of a bucket's matching events by symbol, u16 x 2 per word */
 #define CBC_DLDS_HIST    (CBC_PLAN_TABLE_WORDS + CBC_PLAN_DLDS_SCRATCH_WORDS)   /* 512: registered POS deltas per byte value, u16 x 2 per word */
 #define CBC_DLDS_INS     (CBC_DLDS_HIST + 512u)        /* 256: (output index << 8) | base char      */
 #define CBC_DLDS_FIXED   CBC_PLAN_DLDS_FIXED_WORDS
@@ -646,20 +651,19 @@ struct CbcDec {
             const uint32_t nw = (have + 1u) >> 1;
             const V32 w = W::load32(arr, ln, ln < nw, 0xffffffffu);       /* the whole bucket in one load */
             if (have & 1u) half_word = W::readlane(w, have >> 1);         /* saves the read of the read-modify-write below */
-            for (uint32_t half = 0; half < 2u; half++) {
-                const V32 e = half ? (w >> 16) : (w & 0xffffu);
-                uint64_t bb = W::ballot((e >> 8) == d);
-                while (bb) {
-                    uint32_t src = W::ctz64(bb); bb &= bb - 1u;
-                    uint32_t kk = W::readlane(e, src) & 0xffu;
-                    Mask hitl = ln == (kk >> 2);
-                    uint32_t sub = kk & 3u;
-                    e0 = W::select(hitl & (sub == 0u), e0 + 10u, e0);
-                    e1 = W::select(hitl & (sub == 1u), e1 + 10u, e1);
-                    e2 = W::select(hitl & (sub == 2u), e2 + 10u, e2);
-                    e3 = W::select(hitl & (sub == 3u), e3 + 10u, e3);
-                    m++;
-                }
+            /* the context's events, by symbol: every matching lane adds its event to a 256-bin u16 histogram in LDS (DS
+             * atomics; the wavefront's DS operations complete in order), read back four bins per lane.  The serial form of
+             * this -- one trip per matching event -- was the decoder's largest single item (profiles/r02_ab_kernels.log). */
+            const V32 ea = w & 0xffffu, eb = w >> 16;
+            const Mask ha = (ea >> 8) == d, hb = (eb >> 8) == d;        /* an unused half holds 0xffff: d = 255 is not in the class */
+            m = W::popc64(W::ballot(ha)) + W::popc64(W::ballot(hb));
+            if (m) {
+                uint32_t *vh = tab(CBC_DLDS_VHIST);
+                W::store32(vh, ln * 2u, W::splat(0u), W::all()); W::store32(vh, ln * 2u + 1u, W::splat(0u), W::all());
+                W::lds_add(vh, (ea & 0xffu) >> 1, W::splat(1u) << ((ea & 1u) * 16u), ha);
+                W::lds_add(vh, (eb & 0xffu) >> 1, W::splat(1u) << ((eb & 1u) * 16u), hb);
+                const V32 c01 = W::load32(vh, ln * 2u, W::all(), 0u), c23 = W::load32(vh, ln * 2u + 1u, W::all(), 0u);
+                e0 = (c01 & 0xffffu) * 10u; e1 = (c01 >> 16) * 10u; e2 = (c23 & 0xffffu) * 10u; e3 = (c23 >> 16) * 10u;
             }
             if (have >= CBC_P0_CAP) to_global = 1u;
         }
@@ -667,7 +671,7 @@ struct CbcDec {
         uint32_t h1 = 0, h2 = 0, bw1 = 0, bw2 = 0, bb1 = 0, bb2 = 0;
         if ((to_global | ((p0over >> bkt) & 1u)) != 0u) {
             /* the encoder's filter: two hash functions, both words fetched by one LDS instruction */
-            h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_BLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_BLOOM_LOG2);
+            h1 = (ctx * 0x9E3779B1u) >> (32u - CBC_DBLOOM_LOG2); h2 = (ctx * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32u - CBC_DBLOOM_LOG2);
             const V32 bwv = W::load32(bloom, W::select(ln == 0u, W::splat(h1 >> 5), W::splat(h2 >> 5)), ln < 2u, 0u);
             bw1 = W::readlane(bwv, 0u); bw2 = W::readlane(bwv, 1u);
             bb1 = 1u << (h1 & 31u); bb2 = 1u << (h2 & 31u);

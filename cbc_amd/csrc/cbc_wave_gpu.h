@@ -98,6 +98,7 @@ struct WaveGPU {
         return q >= 4294967295.0 ? 0xffffffffu : (uint32_t)q;
     }
     /* OR into LDS words: lanes may name the same word (ds_or_b32) */
+    static CBC_FN void lds_add(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) __hip_atomic_fetch_add(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     static CBC_FN void lds_or(uint32_t *p, V32 idx, V32 val, Mask m) { if (m) __hip_atomic_fetch_or(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     static CBC_FN void set_lane(V32 &v, uint32_t k, uint32_t val) { v = lane() == k ? val : v; }
     static CBC_FN V32 bswap_v(V32 x) { return __builtin_bswap32(x); }

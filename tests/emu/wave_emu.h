@@ -87,6 +87,7 @@ struct WaveEmu {
         return r;
     }
     static void lds_or(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[idx.v[i]] |= val.v[i]; }
+    static void lds_add(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[idx.v[i]] += val.v[i]; }
     static void set_lane(V32 &v, uint32_t k, uint32_t val) { if (k >= 64) { emu_oob("set_lane index"); return; } v.v[k] = val; }
     static V32 bswap_v(const V32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = __builtin_bswap32(x.v[i]); return r; }
     static uint32_t ctl_load(const uint32_t *) { emu_oob("hand-off counter read in the fused emulation"); return 0; }
