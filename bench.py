@@ -232,19 +232,31 @@ def run_rank(args):
     gather_list = None
     dec = None
 
-    def encode_once(d=None, lo=None, n=None):
+    # HIP events around the dominant kernel of every timed step, on the stream it is launched on (torch's current stream),
+    # read only after the timed region: no host synchronisation inside it
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def encode_once(d=None, lo=None, n=None, ev=None):
         d, lo, n = (db, b0, my_blocks) if d is None else (d, lo, n)
         if n == 0:
             return
+        if ev is not None:
+            ev[0].record()
         (enc.encode_long_device if long_fmt else enc.encode_device)(d, stream)
+        if ev is not None:
+            ev[1].record()
         enc.compact_device(d_out.data_ptr(), d_blocks.data_ptr() + 64 * lo, d_res.data_ptr() + 16 * lo, n,
                            d_offs.data_ptr(), d_packed.data_ptr(), packed_cap, stream)
 
-    def step():
+    def step(ev=None):
         if args.mode == "decode":
+            if ev is not None:
+                ev[0].record()
             (enc.decode_long_device if long_fmt else enc.decode_device)(dec["db"], stream)
+            if ev is not None:
+                ev[1].record()
             return
-        encode_once()
+        encode_once(ev=ev)
         if world > 1:
             dist.gather(d_packed[:gather_cap].to(cdev), gather_list, dst=0)
 
@@ -338,11 +350,9 @@ def run_rank(args):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(enc.last_kernel_ms())      # HIP events recorded on the launch stream
+    for i in range(args.steps):
+        step(kev[i])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -366,6 +376,7 @@ def run_rank(args):
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = total_bases * args.steps / elapsed / 1e6
+    kernel_ms = [a.elapsed_time(b) for a, b in kev]          # read after the timed region (everything has completed)
     k_ms = float(np.mean(kernel_ms))
     n_tok_mine = int(blocks["n_tok"][b0:b1].sum())
     # per launch, this rank: read + reference bases + 16 B record + ~2 B out; long reads also carry their CIGAR tokens
