@@ -9,8 +9,9 @@ and resident in HBM before the timed region starts.
 
   python bench.py --gpus N ...        launched bare: the parent starts N rank processes of itself
                                       (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything
-                                      touches the GPU, forwards rank 0's JSON line and exits non-zero
-                                      if any rank does
+                                      touches the GPU, supervises them (the first rank that fails ends
+                                      the others), forwards rank 0's JSON line and exits non-zero if any
+                                      rank does
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   also works
 
 --scaling weak (default): every rank codes its own cfg2-sized shard (`--reads` records per GPU, seed +
@@ -20,18 +21,29 @@ for byte against a single-GPU encode of the whole dataset.
 
 Prints ONE JSON line on rank 0 (see the task contract), with extra objects:
   roofline     -- algorithmic bytes (2*L+18 per read) / HIP-event kernel time vs 8 TB/s,
-                  plus `issue`: the instruction-issue picture of the committed SQ counter pass
+                  plus `issue`: the instruction-issue picture of the committed SQ counter pass (nulled
+                  when that pass was taken from other kernel sources than the ones built here)
   cpu_baseline -- CPU legs timed single-threaded on this host on a bounded sample of the same workload
                   (N=1, rank 0 only): the oracle on SAM text (parse included) and the packed-input CPU
-                  port (parse excluded)
+                  port (parse excluded).  The CPU port codes the very blocks the GPU coded and its bytes
+                  are compared with the GPU's: `verified_vs_cpu_port` (the run fails on a mismatch)
+  e2e          -- SURVEY 8d's other two timed regions, measured in the run outside the headline region
+                  (N=1): the host-buffer entry point (PCIe included) and the `cbc` CLI on SAM text
+  rccl         -- N > 1: backend, world size, per-rank device / kernel ms / payload bytes, and the
+                  checksum every rank took of its payload on the device before the gather next to the
+                  one rank 0 recomputed on what the collective delivered (the run fails on a mismatch)
+  cfg4         -- N > 1: BASELINE config 4 (GRCh38-shaped, chromosome-sharded, strong scaling) run
+                  after the headline region through the same exchange, so that one SCALE run reports it
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +51,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CHR1_LEN = 248_956_422          # human chr1-sized contig
+KERNEL_SOURCES = ["cbc_gpu.hip", "cbc_encode_body.h", "cbc_decode_body.h", "cbc_stream_body.h", "cbc_long_body.h",
+                  "cbc_tok_core.h", "cbc_tokenise.h", "cbc_plan.h", "cbc_wave_gpu.h"]
 
 
 def parse_args(argv=None):
@@ -51,8 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--contig-len", type=int, default=CHR1_LEN)
     ap.add_argument("--block-reads", type=int, default=4096)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--scale", type=float, default=0.05,
-                    help="cfg4 only: fraction of GRCh38 (contig lengths and read counts both scaled, coverage stays 30x); 1.0 = 618 M reads")
+    ap.add_argument("--scale", type=float, default=None,
+                    help="cfg4: fraction of GRCh38 (contig lengths and read counts both scaled, coverage stays 30x); 1.0 = 618 M reads. "
+                         "Default 0.05 for --workload cfg4, 0.1 for the cfg4 pass of a multi-GPU run")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5", "cfg4"],
                     help="cfg2 = BASELINE.json's headline (150 bp reads, the reference's format, default); cfg5 = 1 M x 10 kb long "
                          "reads with a 5 %% indel + substitution mix through the long-read format extension (no reference parity "
@@ -61,6 +76,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000,
                     help="records of the same workload timed on one host core by the CPU legs (10 M ~ 11 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg4", action="store_true", help="N > 1: skip the cfg4 pass after the headline region")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the PCIe-inclusive and CLI legs after the headline region")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="records of the CLI leg (SAM text is 360 B per record)")
     ap.add_argument("--mode", default="encode", choices=["encode", "decode"],
                     help="encode = BASELINE.json's metric (default); decode = the mirror kernel on the same workload "
                          "(the payloads are produced by one untimed encode launch and checked to decode to the packed bases)")
@@ -83,8 +101,9 @@ def parse_args(argv=None):
 
 
 def spawn_ranks(args):
-    """`python bench.py --gpus N` launched bare: start N rank processes of this script.  Nothing in this
-    parent imports torch or touches HIP; it only waits, forwards rank 0's stdout and reports failures."""
+    """`python bench.py --gpus N` launched bare: start N rank processes of this script and supervise them.  Nothing in
+    this parent imports torch or touches HIP.  The first rank that exits non-zero ends the others (terminate, then kill):
+    ranks left waiting in a collective would otherwise hold the GPUs until the collective's own timeout."""
     n = args.gpus
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -95,48 +114,76 @@ def spawn_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0)
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None:
+        rcs = [p.poll() for p in procs]
+        for r, rc in enumerate(rcs):
+            if rc is not None and rc != 0:
+                failed = (r, rc)
+                break
+        if all(rc is not None for rc in rcs):
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0])
         sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in bad), file=sys.stderr)
-        return max(1, max(abs(rc) for _, rc in bad) & 0xff or 1)
+    if failed is not None:
+        print("bench.py: rank %d failed with rc %d; the other ranks were stopped" % failed, file=sys.stderr)
+        return max(1, abs(failed[1]) & 0xff or 1)
     return 0
 
 
-def issue_picture(root, tag_glob, kernel_ms, n_recs):
-    """roofline.issue: what the committed SQ counter pass of this same command says about the issue ports
-    (the number that binds here; the HBM fraction does not).  Counter values are per launch, summed over the chip."""
-    import glob
-    cands = sorted(glob.glob(os.path.join(root, "profiles", tag_glob)))
-    try:                                                     # profiles/CURRENT.json names the passes of the committed kernels
-        cur = json.load(open(os.path.join(root, "profiles", "CURRENT.json")))
-        named = os.path.join(root, "profiles", cur["decode_pmc" if "decode" in tag_glob else "encode_pmc"])
-        if os.path.exists(named):
-            cands = [named]
-    except Exception:
-        pass
-    if not cands:
-        return None, None, None
+def kernel_source_sha():
+    """sha256 over the kernel sources libcbc_gpu.so is built from: ties a committed counter pass to a kernel build."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "cbc_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def issue_picture(root, which, kernel_ms, n_recs):
+    """roofline.traffic / roofline.issue: what the committed counter passes of this same command say (HBM bytes per
+    launch; the issue ports, the number that binds here).  PMC counters cannot be read from inside this process, so the
+    passes are files under profiles/ named by profiles/CURRENT.json; a pass stamped with another kernel-source hash than
+    the sources in this tree is stale and reported as null.  Counter values are per launch, summed over the chip."""
     try:
-        pm = json.load(open(cands[-1]))
+        cur = json.load(open(os.path.join(root, "profiles", "CURRENT.json")))
+        path = os.path.join(root, "profiles", cur[which])
+        pm = json.load(open(path))
     except Exception:
         return None, None, None
+    src = os.path.relpath(path, root)
+    if pm.get("kernel_source_sha") != kernel_source_sha():
+        return None, src + " (stale: taken from other kernel sources)", None
     sq = pm.get("SQ_per_launch") or {}
     issue = None
     if sq.get("SQ_INSTS_SALU") and sq.get("SQ_BUSY_CYCLES"):
         n_cu, simd_per_cu = 256, 4
-        # shader cycles of one launch at the 2.4 GHz engine clock; the profile's own kernel time when it carries one
-        kcyc = (pm.get("kernel_ms") or kernel_ms) * 2.4e6
+        # shader cycles of one launch: the pass's own busy-cycle counter where it has one (per XCD-SE average), else
+        # the kernel time at the 2.4 GHz engine clock
+        clock_ghz = pm.get("engine_clock_ghz") or 2.4
+        kcyc = (pm.get("kernel_ms") or kernel_ms) * clock_ghz * 1e6
         salu, valu = sq["SQ_INSTS_SALU"], sq["SQ_INSTS_VALU"]
-        waves = sq.get("SQ_WAVES")
-        issue = {"source": os.path.relpath(cands[-1], root),
+        issue = {"source": src, "engine_clock_ghz": clock_ghz,
                  "salu_per_record": round(salu / n_recs, 1), "valu_per_record": round(valu / n_recs, 1),
                  "lds_per_record": round(sq.get("SQ_INSTS_LDS", 0) / n_recs, 2),
-                 "waves_per_launch": waves}
+                 "waves_per_launch": sq.get("SQ_WAVES")}
         if kcyc:
             # one scalar unit per CU issues one wave-instruction per cycle; a SIMD issues one VALU wave-instruction per
             # 2 cycles in wave64 on 32-wide SIMDs (MI355X_MICROARCH.md)
@@ -145,44 +192,107 @@ def issue_picture(root, tag_glob, kernel_ms, n_recs):
             issue["inst_per_cycle_per_simd"] = round((salu + valu) / (kcyc * n_cu * simd_per_cu), 3)
             if sq.get("SQ_WAVE_CYCLES"):
                 issue["mean_waves_per_simd"] = round(sq["SQ_WAVE_CYCLES"] * 4 / (kcyc * n_cu * simd_per_cu), 2)
-                # where a resident wavefront's cycles go (MI355X_MICROARCH.md, SQ counters): parked on s_waitcnt / s_sleep,
-                # ready but not issued, issuing
                 for key, name in (("SQ_WAIT_ANY", "wave_parked_frac"), ("SQ_WAIT_INST_ANY", "wave_issue_stall_frac"),
                                   ("SQ_ACTIVE_INST_ANY", "wave_issuing_frac")):
                     if sq.get(key):
                         issue[name] = round(sq[key] / sq["SQ_WAVE_CYCLES"], 3)
-    return pm.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], root), issue
+    return pm.get("hbm_bytes_per_launch"), src, issue
 
 
-def run_rank(args):
+class Rank:
+    """What every workload needs of this process: its place in the job, its device, the process group."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world), file=sys.stderr)
+            sys.exit(2)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the cbc hot path has no CPU fallback")
+        ndev = torch.cuda.device_count()
+        self.dev_index = self.local_rank % max(ndev, 1)
+        if args.backend == "nccl" and self.world > ndev:
+            raise SystemExit("bench.py: %d ranks but %d GPUs; RCCL needs one GPU per rank (use --backend gloo to rehearse)"
+                             % (self.world, ndev))
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        self.backend = args.backend
+        self.cdev = self.dev if args.backend == "nccl" else torch.device("cpu")     # where collectives run
+        self.dist = dist
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(backend="gloo")
+        from cbc_amd import gpu
+        self.enc = gpu.Encoder(self.dev_index)
+        self.stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._d_sum = torch.zeros(1, dtype=torch.int64, device=self.dev)
+
+    def device_checksum(self, t, nbytes):
+        """cbc_gpu_checksum_device over the first nbytes of a device tensor (as a signed 64-bit Python int)."""
+        import torch
+        self.enc.checksum_device(t.data_ptr(), int(nbytes), self._d_sum.data_ptr(), self.stream)
+        torch.cuda.current_stream().synchronize()
+        return int(self._d_sum.item())
+
+    def checksum_of(self, t, nbytes):
+        """The same checksum of a tensor wherever it lives (device: the kernel; host: libcbc_host's twin)."""
+        from cbc_amd import host
+        if t.is_cuda:
+            return self.device_checksum(t, nbytes)
+        c = host.checksum64(t[:int(nbytes)].numpy())
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def verify_exchange(self, gather_list, payload_bytes, my_sum, extra):
+        """After the timed region: every rank reports (bytes, checksum taken on its device BEFORE the gather, extras);
+        rank 0 recomputes the checksum on what the last gather delivered.  Returns the per-rank table on rank 0 and
+        raises on every rank when anything differs."""
+        import torch
+        dist = self.dist
+        meta = torch.tensor([int(payload_bytes), int(my_sum)] + [int(x) for x in extra], dtype=torch.int64, device=self.cdev)
+        metas = [torch.zeros_like(meta) for _ in range(self.world)]
+        dist.all_gather(metas, meta)
+        ok, table = True, []
+        if self.rank == 0:
+            for r in range(self.world):
+                nb, want = int(metas[r][0].item()), int(metas[r][1].item())
+                got = self.checksum_of(gather_list[r], nb)
+                table.append({"rank": r, "payload_bytes": nb, "checksum_sent": "%016x" % (want & (2 ** 64 - 1)),
+                              "checksum_received": "%016x" % (got & (2 ** 64 - 1)), "extra": [int(v) for v in metas[r][2:].tolist()]})
+                ok = ok and got == want
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int64, device=self.cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            if self.rank == 0:
+                print("bench.py: the bitstreams rank 0 received differ from what the ranks sent: %r" % (table,), file=sys.stderr)
+            raise SystemExit(3)
+        return table
+
+    def device_table(self):
+        """Per-rank device identity, gathered to every rank (small Python objects)."""
+        import torch
+        p = torch.cuda.get_device_properties(self.dev)
+        me = {"rank": self.rank, "device_index": self.dev_index, "device": torch.cuda.get_device_name(self.dev),
+              "arch": getattr(p, "gcnArchName", None), "pci_bus_id": getattr(p, "pci_bus_id", None),
+              "compute_units": p.multi_processor_count}
+        if self.world == 1:
+            return [me]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, me)
+        return out
+
+
+def run_rank(args, R):
     import numpy as np
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
-
     import torch
-    import torch.distributed as dist
     from cbc_amd import gpu, host, shard
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the cbc hot path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)
-    if args.backend == "nccl" and world > ndev:
-        raise SystemExit("bench.py: %d ranks but %d GPUs; RCCL needs one GPU per rank (use --backend gloo to rehearse)"
-                         % (world, ndev))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collectives run
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend="gloo")
+    dist, rank, world, dev, cdev, enc, stream = R.dist, R.rank, R.world, R.dev, R.cdev, R.enc, R.stream
     strong = args.scaling == "strong" and world > 1
 
     # ---- workload (cfg2 shape), packed on the host, then made resident ----
@@ -194,7 +304,6 @@ def run_rank(args):
     else:
         pb = host.synth(seed, args.contig_len, args.reads, args.read_len, 0.003, 0.02, b"chr1", block_reads=args.block_reads)
     t_gen = time.time() - t0
-    enc = gpu.Encoder(dev_index)
     L = gpu.lib()
     blocks = pb.blocks.copy()
     if long_fmt:
@@ -222,7 +331,6 @@ def run_rank(args):
                                pb.n_recs, caps)
 
     db = batch(b0, b1)
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     my_blocks = b1 - b0
     n_recs = int(blocks["n_reads"][b0:b1].sum())
     n_bases = int(pb.info["n_bases"][b0:b1].sum())
@@ -267,9 +375,11 @@ def run_rank(args):
     if (res["status"] != 0).any():
         bad = int(np.nonzero(res["status"])[0][0])
         raise SystemExit("block %d failed: status %d at record %d" % (b0 + bad, res[bad]["status"], res[bad]["fail_read"]))
-    payload_bytes = int(d_offs[my_blocks].item()) if my_blocks else 0
+    offs_first = d_offs.cpu().numpy().astype(np.uint64)[:my_blocks + 1]
+    payload_bytes = int(offs_first[my_blocks]) if my_blocks else 0
     n_symbols = int(res["n_symbols"].sum())
     first_payload = d_packed[:payload_bytes].clone()       # every later step must reproduce these bytes
+    first_sum = R.device_checksum(d_packed, payload_bytes) if world > 1 else None
     strong_check = None
     if world > 1:
         m = torch.tensor([payload_bytes], dtype=torch.int64, device=cdev)
@@ -298,7 +408,7 @@ def run_rank(args):
     if args.mode == "decode":
         # lay the decode launch out over the compacted payloads that are already resident
         stride = (args.read_len + 3) // 4 * 4
-        offs = d_offs.cpu().numpy().astype(np.uint64)[:my_blocks + 1]
+        offs = offs_first
         dblocks = np.zeros(my_blocks, dtype=host.DEC_BLOCK_DTYPE)
         dblocks["in_off"] = offs[:-1]
         dblocks["in_bytes"] = (offs[1:] - offs[:-1]).astype(np.uint32)
@@ -354,6 +464,7 @@ def run_rank(args):
     for i in range(args.steps):
         step(kev[i])
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t_start
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -368,66 +479,102 @@ def run_rank(args):
     else:
         total_bases, total_recs = n_bases, n_recs
 
+    kernel_ms = [a.elapsed_time(b) for a, b in kev]          # read after the timed region (everything has completed)
+    k_ms = float(np.mean(kernel_ms))
+
     if args.mode == "encode":
         torch.cuda.synchronize()
         now_bytes = int(d_offs[my_blocks].item()) if my_blocks else 0
         if now_bytes != payload_bytes or not torch.equal(d_packed[:payload_bytes], first_payload):
             raise SystemExit("bench.py: the timed launches did not reproduce the first launch's bitstreams")
 
+    rccl = None
+    if world > 1:
+        # the exchange proves itself: checksum of this rank's payload taken on its device vs what rank 0 holds after the
+        # LAST timed gather (decode mode makes no gather inside the steps: one is made here)
+        if args.mode == "decode":
+            dist.gather(d_packed[:gather_cap].to(cdev), gather_list, dst=0)
+        table = R.verify_exchange(gather_list, payload_bytes, first_sum, [int(k_ms * 1000), int(t_local * 1e6 / args.steps), n_recs])
+        devs = R.device_table()
+        if rank == 0:
+            for row, d in zip(table, devs):
+                ex = row.pop("extra")
+                row.update({"device_index": d["device_index"], "device": d["device"], "arch": d["arch"], "pci_bus_id": d["pci_bus_id"],
+                            "kernel_ms": ex[0] / 1000.0, "step_ms_local": ex[1] / 1000.0, "reads": ex[2]})
+            rccl = {"backend": args.backend, "is_rccl": args.backend == "nccl", "world_size": dist.get_world_size(),
+                    "collective": "gather of each rank's compacted bitstreams (padded to %d bytes) to rank 0, once per step" % gather_cap,
+                    "gathered_bytes_per_step": int(sum(r["payload_bytes"] for r in table)),
+                    "padded_bytes_per_step": int(gather_cap) * world,
+                    "checksums_match": True, "ranks": table}
+
     ms_per_step = elapsed * 1e3 / args.steps
     value = total_bases * args.steps / elapsed / 1e6
-    kernel_ms = [a.elapsed_time(b) for a, b in kev]          # read after the timed region (everything has completed)
-    k_ms = float(np.mean(kernel_ms))
     n_tok_mine = int(blocks["n_tok"][b0:b1].sum())
     # per launch, this rank: read + reference bases + 16 B record + ~2 B out; long reads also carry their CIGAR tokens
     alg_bytes = (2 * args.read_len + 18) * n_recs + (4 * n_tok_mine if long_fmt else 0)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
-    # HBM traffic and issue-port counters per launch: PMC counters cannot be read from inside this process; the
-    # committed rocprofv3 passes of this same command (profiles/README.md) are reported for the default workload.
     traffic, traffic_src, issue = None, None, None
-    if args.reads == 10_000_000 and args.read_len == 150 and args.block_reads == 4096 and not strong and not long_fmt:
-        traffic, traffic_src, issue = issue_picture(
-            ROOT, "r*_pmc_hbm.json" if args.mode == "encode" else "r*_decode_pmc.json", k_ms, n_recs)
+    default_shape = args.reads == (1_000_000 if long_fmt else 10_000_000) and args.read_len == (10_000 if long_fmt else 150) \
+        and args.block_reads == (64 if long_fmt else 4096) and not strong
+    if default_shape:
+        traffic, traffic_src, issue = issue_picture(ROOT, ("long_" if long_fmt else "") + args.mode + "_pmc", k_ms, n_recs)
 
     cpu = None
     whole_file_bits = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and long_fmt:
-        from oracle import oracle                            # the format's CPU statement, timed as the reported baseline
-        sample = min(args.cpu_sample_reads, args.reads)
-        spb = host.synth_long(0xCBC00005, args.contig_len, sample, args.read_len, 0.05, b"chrL", block_reads=args.block_reads)
+    verified = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle                            # the checker, also timed as the reported baseline
+        # parse excluded + verification: the CPU port codes the VERY blocks the GPU coded (same packed batch), bounded by
+        # --cpu-sample-reads; its bytes must equal the GPU's compacted payload over those blocks
+        cum = np.cumsum(blocks["n_reads"].astype(np.int64))
+        nb_s = max(1, int(np.searchsorted(cum, min(args.cpu_sample_reads, int(cum[-1])), side="right")))
+        nb_s = min(nb_s, pb.n_blocks)
         t1 = time.perf_counter()
-        cbytes = oracle.cpu_encode_blocks(spb, long_reads=True)
+        cflat, coffs, cres = oracle.cpu_encode_blocks(pb, blocks=None if nb_s == pb.n_blocks else range(nb_s), return_flat=True,
+                                                      long_reads=long_fmt)
         t_blk = time.perf_counter() - t1
-        cpu = {"value": round(spb.n_bases / t_blk / 1e6, 2), "unit": "Mbases/s", "cores": 1, "kind": "port",
-               "sample": "%d reads x %d bp of the same synthetic workload as packed blocks (no text parsing), oracle/cbc_long.c "
-                         "block by block, %.1f s of CPU; the format has no reference implementation" % (sample, args.read_len, t_blk),
-               "host_cpus": os.cpu_count(), "payload_bytes": int(cbytes)}
-        spb.close()
-    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle                            # checker, timed as the reported baseline
-        sample = min(args.cpu_sample_reads, args.reads)
-        spb, sam, fa = host.synth(0xCBC00002, args.contig_len, sample, args.read_len, 0.003, 0.02, b"chr1",
-                                  want_text=True, block_reads=args.block_reads)
-        t1 = time.perf_counter()
-        data, st = oracle.encode(sam, fa, return_stats=True)
-        t_cpu = time.perf_counter() - t1
-        whole_file_bits = round(len(data) * 8.0 / max(st.n_records, 1), 3)
-        cpu = {"value": round(st.n_bases / t_cpu / 1e6, 2), "unit": "Mbases/s", "cores": 1, "kind": "port",
-               "sample": "%d reads x %d bp of the same synthetic workload%s, one whole-file stream, SAM text "
-                         "parsing and FASTA load included, %.1f s of CPU" % (
-                             sample, args.read_len, " (all of it)" if sample == args.reads else "", t_cpu),
-               "host_cpus": os.cpu_count()}
-        del sam, fa, data
-        if hasattr(oracle, "cpu_encode_blocks"):
-            # parse excluded: the same packed blocks the GPU codes, through the CPU port with the C ABI's signature
+        s_recs, s_bases = int(cum[nb_s - 1]), int(pb.info["n_bases"][:nb_s].sum())
+        gbytes = int(offs_first[nb_s])
+        gflat = first_payload[:gbytes].cpu().numpy()
+        verified = bool(int(coffs[-1]) == gbytes and np.array_equal(coffs, offs_first[:nb_s + 1]) and np.array_equal(cflat, gflat)
+                        and (cres["n_symbols"] == res["n_symbols"][:nb_s]).all())
+        if not verified:
+            bad = [b for b in range(nb_s) if int(coffs[b + 1] - coffs[b]) != int(offs_first[b + 1] - offs_first[b])
+                   or not np.array_equal(cflat[int(coffs[b]):int(coffs[b + 1])], gflat[int(offs_first[b]):int(offs_first[b + 1])])]
+            raise SystemExit("bench.py: the GPU's bitstreams differ from the CPU port's on the same blocks (first: %r)" % (bad[:4],))
+        port = {"value": round(s_bases / t_blk / 1e6, 2), "unit": "Mbases/s", "cores": 1,
+                "sample": "the first %d blocks (%d reads) the GPU coded, as packed blocks (no text parsing), block by block on one "
+                          "core, %.1f s; bytes compared with the GPU's" % (nb_s, s_recs, t_blk),
+                "payload_bytes": int(coffs[-1])}
+        if long_fmt:
+            cpu = dict(port, kind="port", host_cpus=os.cpu_count())
+            cpu["sample"] += "; oracle/cbc_long.c (the format has no reference implementation)"
+        else:
+            sample = min(args.cpu_sample_reads, args.reads)
+            spb, sam, fa = host.synth(0xCBC00002, args.contig_len, sample, args.read_len, 0.003, 0.02, b"chr1",
+                                      want_text=True, block_reads=args.block_reads)
             t1 = time.perf_counter()
-            cres = oracle.cpu_encode_blocks(spb)
-            t_blk = time.perf_counter() - t1
-            cpu["parse_excluded"] = {"value": round(spb.n_bases / t_blk / 1e6, 2), "unit": "Mbases/s", "cores": 1,
-                                     "sample": "the same %d reads as packed blocks (no text parsing), block by block, %.1f s" % (sample, t_blk),
-                                     "payload_bytes": int(cres)}
-        spb.close()
+            data, st = oracle.encode(sam, fa, return_stats=True)
+            t_cpu = time.perf_counter() - t1
+            whole_file_bits = round(len(data) * 8.0 / max(st.n_records, 1), 3)
+            cpu = {"value": round(st.n_bases / t_cpu / 1e6, 2), "unit": "Mbases/s", "cores": 1, "kind": "port",
+                   "sample": "%d reads x %d bp of the same synthetic workload%s, one whole-file stream, SAM text "
+                             "parsing and FASTA load included, %.1f s of CPU" % (
+                                 sample, args.read_len, " (all of it)" if sample == args.reads else "", t_cpu),
+                   "host_cpus": os.cpu_count(), "parse_excluded": port}
+            del sam, fa, data
+            spb.close()
+
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e and not long_fmt and args.mode == "encode":
+        e2e = e2e_legs(args, enc, pb, first_payload, offs_first)
+
+    cfg4 = None
+    if world > 1 and not args.no_cfg4 and not long_fmt and args.mode == "encode":
+        del d_recs, d_seq, d_tok, d_out, d_packed, first_payload
+        torch.cuda.empty_cache()
+        cfg4 = cfg4_pass(args, R, args.scale if args.scale is not None else 0.1)
 
     if rank == 0:
         n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -439,6 +586,7 @@ def run_rank(args):
             "value": round(value, 2), "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "verified_vs_cpu_port": verified,
             "config": {"workload": "%s: synthetic %d bp SAM, %d reads %s vs a %d bp uniform-ACGT "
                                    "contig, block-parallel %s" % (
                                        "cfg5 (long reads, 5 %% edits)" if long_fmt else {10_000_000: "cfg2", 49_791_284: "cfg3 (30x)"}.get(args.reads, "custom"),
@@ -448,20 +596,90 @@ def run_rank(args):
                        "bits_per_read": round(payload_bytes * 8.0 / max(n_recs, 1), 3),
                        "whole_file_bits_per_read": whole_file_bits,
                        "symbols_per_read": round(n_symbols / max(n_recs, 1), 3),
-                       "parallelism": "blocks sharded over %d GPU(s), gather of bitstreams to rank 0 (%s)" % (world, args.backend),
+                       "parallelism": "one GPU, no collective" if world == 1 else
+                                      "blocks sharded over %d GPUs (one process each), gather of bitstreams to rank 0 (%s)" % (
+                                          world, "RCCL" if args.backend == "nccl" else "gloo rehearsal"),
                        "gathered_equals_single_gpu": strong_check,
-                       "host_pack_seconds": round(t_gen, 1)},
+                       "host_pack_seconds": round(t_gen, 1),
+                       "note": "the one output that is bit-identical to the reference's WHOLE file is the compat stream (cbc -c --compat): "
+                               "one serial arithmetic stream, one wavefront, ~38 Mbases/s (0.17x of one CPU core); the figure here is "
+                               "block mode, each block bit-identical to the reference run on that block alone, at 16.6 vs 12.9 bit/read"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("cbc_long_%s_kernel" % args.mode) if long_fmt else
                                    "cbc_%s_blocks_kernel%s" % (args.mode, "_w6" if args.mode == "encode" and my_blocks > 10 * n_cus else ""),
                          "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
-                         "issue": issue},
+                         "kernel_source_sha": kernel_source_sha(), "issue": issue},
             "cpu_baseline": cpu,
         }
+        if e2e is not None:
+            out["e2e"] = e2e
+        if rccl is not None:
+            out["rccl"] = rccl
+        if cfg4 is not None:
+            out["cfg4"] = cfg4
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+
+
+def e2e_legs(args, enc, pb, first_payload, offs_first):
+    """SURVEY 8d's timed regions (ii) and (iii), measured in this run outside the headline region, N = 1 only.
+    (ii) the host-buffer entry point of the C ABI on the very batch the headline coded: H2D of the packed blocks (bases as
+    2-bit codes), encode, compaction, D2H of the bitstreams -- second call of two, so the context's persistent device
+    buffers and pinned staging exist (the first call's time is reported too); output bytes compared with the headline's.
+    (iii) the `cbc` CLI on SAM text of the same generator (--e2e-reads records): wall time of `cbc -c` incl. text parsing."""
+    import numpy as np
+    from cbc_amd import host
+    out = {}
+    try:
+        enc.upload_reference(pb.ref)
+        codes, runs = host.pack_2bit(pb.seq)
+        want = first_payload.cpu().numpy()
+        times = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            payloads, res, offs, flat = enc.encode_blocks_2bit(pb, codes, runs, want_payload_list=False)
+            times.append(time.perf_counter() - t1)
+            if int(offs[-1]) != int(offs_first[-1]) or not np.array_equal(flat, want):
+                raise SystemExit("bench.py: the host-buffer entry point's bitstreams differ from the device path's")
+        h2d = 16 * pb.n_recs + codes.nbytes + 16 * len(runs) + 4 * pb.n_tok + 64 * pb.n_blocks
+        out.update({"device_gbases_s": round(pb.n_bases / min(times[1:]) / 1e9, 2),
+                    "device_gbases_s_first_call": round(pb.n_bases / times[0] / 1e9, 2),
+                    "device_ms": round(min(times[1:]) * 1e3, 2),
+                    "bytes_h2d_per_read": round(h2d / max(pb.n_recs, 1), 1),
+                    "bytes_d2h_per_read": round((int(offs[-1]) + 24 * pb.n_blocks) / max(pb.n_recs, 1), 2),
+                    "device_what": "cbc_gpu_encode_blocks_2bit on host buffers: H2D (bases as 2-bit codes) + encode + compaction + D2H, "
+                                   "best of the 2nd/3rd call (persistent device buffers and pinned staging exist), bytes == the device path's"})
+    except AttributeError as e:                                # an older library without the entry point
+        out["device_error"] = str(e)
+    exe = os.path.join(ROOT, "cbc_amd", "csrc", "cbc")
+    if os.path.exists(exe) and args.e2e_reads > 0:
+        import tempfile
+        n = min(args.e2e_reads, args.reads)
+        clen = max(int(args.contig_len * (n / args.reads)), 10 * args.read_len)
+        spb, sam, fa = host.synth(0xCBC00002, clen, n, args.read_len, 0.003, 0.02, b"chr1", want_text=True, block_reads=args.block_reads)
+        nb = spb.n_bases
+        spb.close()
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+            open(os.path.join(td, "in.sam"), "wb").write(sam)
+            open(os.path.join(td, "ref.fa"), "wb").write(fa)
+            sam_bytes = len(sam)
+            del sam, fa
+            best, stages = None, None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                r = subprocess.run([exe, "-c", os.path.join(td, "in.sam"), os.path.join(td, "out.cbc"), os.path.join(td, "ref.fa"), "--verbose"],
+                                   capture_output=True, text=True)
+                dt = time.perf_counter() - t1
+                if r.returncode != 0:
+                    out["cli_error"] = (r.stderr or r.stdout)[-300:]
+                    break
+                if best is None or dt < best:
+                    best, stages = dt, [l.strip() for l in (r.stdout + r.stderr).splitlines() if "stage" in l][:12]
+            if best is not None:
+                out.update({"cli_gbases_s": round(nb / best / 1e9, 3), "cli_seconds": round(best, 3), "cli_reads": n,
+                            "cli_sam_bytes": sam_bytes, "cli_stages": stages,
+                            "cli_what": "`cbc -c in.sam out.cbc ref.fa` wall time (process start to exit, files in /dev/shm), best of 2"})
+    return out
 
 
 # GRCh38 primary assembly, chr1..22, X, Y (bases) -- SURVEY.md 8d, config 4
@@ -481,34 +699,27 @@ def assign_largest_first(loads, n_parts):
     return part
 
 
-def run_cfg4(args):
-    """BASELINE config 4: whole GRCh38-shaped genome at 30x, chromosome-sharded.  Every rank generates and codes the
-    contigs it is dealt (no collective on the data path); the one exchange is the gather of the bitstreams to rank 0."""
+def cfg4_workload(scale, read_len):
+    """Contig lengths and read counts of BASELINE config 4 at `scale` of GRCh38 (30x coverage at every scale)."""
+    lens = [max(int(l * scale), 4 * read_len + 1000) for l in GRCH38]
+    reads = [max(int(30 * l / read_len), 1) for l in lens]
+    return lens, reads
+
+
+def cfg4_pass(args, R, scale):
+    """BASELINE config 4: whole GRCh38-shaped genome at 30x, chromosome-sharded (strong scaling: the genome is fixed, the
+    ranks split it).  Every rank generates and codes the contigs it is dealt (no collective on the data path); the one
+    exchange is the gather of the bitstreams to rank 0, checksummed on both sides.  Returns the result dict on rank 0."""
     import numpy as np
     import torch
-    import torch.distributed as dist
     from cbc_amd import gpu, host
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        sys.exit(2)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the cbc hot path has no CPU fallback")
-    ndev = torch.cuda.device_count(); dev_index = local_rank % max(ndev, 1)
-    if args.backend == "nccl" and world > ndev:
-        raise SystemExit("bench.py: %d ranks but %d GPUs" % (world, ndev))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index); cdev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
-    lens = [max(int(l * args.scale), 4 * args.read_len + 1000) for l in GRCH38]
-    reads = [max(int(30 * l / args.read_len), 1) for l in lens]
+    dist, rank, world, dev, cdev, enc, stream = R.dist, R.rank, R.world, R.dev, R.cdev, R.enc, R.stream
+    lens, reads = cfg4_workload(scale, args.read_len)
     part = assign_largest_first(reads, world)
     mine = [c for c in range(24) if part[c] == rank]
-    enc = gpu.Encoder(dev_index); L = gpu.lib()
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = gpu.lib()
     t0 = time.time()
-    res_list, n_bases, n_recs, n_blocks, payload = [], 0, 0, 0, 0
+    res_list, n_bases, n_recs, n_blocks = [], 0, 0, 0
 
     def to_dev(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
@@ -517,15 +728,15 @@ def run_cfg4(args):
         pb = host.synth(0xCBC00004 + c, lens[c], reads[c], args.read_len, 0.003, 0.02, GRCH38_NAMES[c].encode(), block_reads=args.block_reads)
         blocks = pb.blocks.copy()
         scratch = int(L.cbc_gpu_plan_output(blocks.ctypes.data, pb.n_blocks, pb.recs.ctypes.data, pb.tok.ctypes.data))
-        R = {"t": [to_dev(x) for x in (pb.recs, pb.seq, pb.tok, pb.names, blocks, pb.ref)], "nb": pb.n_blocks,
+        C = {"t": [to_dev(x) for x in (pb.recs, pb.seq, pb.tok, pb.names, blocks, pb.ref)], "nb": pb.n_blocks,
              "out": torch.empty(scratch, dtype=torch.uint8, device=dev), "res": torch.full((pb.n_blocks * 16,), 0xff, dtype=torch.uint8, device=dev),
              "offs": torch.zeros(pb.n_blocks + 1, dtype=torch.int64, device=dev), "cap": max(1 << 20, 8 * pb.n_recs)}
-        R["packed"] = torch.empty(R["cap"], dtype=torch.uint8, device=dev)
-        t = R["t"]
-        R["db"] = gpu.DeviceBatch(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), pb.n_blocks,
-                                  t[5].data_ptr(), t[5].numel(), R["out"].data_ptr(), scratch, R["res"].data_ptr(), t[1].numel(),
+        C["packed"] = torch.empty(C["cap"], dtype=torch.uint8, device=dev)
+        t = C["t"]
+        C["db"] = gpu.DeviceBatch(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), pb.n_blocks,
+                                  t[5].data_ptr(), t[5].numel(), C["out"].data_ptr(), scratch, C["res"].data_ptr(), t[1].numel(),
                                   max(pb.n_tok, 1), pb.n_recs, host.LdsCaps(pb.cap_pos, pb.cap_var))
-        res_list.append(R); n_bases += pb.n_bases; n_recs += pb.n_recs; n_blocks += pb.n_blocks
+        res_list.append(C); n_bases += pb.n_bases; n_recs += pb.n_recs; n_blocks += pb.n_blocks
         pb.close()
     t_gen = time.time() - t0
 
@@ -533,35 +744,48 @@ def run_cfg4(args):
     side = [torch.cuda.Stream(device=dev) for _ in range(4)]
     hs = [ctypes.c_void_p(x.cuda_stream) for x in side]
 
-    def step():
-        for i, R in enumerate(res_list):
-            q = hs[i % len(hs)]
-            enc.encode_device(R["db"], q)
-            enc.compact_device(R["out"].data_ptr(), R["t"][4].data_ptr(), R["res"].data_ptr(), R["nb"], R["offs"].data_ptr(),
-                               R["packed"].data_ptr(), R["cap"], q)
-        for x in side:
-            x.synchronize()
-        if world > 1:
-            dist.gather(flat[:gather_cap].to(cdev), gather_list, dst=0)
-
-    flat = torch.zeros(1, dtype=torch.uint8, device=dev); gather_cap = 1; gather_list = None
-    for R in res_list:                                        # first launch: every block must finish
-        enc.encode_device(R["db"], stream)
-        enc.compact_device(R["out"].data_ptr(), R["t"][4].data_ptr(), R["res"].data_ptr(), R["nb"], R["offs"].data_ptr(), R["packed"].data_ptr(), R["cap"], stream)
+    for C in res_list:                                        # first launch: every block must finish
+        enc.encode_device(C["db"], stream)
+        enc.compact_device(C["out"].data_ptr(), C["t"][4].data_ptr(), C["res"].data_ptr(), C["nb"], C["offs"].data_ptr(), C["packed"].data_ptr(), C["cap"], stream)
     torch.cuda.synchronize()
-    for R in res_list:
-        r = R["res"].cpu().numpy().view(host.RESULT_DTYPE)
+    payload = 0
+    for C in res_list:
+        r = C["res"].cpu().numpy().view(host.RESULT_DTYPE)
         if (r["status"] != 0).any():
             raise SystemExit("a block failed: %r" % (r[r["status"] != 0][:1],))
-        payload += int(R["offs"][R["nb"]].item())
-    if world > 1:                                             # the exchange step: this rank's bitstreams (all its contigs) to rank 0
-        flat = torch.cat([R["packed"][:int(R["offs"][R["nb"]].item())] for R in res_list]) if res_list else flat
-        m = torch.tensor([flat.numel()], dtype=torch.int64, device=cdev)
+        C["bytes"] = int(C["offs"][C["nb"]].item())
+        C["at"] = payload
+        payload += C["bytes"]
+    # this rank's bitstreams (all its contigs, contig order) as ONE buffer: what the exchange step sends
+    gather_cap, gather_list = max(payload, 1), None
+    if world > 1:
+        m = torch.tensor([payload], dtype=torch.int64, device=cdev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        gather_cap = int(m.item())
-        flat = torch.cat([flat, torch.zeros(gather_cap - flat.numel(), dtype=torch.uint8, device=dev)])
+        gather_cap = max(int(m.item()), 1)
         if rank == 0:
             gather_list = [torch.empty(gather_cap, dtype=torch.uint8, device=cdev) for _ in range(world)]
+    flat = torch.zeros(gather_cap, dtype=torch.uint8, device=dev)
+
+    def flatten():
+        for C in res_list:
+            flat[C["at"]:C["at"] + C["bytes"]].copy_(C["packed"][:C["bytes"]])
+
+    flatten()
+    first_flat = flat[:payload].clone()
+    first_sum = R.device_checksum(flat, payload)
+
+    def step():
+        for i, C in enumerate(res_list):
+            q = hs[i % len(hs)]
+            enc.encode_device(C["db"], q)
+            enc.compact_device(C["out"].data_ptr(), C["t"][4].data_ptr(), C["res"].data_ptr(), C["nb"], C["offs"].data_ptr(),
+                               C["packed"].data_ptr(), C["cap"], q)
+        for x in side:
+            x.synchronize()
+        flatten()                                             # the per-step concatenation a real exchange needs
+        if world > 1:
+            dist.gather(flat.to(cdev), gather_list, dst=0)
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -569,46 +793,66 @@ def run_cfg4(args):
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    kms = 0.0
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t_start
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    if not torch.equal(flat[:payload], first_flat):
+        raise SystemExit("bench.py (cfg4): the timed launches did not reproduce the first launch's bitstreams")
     tot = torch.tensor([float(n_bases), float(n_recs), float(n_blocks), float(payload), elapsed], dtype=torch.float64, device=cdev)
+    table = None
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         elapsed = float(mx[4].item())
+        table = R.verify_exchange(gather_list, payload, first_sum, [int(t_local * 1e6 / args.steps), n_recs, len(mine)])
     total_bases, total_recs, total_blocks, total_payload = (int(tot[i].item()) for i in range(4))
-    if rank == 0:
-        print(json.dumps({
-            "metric": "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM", "value": round(total_bases * args.steps / elapsed / 1e6, 2),
-            "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "cfg4: 24 contigs of GRCh38's primary lengths x %.3g at 30x coverage, %d bp reads, chromosome-sharded over %d GPU(s) "
-                                   "(whole contigs dealt largest first; every rank generates and codes its own contigs)" % (args.scale, args.read_len, world),
-                       "reads_total": total_recs, "blocks_total": total_blocks, "payload_bytes_total": total_payload,
-                       "bits_per_read": round(total_payload * 8.0 / max(total_recs, 1), 3), "contigs_rank0": [GRCH38_NAMES[c] for c in mine],
-                       "reads_rank0": n_recs, "host_pack_seconds_rank0": round(t_gen, 1),
-                       "parallelism": "contigs sharded over %d GPU(s), gather of bitstreams to rank 0 (%s)" % (world, args.backend)},
-            "roofline": {"bound": "hbm", "achieved": round((2 * args.read_len + 18) * total_recs * args.steps / elapsed / 1e9, 3), "peak": HBM_PEAK_GBS * world,
-                         "unit": "GB/s", "frac": round((2 * args.read_len + 18) * total_recs * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 6),
-                         "traffic": None, "kernel": "cbc_encode_blocks_kernel(_w6) over every contig", "note": "whole-step wall time, all launches of the step"},
-            "cpu_baseline": None}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    alg = (2 * args.read_len + 18) * total_recs * args.steps / elapsed / 1e9
+    out = {
+        "metric": "Mbases/s encoded (bit-exact) on synthetic 150 bp SAM", "value": round(total_bases * args.steps / elapsed / 1e6, 2),
+        "unit": "Mbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "cfg4: 24 contigs of GRCh38's primary lengths x %.3g at 30x coverage, %d bp reads, chromosome-sharded over %d GPU(s) "
+                               "(whole contigs dealt largest first; every rank generates and codes its own contigs)" % (scale, args.read_len, world),
+                   "scale": scale, "reads_total": total_recs, "blocks_total": total_blocks, "payload_bytes_total": total_payload,
+                   "bits_per_read": round(total_payload * 8.0 / max(total_recs, 1), 3), "contigs_rank0": [GRCH38_NAMES[c] for c in mine],
+                   "contig_to_rank": {GRCH38_NAMES[c]: part[c] for c in range(24)},
+                   "reads_rank0": n_recs, "host_pack_seconds_rank0": round(t_gen, 1),
+                   "parallelism": "one GPU, no collective" if world == 1 else
+                                  "contigs sharded over %d GPUs (one process each), gather of bitstreams to rank 0 (%s)" % (
+                                      world, "RCCL" if args.backend == "nccl" else "gloo rehearsal")},
+        "roofline": {"bound": "hbm", "achieved": round(alg, 3), "peak": HBM_PEAK_GBS * world,
+                     "unit": "GB/s", "frac": round(alg / (HBM_PEAK_GBS * world), 6),
+                     "traffic": None, "kernel": "cbc_encode_blocks_kernel(_w6) over every contig", "note": "whole-step wall time, all launches of the step"},
+        "cpu_baseline": None}
+    if table is not None:
+        for row in table:
+            ex = row.pop("extra")
+            row.update({"step_ms_local": ex[0] / 1000.0, "reads": ex[1], "contigs": ex[2]})
+        out["rccl"] = {"backend": args.backend, "is_rccl": args.backend == "nccl", "world_size": dist.get_world_size(),
+                       "gathered_bytes_per_step": total_payload, "padded_bytes_per_step": gather_cap * world,
+                       "checksums_match": True, "ranks": table}
+    return out
 
 
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    R = Rank(args)
     if args.workload == "cfg4":
-        run_cfg4(args)
-        return
-    run_rank(args)
+        out = cfg4_pass(args, R, args.scale if args.scale is not None else 0.05)
+        if R.rank == 0:
+            print(json.dumps(out), flush=True)
+    else:
+        run_rank(args, R)
+    if R.world > 1:
+        R.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -183,6 +183,26 @@ cbc_compact_kernel(const uint8_t *__restrict__ scratch, const cbc_block_desc *__
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) dst[d0 + i] = scratch[so + i];
 }
 
+/* 64-bit checksum of a byte range (cbc_gpu_checksum_device): sum of CBC_CHECKSUM_TERM(i, byte) mod 2^64 -- the sum is
+ * order-free, so lanes, wavefronts and workgroups add their parts in any order and the value is exact */
+__global__ void __launch_bounds__(256)
+cbc_checksum_kernel(const uint8_t *__restrict__ p, uint64_t n, unsigned long long *__restrict__ sum)
+{
+    uint64_t acc = 0;
+    const uint64_t n16 = n / 16;                              /* 16 bytes per lane where the base is aligned */
+    if (((uintptr_t)p & 15) == 0) {
+        for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < n16; w += (uint64_t)gridDim.x * 256) {
+            const uint4 v = ((const uint4 *)p)[w];
+            const uint32_t q[4] = { v.x, v.y, v.z, v.w };
+            for (uint32_t k = 0; k < 16u; k++) acc += CBC_CHECKSUM_TERM(w * 16 + k, (uint8_t)(q[k >> 2] >> (8 * (k & 3))));
+        }
+        for (uint64_t i = n16 * 16 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) acc += CBC_CHECKSUM_TERM(i, p[i]);
+    } else
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) acc += CBC_CHECKSUM_TERM(i, p[i]);
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down((unsigned long long)acc, d, 64);
+    if ((threadIdx.x & 63u) == 0u && acc) atomicAdd(sum, (unsigned long long)acc);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * context
  * ---------------------------------------------------------------------------------------------- */
@@ -336,6 +356,20 @@ API int cbc_gpu_compact_device(cbc_gpu_ctx *ctx, const uint8_t *d_scratch, const
     hipLaunchKernelGGL(cbc_compact_kernel, dim3(n_blocks), dim3(256), 0, s, d_scratch, d_blocks,
                        (const uint64_t *)d_offsets, d_packed, packed_cap, n_blocks);
     HIPCHK(hipGetLastError(), "launch cbc_compact_kernel");
+    return CBC_OK;
+}
+
+API int cbc_gpu_checksum_device(cbc_gpu_ctx *ctx, const uint8_t *d_bytes, uint64_t n, uint64_t *d_sum, void *hip_stream)
+{
+    if (!ctx || !d_sum || (n && !d_bytes)) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t s = hip_stream == CBC_CTX_STREAM ? ctx->stream : (hipStream_t)hip_stream;
+    HIPCHK(hipMemsetAsync(d_sum, 0, 8, s), "memset checksum");
+    if (n == 0) return CBC_OK;
+    const uint64_t want = (n / 16 + 255) / 256 + 1;
+    const unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(cbc_checksum_kernel, dim3(grid), dim3(256), 0, s, d_bytes, n, (unsigned long long *)d_sum);
+    HIPCHK(hipGetLastError(), "launch cbc_checksum_kernel");
     return CBC_OK;
 }
 

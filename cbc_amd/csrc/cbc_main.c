@@ -11,8 +11,9 @@
  * Network / QV modes of the reference (-u -s -r -D -w -t, and -d with user@host:file) are outside
  * the hot path and are refused with a message.  Extra options: --block-reads N, --device N,
  * --threads N, --verbose, and --compat: write the reference's OWN file format (one arithmetic stream for the whole
- * file, compress() src/compression.c:112-170) instead of the block container -- byte-identical to what
- * `program -c 1` (-DDEBUG build) writes and readable by its `-x`; one wavefront codes it, so it is slow.
+ * file, compress() src/compression.c:112-170) instead of the block container -- byte-identical to the in-repo
+ * oracle of compress() (-DDEBUG seed; parity with the upstream binary itself is unpinned);
+ * one wavefront codes it, so it is slow.
  * `cbc -d` recognises either format.  --devices 0,1,...: one context and one host thread per listed device; whole
  * contigs are dealt to them largest first (encode) / contiguous block ranges (decode); the output does not depend
  * on the device count.  --long: the long-read format extension (stream version 3) -- reads up

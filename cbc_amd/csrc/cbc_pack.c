@@ -1448,7 +1448,8 @@ API uint64_t cbc_sam_body_offset(const char *sam, size_t len)
     return off;
 }
 
-typedef struct { uint32_t pos; uint16_t flag, rl; uint32_t nt_ev; uint32_t line; } dev_summary;
+typedef cbc_tok_record_summary dev_summary;             /* the one public struct (include/cbc_gpu.h) */
+_Static_assert(sizeof(cbc_tok_record_summary) == 16, "record summary crosses the device/host seam as 16 bytes");
 
 API int cbc_pack_from_device_tokens(const char *sam, size_t sam_len, const char *fasta, size_t fasta_len, const cbc_pack_opts *opts,
                                     const void *summaries, const uint8_t *rname_change, const uint64_t *change_name_off,
@@ -1589,17 +1590,26 @@ done:
 
 API int cbc_2bit_unpack(const cbc_2bit *p, uint8_t *bases)
 {
-    if (!p || !bases) return CBC_E_ARG;
+    if (!p || !bases || (p->n_bases && !p->codes) || (p->n_runs && !p->runs)) return CBC_E_ARG;
     static const char ACGT[4] = { 'A', 'C', 'G', 'T' };
     for (uint64_t i = 0; i < p->n_bases; i++) bases[i] = (uint8_t)ACGT[(p->codes[i >> 4] >> (2u * (uint32_t)(i & 15u))) & 3u];
     for (uint64_t k = 0; k < p->n_runs; k++) {
-        if (p->runs[k].start + p->runs[k].length > p->n_bases) return CBC_E_INPUT;
+        /* no `start + length`: that sum wraps in u64 for a crafted run (round-2 advisor finding) */
+        if (p->runs[k].start > p->n_bases || p->runs[k].length > p->n_bases - p->runs[k].start) return CBC_E_INPUT;
         memset(bases + p->runs[k].start, (int)p->runs[k].byte, p->runs[k].length);
     }
     return 0;
 }
 
 /* ================================= sharding =============================================== */
+API uint64_t cbc_checksum64(const uint8_t *bytes, uint64_t n)
+{
+    uint64_t acc = 0;
+    if (!bytes) return 0;
+    for (uint64_t i = 0; i < n; i++) acc += CBC_CHECKSUM_TERM(i, bytes[i]);
+    return acc;
+}
+
 API int cbc_assign_contigs(const cbc_packed *p, uint32_t n_parts, uint32_t *part_of_contig)
 {
     if (!p || !part_of_contig || n_parts == 0) return CBC_E_ARG;

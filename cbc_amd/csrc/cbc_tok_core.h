@@ -39,10 +39,7 @@ typedef struct cbc_tok_line {
 } cbc_tok_line;
 
 /* what the host needs of a mapped record to cut blocks (cbc_pack.c place_record) */
-typedef struct cbc_tok_summary {
-    uint32_t pos; uint16_t flag, rl; uint32_t nt_ev;    /* nt | ev << 16 */
-    uint32_t line;                                      /* index of the record's line */
-} cbc_tok_summary;
+typedef cbc_tok_record_summary cbc_tok_summary;         /* the one public 16-byte struct (include/cbc_gpu.h): nt | ev << 16, line index */
 
 CBC_TOK_FN int cbc_tok_isdigit(uint8_t c) { return c >= '0' && c <= '9'; }
 CBC_TOK_FN int cbc_tok_isspace(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }

@@ -163,6 +163,8 @@ def lib():
         L.cbc_gpu_last_kernel_variant.argtypes = [ctypes.c_void_p]
         L.cbc_gpu_synchronize.restype = ctypes.c_int
         L.cbc_gpu_synchronize.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_checksum_device.restype = ctypes.c_int
+        L.cbc_gpu_checksum_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         if L.cbc_gpu_abi_version() != 1:
             raise CbcGpuError("libcbc_gpu.so ABI version mismatch")
         _lib = L
@@ -177,7 +179,8 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_tokenise_sam", "cbc_gpu_tokenise_fetch", "cbc_gpu_tokenise_free", "cbc_gpu_encode_blocks_tokenised",
            "cbc_gpu_upload_reference_2bit", "cbc_gpu_encode_blocks_2bit", "cbc_gpu_decode_blocks_2bit",
            "cbc_gpu_long_plan_output", "cbc_gpu_long_lds_bytes", "cbc_gpu_long_encode_blocks_device",
-           "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks"]
+           "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks",
+           "cbc_gpu_checksum_device"]
 
 
 class Encoder:
@@ -260,7 +263,7 @@ class Encoder:
         self._check(lib().cbc_gpu_upload_reference_2bit(self._ctx, codes.ctypes.data, n_bases, runs.ctypes.data if len(runs) else None,
                                                         len(runs)), "cbc_gpu_upload_reference_2bit")
 
-    def encode_blocks_2bit(self, pb: "host.PackedBatch", codes: np.ndarray, runs: np.ndarray):
+    def encode_blocks_2bit(self, pb: "host.PackedBatch", codes: np.ndarray, runs: np.ndarray, want_payload_list=True):
         """cbc_gpu_encode_blocks with the batch's bases given in 2-bit transport form (host.pack_2bit(pb.seq))."""
         nb = pb.n_blocks
         hb, blocks = self._host_batch(pb)
@@ -274,7 +277,7 @@ class Encoder:
                                               out.ctypes.data, out.size, offs.ctypes.data, res.ctypes.data)
         if rc != 0 and rc != -4:
             self._check(rc, "cbc_gpu_encode_blocks_2bit")
-        return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res, offs, out[:int(offs[nb])]
+        return ([out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)] if want_payload_list else None), res, offs, out[:int(offs[nb])]
 
     def decode_blocks_2bit(self, plan: "host.UnpackPlan", stride=None):
         """cbc_gpu_decode_blocks with the bases coming back as 2-bit rows.  Returns (recs, bases[n, stride] rebuilt on the
@@ -306,10 +309,12 @@ class Encoder:
             bases.reshape(-1)[ei[:k].astype(np.int64)] = ev[:k]
         return recs, bases, res, c.nbytes + 9 * k
 
-    def encode_blocks(self, pb: "host.PackedBatch"):
-        """Host-buffer path.  Returns (list of payload bytes per block, results array, out_offsets)."""
-        nb = pb.n_blocks
-        blocks = pb.blocks.copy()
+    def encode_blocks(self, pb: "host.PackedBatch", which=None):
+        """Host-buffer path.  Returns (list of payload bytes per block, results array, out_offsets, flat payload bytes).
+        which: optional list of block indices (a rank's share of the batch); the descriptors carry absolute bases into the
+        batch's arrays, so any subset is a batch of its own."""
+        blocks = pb.blocks.copy() if which is None else np.ascontiguousarray(pb.blocks[list(which)])
+        nb = len(blocks)
         hb = HostBatch(pb.recs.ctypes.data, pb.n_recs, pb.seq.ctypes.data, len(pb.seq), pb.tok.ctypes.data, pb.n_tok,
                        pb.names.ctypes.data, len(pb.names), blocks.ctypes.data, nb, host.LdsCaps(pb.cap_pos, pb.cap_var))
         total = lib().cbc_gpu_plan_output(blocks.ctypes.data, nb, pb.recs.ctypes.data, pb.tok.ctypes.data)
@@ -436,6 +441,10 @@ class Encoder:
     def compact_device(self, d_scratch, d_blocks, d_results, n_blocks, d_offsets, d_packed, packed_cap, stream=None):
         self._check(lib().cbc_gpu_compact_device(self._ctx, d_scratch, d_blocks, d_results, n_blocks, d_offsets,
                                                  d_packed, packed_cap, stream), "cbc_gpu_compact_device")
+
+    def checksum_device(self, d_bytes, n, d_sum, stream=None):
+        """cbc_gpu_checksum_device: *d_sum (device, 8 bytes) = checksum of n device bytes, asynchronous on `stream`."""
+        self._check(lib().cbc_gpu_checksum_device(self._ctx, d_bytes, n, d_sum, stream), "cbc_gpu_checksum_device")
 
     def last_kernel_ms(self):
         ms = ctypes.c_float()

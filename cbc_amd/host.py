@@ -159,6 +159,8 @@ def lib():
         L.cbc_2bit_free.argtypes = [ctypes.POINTER(TwoBitC)]
         L.cbc_assign_contigs.restype = ctypes.c_int
         L.cbc_assign_contigs.argtypes = [ctypes.POINTER(Packed), ctypes.c_uint32, ctypes.c_void_p]
+        L.cbc_checksum64.restype = ctypes.c_uint64
+        L.cbc_checksum64.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         L.cbc_unpack_plan_create.restype = ctypes.c_int
         L.cbc_unpack_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t,
                                              ctypes.POINTER(ctypes.POINTER(UnpackPlanC)), ctypes.c_char_p, ctypes.c_size_t]
@@ -349,6 +351,12 @@ def unpack_2bit(codes: np.ndarray, runs: np.ndarray, n_bases: int) -> np.ndarray
     if rc != 0:
         raise RuntimeError("cbc_2bit_unpack failed: %d" % rc)
     return out
+
+
+def checksum64(data) -> int:
+    """cbc_checksum64 over a bytes object or a uint8 numpy array (host twin of the device checksum)."""
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else data, dtype=np.uint8)
+    return int(lib().cbc_checksum64(a.ctypes.data if a.size else None, a.size))
 
 
 def pack_sam(sam: bytes, fasta: bytes, **kw) -> PackedBatch:

@@ -186,6 +186,14 @@ int  cbc_gpu_compact_device(cbc_gpu_ctx *ctx, const uint8_t *d_scratch, const cb
                             const cbc_block_result *d_results, uint32_t n_blocks, uint64_t *d_offsets,
                             uint8_t *d_packed, uint64_t packed_cap, void *hip_stream);
 
+/* Checksum of payload bytes, for the exchange step of the multi-GPU path: every rank sums its
+ * compacted payloads on the device before the gather, the receiver sums what arrived (on its device, or on the host with
+ * libcbc_host's cbc_checksum64 -- same value) and compares.  sum over i of (byte[i] + 1) * (((i + 1) * 0x9E3779B97F4A7C15) | 1)
+ * mod 2^64: order-free, so it is exact under any reduction order; position-weighted, so a shifted, truncated, padded or
+ * permuted buffer does not pass.  *d_sum (device, 8 bytes) is valid once `hip_stream` has reached this point. */
+#define CBC_CHECKSUM_TERM(i, byte) ((uint64_t)((uint32_t)(byte) + 1u) * ((((uint64_t)(i) + 1u) * 0x9E3779B97F4A7C15ull) | 1ull))
+int  cbc_gpu_checksum_device(cbc_gpu_ctx *ctx, const uint8_t *d_bytes, uint64_t n, uint64_t *d_sum, void *hip_stream);
+
 /* Fills blocks[b].out_off / out_cap with a worst-case bound (every coded symbol costs at most 20
  * bits because every model total stays below 2^20) and returns the scratch bytes needed. */
 uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks,

@@ -154,6 +154,9 @@ void cbc_2bit_free(cbc_2bit *p);
  * largest first, each to the part with the least records so far (cfg4: chromosome-sharded).  part_of_contig[c]
  * receives the part of contig c.  Deterministic: ties go to the lower part index. */
 int  cbc_assign_contigs(const cbc_packed *p, uint32_t n_parts, uint32_t *part_of_contig /* n_contigs */);
+/* host twin of cbc_gpu_checksum_device (include/cbc_gpu.h, CBC_CHECKSUM_TERM): what the receiving side of the bitstream
+ * gather recomputes when the bytes arrive in host memory */
+uint64_t cbc_checksum64(const uint8_t *bytes, uint64_t n);
 
 /* ---- the reference alone (whole-file stream decode: the stream names contigs only by "next one") ----
  * FASTA text -> upper-cased contig bases, each + CBC_REF_PAD zero bytes, and the contig table in file order

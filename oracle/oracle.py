@@ -96,10 +96,11 @@ def decode(stream: bytes, fasta: bytes, max_out: int = None):
     return out.raw[:n], nr.value
 
 
-def cpu_encode_blocks(pb, blocks=None, return_payloads=False, long_reads=False):
+def cpu_encode_blocks(pb, blocks=None, return_payloads=False, long_reads=False, return_flat=False):
     """The cbc_cpu_* entry points (oracle/cbc_cpu.c): the SAME packed batch the HIP library takes, coded block
     by block on one core.  `blocks` = optional list of block indices (default: all).  Returns the total payload
-    bytes, or (list of payload bytes, results array) with return_payloads."""
+    bytes, or (list of payload bytes, results array) with return_payloads, or (flat payload bytes as a uint8 array,
+    offsets[n + 1], results array) with return_flat -- the layout of the HIP library's compacted output."""
     import numpy as np
     from cbc_amd import gpu, host          # struct layouts only (ctypes mirrors of include/cbc_gpu.h)
     L = lib()
@@ -122,6 +123,8 @@ def cpu_encode_blocks(pb, blocks=None, return_payloads=False, long_reads=False):
         rc = fn(ctx, ctypes.byref(hb), out.ctypes.data, cap, offs.ctypes.data, res.ctypes.data)
         if rc not in (0, -4):
             raise OracleError("cbc_cpu_encode_blocks failed: %d" % rc)
+        if return_flat:
+            return out[:int(offs[nb])].copy(), offs, res
         if not return_payloads:
             return int(offs[nb])
         return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res

@@ -19,6 +19,8 @@ def built():
     gfx950 without a GPU), the cbc program, and the oracle."""
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "cbc_amd", "csrc"), "all"], stdout=subprocess.DEVNULL)
+    # the lock-step emulation too: worker processes of the gloo tests would otherwise each start their own `make` of it
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu"), "libcbc_emu.so"], stdout=subprocess.DEVNULL)
     from oracle import oracle
     oracle.build()
     return True

@@ -1,5 +1,7 @@
 """2-bit transport of bases: host pack / unpack exactness, and -- on the GPU -- the device
 expansion giving the same reference / the same payloads, the device packing giving back the same reads."""
+import os
+
 import numpy as np
 import pytest
 
@@ -87,3 +89,35 @@ def test_gpu_2bit_transport(built):
     want = np.frombuffer(b"".join(ln.split(b"\t")[9] for ln in sam2.splitlines() if not ln.startswith(b"@")), dtype=np.uint8).reshape(-1, 100)
     assert (bases2[:, :100] == want).all() and (want == ord("N")).sum() > 100
     enc.close()
+
+
+def test_wrapped_exception_run_is_rejected_under_asan(built):
+    """cbc_2bit_unpack with a run whose start + length wraps in 64 bits (round-2 advisor finding: that sum passed the old
+    range check and memset wrote out of bounds): an input error, checked on the AddressSanitizer build in a child process;
+    so are a run past the end, a run count without a run array, and a good run right at the end."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "cbc_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "libcbc_host_asan.so"], stdout=subprocess.DEVNULL)
+    code = textwrap.dedent("""
+        import sys, ctypes
+        sys.path.insert(0, %r)
+        import numpy as np
+        from cbc_amd import host
+        host.HOST_LIB = %r
+        n = 1000
+        codes = np.zeros((n + 15) // 16, dtype=np.uint32)
+        out = np.zeros(n, dtype=np.uint8)
+        def unpack(runs, n_runs=None, null_runs=False):
+            r = np.array(runs, dtype=host.RUN_DTYPE)
+            c = host.TwoBitC(codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n,
+                             None if null_runs else ctypes.cast(r.ctypes.data, ctypes.POINTER(host.TwoBitRun)), len(r) if n_runs is None else n_runs)
+            return host.lib().cbc_2bit_unpack(ctypes.byref(c), out.ctypes.data)
+        rcs = [unpack([(0xffffffffffffff00, 0x140, 78)]), unpack([(990, 11, 78)]), unpack([(2000, 1, 78)]),
+               unpack([], n_runs=3, null_runs=True), unpack([(990, 10, 78)])]
+        print("RCS", rcs, bytes(out[988:1000]))
+    """ % (root, os.path.join(csrc, "libcbc_host_asan.so")))
+    env = dict(os.environ, LD_PRELOAD=subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip(),
+               ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert "RCS [-5, -5, -5, -1, 0] b'AANNNNNNNNNN'" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

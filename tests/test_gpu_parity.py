@@ -474,3 +474,124 @@ def test_cli_several_devices(built, tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert (tmp_path / "reads.txt").read_bytes() == expect
+
+
+# ------------------------------------------------------------------ BASELINE config 4 through bench.py's own generator
+def _cfg4_inputs(scale, L=150):
+    """bench.py's cfg4 workload (24 GRCh38-shaped contigs, 30x, the C generator per contig with bench's seeds) as ONE
+    SAM + FASTA pair, packed into one 24-contig batch by the host packer."""
+    import bench
+    lens, reads = bench.cfg4_workload(scale, L)
+    sams, fas = [], []
+    for c in range(24):
+        pb, sam, fa = host.synth(0xCBC00004 + c, lens[c], reads[c], L, 0.003, 0.02, bench.GRCH38_NAMES[c].encode(), want_text=True)
+        pb.close()
+        sams.append(b"".join(l for l in sam.splitlines(keepends=True) if not l.startswith(b"@")))
+        fas.append(fa)
+    return b"".join(sams), b"".join(fas), reads
+
+
+def _cfg4_worker(rank, world, port, q, scale):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as dist
+    import bench
+    from cbc_amd import gpu as G, host as H, shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sam, fa, reads = _cfg4_inputs(scale)
+    pb = H.pack_sam(sam, fa, block_reads=4096)
+    enc = G.Encoder(0)                                        # both ranks share the one GPU of this box
+    enc.upload_reference(pb.ref)
+    ran = []
+
+    def encode_blocks(which):
+        ran.extend(which)
+        if not which:
+            return torch.zeros(0, dtype=torch.uint8), torch.zeros(0, dtype=torch.int64)
+        payloads, res, offs, flat = enc.encode_blocks(pb, which=which)
+        assert (res["status"] == 0).all()
+        return torch.from_numpy(flat.copy()), torch.from_numpy(np.diff(offs.astype(np.int64)))
+
+    mine, allp, alls = shard.encode_sharded_by_contig(dist, pb, encode_blocks, torch.device("cpu"), dst=0)
+    part = [int(x) for x in pb.assign_contigs(world)]
+    ok = ran == mine and part == bench.assign_largest_first(reads, world)
+    if rank == 0:
+        offs = np.concatenate([[0], np.cumsum(alls.numpy())]).astype(np.uint64)
+        blob = pb.container(allp.numpy(), offs)
+        q.put((ok, blob, part, len(mine), pb.n_blocks))
+    enc.close()
+    dist.destroy_process_group()
+
+
+def test_cfg4_contig_sharded_two_ranks_vs_oracle(enc, built):
+    """BASELINE config 4 (24 contigs with GRCh38's primary lengths, 30x, 150 bp) at a small scale through bench.py's own
+    generator and assignment rule: two gloo ranks share this box's GPU, each codes the blocks of the contigs it is dealt
+    (shard.encode_sharded_by_contig, the function `bench.py --workload cfg4` and `cbc --devices` mirror), rank 0 puts the
+    gathered bitstreams back into block order.  Every block == the oracle's packed-input CPU port on that block alone,
+    sampled blocks == the oracle on the block's own SAM text, the container == the one-rank container, and the decode of
+    the gathered container == the SEQ column."""
+    import torch.multiprocessing as mp
+    scale = 0.0007                                            # ~430 k reads, 24 contigs of 174 k .. 33 k bases
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_cfg4_worker, args=(r, 2, port, q, scale)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, blob, part, n_mine, nb = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok and len(set(part)) == 2 and 0 < n_mine < nb and nb >= 100
+    sam, fa, reads = _cfg4_inputs(scale)
+    pb = host.pack_sam(sam, fa, block_reads=4096)
+    assert len(pb.contigs) == 24 and pb.n_blocks == nb and pb.n_recs == sum(reads)
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)         # the one-rank result
+    assert (res["status"] == 0).all()
+    assert blob == pb.container(flat, offs)
+    cp, cres = oracle.cpu_encode_blocks(pb, return_payloads=True)
+    assert payloads == cp and (res["n_symbols"] == cres["n_symbols"]).all()
+    lines = blockref.mapped_sam_lines(sam)
+    for b in sorted(set(range(0, nb, 9)) | {nb - 1}):
+        bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
+        assert payloads[b] == oracle.encode(bsam, bfa), b
+    plan = host.UnpackPlan(blob, fa)
+    enc.upload_reference(plan.ref)
+    recs, seq, dres = enc.decode_blocks(plan)
+    assert (dres["status"] == 0).all()
+    assert plan.text(recs, seq) == b"".join(ln.split(b"\t")[9] + b"\n" for ln in sam.splitlines())
+
+
+def test_paired_end_flag_sets_of_more_than_64_values(enc, built):
+    """A paired-end file with secondary / supplementary / duplicate flags: well over 64 distinct FLAG values.  Block mode
+    keeps at most CBC_CAP_FLAG distinct values per block (the packer cuts on the 65th); every block == the oracle."""
+    flags = tuple(sorted({f | x for f in (65, 81, 83, 97, 99, 113, 129, 145, 147, 161, 163, 177) for x in (0, 256, 1024, 2048, 512, 1280, 2304, 3072, 768)}))
+    assert len(flags) >= 100
+    fa, sam, _, _ = synth.dataset(61, [400000], [9000], 100, sub_rate=0.005, indel_frac=0.05, flags=flags)
+    pb = host.pack_sam(sam, fa, block_reads=4096)
+    assert len({int(f) for f in pb.recs["flag"]}) >= 100 and pb.n_blocks > 3
+    for b in range(pb.n_blocks):
+        r0, n = int(pb.blocks[b]["rec_base"]), int(pb.blocks[b]["n_reads"])
+        assert len({int(f) for f in pb.recs["flag"][r0:r0 + n]}) <= 64
+    _check_blocks(enc, pb, sam)
+    _gpu_roundtrip(enc, pb, sam, fa)
+
+
+def test_checksum_kernel_equals_host_twin(enc, built):
+    """cbc_gpu_checksum_device == cbc_checksum64 (what the two sides of the bitstream gather compute), on aligned and
+    unaligned device ranges, empty input included."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, 5_000_011, dtype=np.uint8)
+    t = torch.from_numpy(a).cuda()
+    d_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for off, n in ((0, len(a)), (0, 4096), (1, 100_000), (7, 17), (16, 0), (3, 1)):
+        enc.checksum_device(t.data_ptr() + off, n, d_sum.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert int(d_sum.item()) & (2 ** 64 - 1) == host.checksum64(a[off:off + n]), (off, n)

@@ -140,4 +140,59 @@ def test_bench_spawns_its_own_ranks(built, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--reads", "1000",
                         "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
-    assert "needs an MI355X" in r.stderr and "rank(s) failed: rank 0" in r.stderr
+    assert "needs an MI355X" in r.stderr and "failed with rc" in r.stderr and "the other ranks were stopped" in r.stderr
+
+
+def test_bench_parent_stops_the_other_ranks_when_one_dies(built, tmp_path):
+    """Supervision of the bare launch (round-2 advisor finding): a rank that dies must not leave the others waiting in
+    a collective until its timeout.  Rank 1 of a fake two-rank job exits 7 at once, rank 0 would sleep for minutes:
+    the parent ends it and returns within seconds."""
+    import subprocess, textwrap, time
+    fake = tmp_path / "fake_bench.py"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    fake.write_text(src.replace("def main():", textwrap.dedent("""
+        def main():
+            if "WORLD_SIZE" in os.environ:
+                if os.environ["RANK"] == "1":
+                    sys.exit(7)
+                print("rank 0 alive", flush=True)
+                time.sleep(600)
+                return
+            return _real_main()
+
+
+        def _real_main():"""), 1).replace('ROOT = os.path.dirname(os.path.abspath(__file__))', 'ROOT = %r' % ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(fake), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert time.time() - t0 < 60
+    assert r.returncode == 7 and "rank 1 failed with rc 7" in r.stderr and "rank 0 alive" in r.stdout
+
+
+def test_checksum_twin_and_cfg4_generator(built):
+    """The exchange checksum (host twin of cbc_gpu_checksum_device): position-weighted, so a shifted / swapped / padded
+    buffer does not pass; and bench.py's cfg4 assignment rule == the C host's cbc_assign_contigs."""
+    import bench
+    from cbc_amd import host
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, 100_003, dtype=np.uint8)
+    c = host.checksum64(a)
+    want = 0
+    for i in range(0, 1000):
+        want = (want + (int(a[i]) + 1) * ((((i + 1) * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)) | 1)) & (2 ** 64 - 1)
+    assert host.checksum64(a[:1000]) == want
+    b = a.copy(); b[[10, 20]] = b[[20, 10]]
+    assert (a[10] == a[20]) or host.checksum64(b) != c
+    assert host.checksum64(np.concatenate([a, np.zeros(1, np.uint8)])) != c            # padding is seen (byte + 1)
+    assert host.checksum64(np.roll(a, 1)) != c and host.checksum64(a[:-1]) != c
+    assert host.checksum64(b"") == 0 and host.checksum64(a.tobytes()) == c
+    # cfg4: the Python rule (bench.py deals contigs before any batch exists) == cbc_assign_contigs on a packed batch
+    import synth
+    lens, reads = bench.cfg4_workload(0.00004, 100)
+    assert len(lens) == 24 and all(r >= 1 for r in reads)
+    small = [max(r // 4, 20) for r in reads[:6]]
+    fa, sam, _, _ = synth.dataset(31, [max(l, 3000) for l in lens[:6]], small, 100, names=bench.GRCH38_NAMES[:6])
+    pb = host.pack_sam(sam, fa, block_reads=64)
+    per_contig = [int(sum(int(pb.info[b]["n_reads"]) for b in range(pb.n_blocks) if int(pb.info[b]["contig"]) == c)) for c in range(6)]
+    for n in (1, 2, 3, 8):
+        assert list(pb.assign_contigs(n)) == bench.assign_largest_first(per_contig, n)

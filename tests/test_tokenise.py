@@ -93,6 +93,14 @@ def test_gpu_tokeniser_equals_host_packer(built, kw, L, br):
     p_dev, r_dev, _, _ = enc.encode_blocks_tokenised(pd, tr)
     p_host, r_host, _, _ = enc.encode_blocks(ph)
     assert (r_dev["status"] == 0).all() and p_dev == p_host
+    # ... and == the oracle run on each block's own SAM text + FASTA window: the device tokeniser against the checker,
+    # not against the product's other packer (the block cuts come from the device-tokenised batch itself)
+    from oracle import oracle
+    lines = blockref.mapped_sam_lines(sam)
+    assert len(lines) == pd.n_recs
+    for b in range(pd.n_blocks):
+        bsam, bfa = blockref.block_alone_inputs(pd, lines, b)
+        assert p_dev[b] == oracle.encode(bsam, bfa), "block %d of the device-tokenised batch differs from the oracle" % b
     enc.tokenise_free(tr)
     enc.close()
 
