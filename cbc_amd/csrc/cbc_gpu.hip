@@ -112,23 +112,24 @@ cbc_expand_2bit_kernel(const uint32_t *__restrict__ codes, uint64_t n_words, uin
 }
 /* exception runs: workgroup = run, threads stride over its bytes */
 __global__ void __launch_bounds__(256)
-cbc_apply_runs_kernel(const cbc_2bit_run_dev *__restrict__ runs, uint64_t n_runs, uint8_t *__restrict__ out, uint64_t n_bases)
+cbc_apply_runs_kernel(const cbc_2bit_run_dev *__restrict__ runs, uint64_t n_runs, uint8_t *__restrict__ out, uint64_t n_bases,
+                      uint64_t lo, uint64_t hi /* only the bytes of [lo, hi): the chunk that has just been expanded */)
 {
     const uint64_t r = blockIdx.x;
     if (r >= n_runs) return;
     const uint64_t s0 = runs[r].start; const uint32_t len = runs[r].length; const uint8_t b = (uint8_t)runs[r].byte;
-    if (s0 > n_bases || len > n_bases - s0) return;
-    for (uint32_t i = threadIdx.x; i < len; i += 256) out[s0 + i] = b;
+    if (s0 > n_bases || len > n_bases - s0 || s0 >= hi || s0 + len <= lo) return;
+    for (uint32_t i = threadIdx.x; i < len; i += 256) if (s0 + i >= lo && s0 + i < hi) out[s0 + i] = b;
 }
 /* pack decoded reads: thread = one 16-base word of one read row; bases past the read's length are not looked at */
 __global__ void __launch_bounds__(256)
-cbc_pack_2bit_kernel(const uint8_t *__restrict__ seq, const cbc_read_rec *__restrict__ recs, uint64_t n_recs, uint32_t stride,
+cbc_pack_2bit_kernel(const uint8_t *__restrict__ seq, const cbc_read_rec *__restrict__ recs, uint64_t rec0, uint64_t rec1, uint32_t stride,
                      uint32_t *__restrict__ codes, uint64_t *__restrict__ exc_idx, uint8_t *__restrict__ exc_val,
                      uint64_t exc_cap, unsigned long long *__restrict__ n_exc)
 {
     const uint32_t row_words = stride >> 4;
-    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (w >= n_recs * row_words) return;
+    const uint64_t w = rec0 * row_words + (uint64_t)blockIdx.x * 256 + threadIdx.x;      /* records [rec0, rec1): one chunk of the decode */
+    if (w >= rec1 * row_words) return;
     const uint64_t r = w / row_words; const uint32_t k0 = (uint32_t)(w % row_words) * 16u;
     const uint32_t rl = recs[r].rlen;
     const uint4 raw = *(const uint4 *)(seq + r * stride + k0);             /* rows are 16-byte aligned (stride % 16 == 0) */
@@ -206,14 +207,26 @@ cbc_checksum_kernel(const uint8_t *__restrict__ p, uint64_t n, unsigned long lon
 /* ------------------------------------------------------------------------------------------------
  * context
  * ---------------------------------------------------------------------------------------------- */
+/* grow-only device buffer owned by the context: the host-buffer entry points keep their device arrays between calls
+ * (a hipMalloc / hipFree pair per array and call cost more than the copies they framed: profiles/r02_final_pcie.log) */
+struct cbc_arena { void *p; uint64_t cap; };
+enum { A_RECS, A_SEQ, A_TOK, A_NAMES, A_BLOCKS, A_OUT, A_RES, A_OFF, A_PACKED, A_CODES, A_RUNS, A_VS, A_IN, A_EXC_I, A_EXC_V, A_CNT, A_COUNT };
+#define CBC_MAX_CHUNKS 8
+#define CBC_N_KSTREAMS 8           /* every chunk's launch on a stream of its own: launches of different chunks share the chip */
+
 struct cbc_gpu_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t s_copy;            /* H2D / D2H of the chunked host-buffer paths */
+    hipStream_t s_k[CBC_N_KSTREAMS];   /* their kernel launches, chunk c on stream c % CBC_N_KSTREAMS */
     hipEvent_t ev0, ev1;
+    hipEvent_t ev_chunk[CBC_MAX_CHUNKS], ev_done[CBC_N_KSTREAMS];
     int have_timing;
     int last_variant;              /* waves per SIMD of the encode build launched last */
     int n_cus;                     /* compute units of the device (block residency decides the kernel build) */
     uint8_t *d_ref; uint64_t ref_bytes;
+    cbc_arena arena[A_COUNT];
+    cbc_e2e_times last_e2e;
     char err[512];
 };
 
@@ -223,6 +236,19 @@ static int set_err(cbc_gpu_ctx *c, int code, const char *what, hipError_t e)
     return code;
 }
 #define HIPCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(ctx, CBC_E_NODEV, what, e_); } while (0)
+
+/* at least `bytes` in arena k; growing frees the old buffer (hipFree waits for the device) */
+static int arena_need(cbc_gpu_ctx *ctx, int k, uint64_t bytes, const char *what)
+{
+    cbc_arena *a = &ctx->arena[k];
+    if (a->p && a->cap >= bytes) return CBC_OK;
+    if (a->p) { (void)hipFree(a->p); a->p = NULL; a->cap = 0; }
+    const uint64_t want = (bytes + (bytes >> 3) + (2ull << 20)) & ~((2ull << 20) - 1);      /* 1/8 headroom, 2 MiB granules */
+    HIPCHK(hipMalloc(&a->p, want), what);
+    a->cap = want;
+    return CBC_OK;
+}
+static double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 API int cbc_gpu_abi_version(void) { return CBC_ABI_VERSION; }
 
@@ -245,9 +271,15 @@ API int cbc_gpu_init(int device_ordinal, cbc_gpu_ctx **out)
     ctx->device = device_ordinal;
     if (hipSetDevice(device_ordinal) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx; return CBC_E_NODEV;
     }
+    for (int k = 0; k < CBC_N_KSTREAMS; k++)
+        if (hipStreamCreateWithFlags(&ctx->s_k[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming) != hipSuccess) { delete ctx; return CBC_E_NODEV; }
+    for (int k = 0; k < CBC_MAX_CHUNKS; k++)
+        if (hipEventCreateWithFlags(&ctx->ev_chunk[k], hipEventDisableTiming) != hipSuccess) { delete ctx; return CBC_E_NODEV; }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) != hipSuccess || cus <= 0) cus = 256;
@@ -269,9 +301,13 @@ API int cbc_gpu_shutdown(cbc_gpu_ctx *ctx)
 {
     if (!ctx) return CBC_E_ARG;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    for (int k = 0; k < A_COUNT; k++) if (ctx->arena[k].p) (void)hipFree(ctx->arena[k].p);
     (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1);
+    for (int k = 0; k < CBC_MAX_CHUNKS; k++) (void)hipEventDestroy(ctx->ev_chunk[k]);
+    for (int k = 0; k < CBC_N_KSTREAMS; k++) { (void)hipEventDestroy(ctx->ev_done[k]); (void)hipStreamDestroy(ctx->s_k[k]); }
+    (void)hipStreamDestroy(ctx->s_copy);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CBC_OK;
@@ -290,13 +326,41 @@ API int cbc_gpu_upload_reference(cbc_gpu_ctx *ctx, const uint8_t *bases, uint64_
     return CBC_OK;
 }
 
+/* the reference as several host pieces laid end to end on the device (a device that owns some contigs uploads just those) */
+API int cbc_gpu_upload_reference_parts(cbc_gpu_ctx *ctx, const uint8_t *const *parts, const uint64_t *bytes, uint32_t n_parts)
+{
+    if (!ctx || !parts || !bytes || n_parts == 0) return CBC_E_ARG;
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_parts; k++) { if (!parts[k] && bytes[k]) return CBC_E_ARG; total += bytes[k]; }
+    if (total == 0) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->d_ref) { (void)hipFree(ctx->d_ref); ctx->d_ref = NULL; ctx->ref_bytes = 0; }
+    HIPCHK(hipMalloc((void **)&ctx->d_ref, total + 16), "hipMalloc(reference)");
+    uint64_t at = 0;
+    for (uint32_t k = 0; k < n_parts; k++) {
+        if (bytes[k]) HIPCHK(hipMemcpyAsync(ctx->d_ref + at, parts[k], bytes[k], hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(reference part)");
+        at += bytes[k];
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_ref + total, 0, 16, ctx->stream), "memset reference pad");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "reference upload");
+    ctx->ref_bytes = total;
+    return CBC_OK;
+}
+
 API uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_read_rec *recs, const uint32_t *tok)
 {
     return cbc_plan_output(blocks, n_blocks, recs, tok);
 }
 API uint32_t cbc_gpu_lds_bytes(const cbc_lds_caps *caps) { return caps ? cbc_plan_lds_bytes(caps) : 0; }
 
+static int encode_blocks_launch(cbc_gpu_ctx *ctx, const cbc_device_batch *b, void *hip_stream, uint64_t resident_blocks);
 API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b, void *hip_stream)
+{
+    return encode_blocks_launch(ctx, b, hip_stream, b ? b->n_blocks : 0);
+}
+/* resident_blocks: how many blocks compete for the chip while this launch runs (the chunked host-buffer path makes several
+ * launches that run side by side): it, not the launch's own grid, decides the register budget of the build */
+static int encode_blocks_launch(cbc_gpu_ctx *ctx, const cbc_device_batch *b, void *hip_stream, uint64_t resident_blocks)
 {
     if (!ctx || !b) return CBC_E_ARG;
     if (b->n_blocks == 0) return CBC_OK;
@@ -315,7 +379,7 @@ API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b
     A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
     A.names_bytes = 0x7fffffffu;   /* names are NUL-terminated; bounded by CBC_CAP_NAME in the kernel */
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
-    if ((uint64_t)b->n_blocks > 10ull * (uint64_t)ctx->n_cus)     /* more blocks than are resident at 5 waves per SIMD */
+    if (resident_blocks > 10ull * (uint64_t)ctx->n_cus)           /* more blocks than are resident at 5 waves per SIMD */
         { hipLaunchKernelGGL(cbc_encode_blocks_kernel_w6, dim3(b->n_blocks), dim3(128), lds, s, A); ctx->last_variant = 6; }
     else
         { hipLaunchKernelGGL(cbc_encode_blocks_kernel, dim3(b->n_blocks), dim3(128), lds, s, A); ctx->last_variant = 5; }
@@ -388,7 +452,7 @@ static int expand_2bit(cbc_gpu_ctx *ctx, const uint32_t *codes, uint64_t n_bases
         HIPCHK(hipMalloc(d_tmp_runs, n_runs * sizeof(cbc_2bit_run_dev)), "hipMalloc 2-bit runs");
         HIPCHK(hipMemcpyAsync(*d_tmp_runs, runs, n_runs * sizeof(cbc_2bit_run_dev), hipMemcpyHostToDevice, ctx->stream), "H2D 2-bit runs");
         hipLaunchKernelGGL(cbc_apply_runs_kernel, dim3((unsigned)n_runs), dim3(256), 0, ctx->stream,
-                           (const cbc_2bit_run_dev *)*d_tmp_runs, n_runs, d_out, n_bases);
+                           (const cbc_2bit_run_dev *)*d_tmp_runs, n_runs, d_out, n_bases, (uint64_t)0, n_bases);
         HIPCHK(hipGetLastError(), "launch cbc_apply_runs_kernel");
     }
     return CBC_OK;
@@ -445,6 +509,17 @@ API int cbc_gpu_encode_blocks_2bit(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, c
     return encode_blocks_impl(ctx, hb, seq_codes, seq_runs, n_seq_runs, out, out_cap, out_offsets, results);
 }
 
+/* The host-buffer encode path (timed region ii), as a pipeline:
+ *   - device arrays are the context's grow-only arenas (no hipMalloc / hipFree per call once they have their size);
+ *   - the batch is cut into up to CBC_MAX_CHUNKS runs of consecutive blocks; chunk c's records, bases (bytes or 2-bit
+ *     codes) and tokens go H2D on the copy stream, an event later its expansion (2-bit) and its encode launch run on
+ *     kernel stream c % 2 -- so chunk c + 1 crosses PCIe while chunk c is being coded, and launches of neighbouring
+ *     chunks share the chip (a block is one serial chain: a launch of few blocks cannot fill it alone);
+ *   - one size scan + compaction over all blocks and one D2H of the compacted bitstreams (2 bytes per read) end it.
+ * Source buffers that are page-locked (cbc_gpu_host_register, or the caller's own hipHostMalloc) are read by DMA at the
+ * link rate; pageable ones go through the runtime's staging, which blocks this thread but not the launches already made.
+ * Needs the blocks' bases in ascending order with rec / seq / tok ranges contiguous from block to block (what the packers
+ * produce); any other descriptor list is sent as one chunk covering the arrays whole. */
 static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const uint32_t *seq_codes, const cbc_2bit_run_dev *seq_runs,
                               uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results,
                               const uint8_t *d_seq_ext, const uint32_t *d_tok_ext, const cbc_tok_record_summary *sums)
@@ -455,73 +530,183 @@ static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const 
     out_offsets[0] = 0;
     if (nb == 0) return CBC_OK;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    const double T0 = wall_now();
+    cbc_e2e_times tm; memset(&tm, 0, sizeof tm);
     const uint64_t scratch = sums ? plan_output_from_summaries(hb->blocks, nb, sums) : cbc_plan_output(hb->blocks, nb, hb->recs, hb->tok);
-    void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_blocks = NULL, *d_out = NULL, *d_res = NULL,
-         *d_off = NULL, *d_packed = NULL, *d_codes = NULL, *d_runs = NULL;
     cbc_block_result *res = NULL;
+    uint8_t *d_compact = NULL;
     int rc = CBC_OK;
     uint64_t total = 0;
     const uint64_t ntok = hb->n_tok ? hb->n_tok : 1;
+    const cbc_block_desc *B = hb->blocks;
 #define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
-    GO(hipMalloc(&d_recs, hb->n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
-    if (!d_seq_ext) GO(hipMalloc(&d_seq, hb->seq_bytes + 16), "hipMalloc seq");
-    if (!d_tok_ext) GO(hipMalloc(&d_tok, ntok * 4 + 16), "hipMalloc tok");
-    GO(hipMalloc(&d_names, hb->names_bytes + 16), "hipMalloc names");
-    GO(hipMalloc(&d_blocks, (uint64_t)nb * sizeof(cbc_block_desc)), "hipMalloc blocks");
-    GO(hipMalloc(&d_out, scratch), "hipMalloc out scratch");
-    GO(hipMalloc(&d_res, (uint64_t)nb * sizeof(cbc_block_result)), "hipMalloc results");
-    GO(hipMalloc(&d_off, ((uint64_t)nb + 1) * 8), "hipMalloc offsets");
-    GO(hipMemcpyAsync(d_recs, hb->recs, hb->n_recs * sizeof(cbc_read_rec), hipMemcpyHostToDevice, ctx->stream), "H2D recs");
-    if (d_seq_ext) { /* already resident */ }
-    else if (seq_codes) {                                      /* 2-bit transport: a quarter of the bytes cross PCIe, expanded here */
-        rc = expand_2bit(ctx, seq_codes, hb->seq_bytes, seq_runs, n_seq_runs, (uint8_t *)d_seq, &d_codes, &d_runs);
-        if (rc) goto done;
-    } else
-    GO(hipMemcpyAsync(d_seq, hb->seq, hb->seq_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D seq");
-    if (!d_tok_ext) GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
-    GO(hipMemcpyAsync(d_names, hb->names, hb->names_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D names");
-    GO(hipMemcpyAsync(d_blocks, hb->blocks, (uint64_t)nb * sizeof(cbc_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
-    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)nb * sizeof(cbc_block_result), ctx->stream), "memset results");
-    {
-        cbc_device_batch db;
-        memset(&db, 0, sizeof db);
-        db.d_recs = (const cbc_read_rec *)d_recs; db.d_seq = d_seq_ext ? d_seq_ext : (const uint8_t *)d_seq; db.d_tok = d_tok_ext ? d_tok_ext : (const uint32_t *)d_tok;
-        db.d_names = (const uint8_t *)d_names; db.d_blocks = (const cbc_block_desc *)d_blocks; db.n_blocks = nb;
-        db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_out = (uint8_t *)d_out; db.out_bytes = scratch;
-        db.d_results = (cbc_block_result *)d_res; db.seq_bytes = hb->seq_bytes; db.n_tok = ntok; db.n_recs = hb->n_recs;
-        db.caps = hb->caps;
-        rc = cbc_gpu_encode_blocks_device(ctx, &db, CBC_CTX_STREAM);
-        if (rc) goto done;
+#define NEED(k, bytes, what) do { rc = arena_need(ctx, k, bytes, what); if (rc) goto done; } while (0)
+    NEED(A_RECS, hb->n_recs * sizeof(cbc_read_rec) + 16, "hipMalloc recs");
+    if (!d_seq_ext) NEED(A_SEQ, hb->seq_bytes + 32, "hipMalloc seq");
+    if (!d_tok_ext) NEED(A_TOK, ntok * 4 + 16, "hipMalloc tok");
+    NEED(A_NAMES, hb->names_bytes + 16, "hipMalloc names");
+    NEED(A_BLOCKS, (uint64_t)nb * sizeof(cbc_block_desc), "hipMalloc blocks");
+    NEED(A_OUT, scratch, "hipMalloc out scratch");
+    NEED(A_RES, (uint64_t)nb * sizeof(cbc_block_result), "hipMalloc results");
+    NEED(A_OFF, ((uint64_t)nb + 1) * 8, "hipMalloc offsets");
+    if (seq_codes && !d_seq_ext) {
+        NEED(A_CODES, ((hb->seq_bytes + 15) / 16) * 4 + 16, "hipMalloc 2-bit codes");
+        if (n_seq_runs) NEED(A_RUNS, n_seq_runs * sizeof(cbc_2bit_run_dev), "hipMalloc 2-bit runs");
+        if (n_seq_runs > 0x7fffffffull) { rc = set_err(ctx, CBC_E_ARG, "2-bit transport: too many runs", hipSuccess); goto done; }
     }
-    GO(hipMalloc(&d_packed, scratch), "hipMalloc packed");
-    rc = cbc_gpu_compact_device(ctx, (const uint8_t *)d_out, (const cbc_block_desc *)d_blocks, (const cbc_block_result *)d_res,
-                                nb, (uint64_t *)d_off, (uint8_t *)d_packed, scratch, CBC_CTX_STREAM);
-    if (rc) goto done;
-    res = results ? results : (cbc_block_result *)malloc((size_t)nb * sizeof(cbc_block_result));
-    if (!res) { rc = CBC_E_NOMEM; goto done; }
-    GO(hipMemcpyAsync(res, d_res, (uint64_t)nb * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
-    GO(hipMemcpyAsync(out_offsets, d_off, ((uint64_t)nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H offsets");
-    GO(hipStreamSynchronize(ctx->stream), "encode kernel");
+    tm.alloc_s = wall_now() - T0;
+    {
+        uint8_t *d_recs = (uint8_t *)ctx->arena[A_RECS].p, *d_seq = d_seq_ext ? NULL : (uint8_t *)ctx->arena[A_SEQ].p;
+        uint32_t *d_tok = d_tok_ext ? NULL : (uint32_t *)ctx->arena[A_TOK].p, *d_codes = (uint32_t *)ctx->arena[A_CODES].p;
+        cbc_block_desc *d_blocks = (cbc_block_desc *)ctx->arena[A_BLOCKS].p;
+        cbc_block_result *d_res = (cbc_block_result *)ctx->arena[A_RES].p;
+        hipStream_t sc = ctx->s_copy;
+        /* chunks: runs of consecutive blocks of about equal H2D volume, when the descriptor list is contiguous */
+        uint32_t n_chunks = 1, cut[CBC_MAX_CHUNKS + 1];
+        bool contiguous = true;
+        for (uint32_t b = 0; b + 1 < nb && contiguous; b++)
+            contiguous = B[b + 1].rec_base == B[b].rec_base + B[b].n_reads && B[b + 1].seq_base >= B[b].seq_base && B[b + 1].tok_base >= B[b].tok_base;
+        contiguous = contiguous && B[0].rec_base + 0 <= hb->n_recs && B[nb - 1].rec_base + B[nb - 1].n_reads <= hb->n_recs
+                     && B[nb - 1].seq_base <= hb->seq_bytes && B[nb - 1].tok_base <= ntok;
+        const uint64_t vol = hb->n_recs * 16 + (d_seq_ext ? 0 : seq_codes ? hb->seq_bytes / 4 : hb->seq_bytes) + (d_tok_ext ? 0 : ntok * 4);
+        if (contiguous && nb >= 512) {
+            /* A block is one serial chain (~5.6 ms for 4096 reads) however few blocks a launch holds, and the link moves
+             * ~57 GB/s: chunks of >= 64 MB and >= 256 blocks, each launched on its own stream the moment it has arrived */
+            uint64_t want = vol / (64ull << 20);
+            if (want > CBC_MAX_CHUNKS) want = CBC_MAX_CHUNKS;
+            if (want > nb / 256) want = nb / 256;
+            if (want >= 2) n_chunks = (uint32_t)want;
+        }
+        cut[0] = 0; cut[n_chunks] = nb;
+        for (uint32_t c = 1; c < n_chunks; c++) {                 /* equal record counts ~ equal bytes */
+            const uint64_t target = B[0].rec_base + (B[nb - 1].rec_base + B[nb - 1].n_reads - B[0].rec_base) * c / n_chunks;
+            uint32_t lo = cut[c - 1] + 1, hi = nb - (n_chunks - c);
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (B[mid].rec_base < target) lo = mid + 1; else hi = mid; }
+            cut[c] = lo;
+        }
+        tm.n_chunks = n_chunks;
+        /* small things first: descriptors, names, result slots, exception runs */
+        GO(hipMemcpyAsync(d_blocks, B, (uint64_t)nb * sizeof(cbc_block_desc), hipMemcpyHostToDevice, sc), "H2D blocks");
+        GO(hipMemcpyAsync(ctx->arena[A_NAMES].p, hb->names, hb->names_bytes, hipMemcpyHostToDevice, sc), "H2D names");
+        GO(hipMemsetAsync(d_res, 0xff, (uint64_t)nb * sizeof(cbc_block_result), sc), "memset results");
+        if (seq_codes && !d_seq_ext && n_seq_runs)
+            GO(hipMemcpyAsync(ctx->arena[A_RUNS].p, seq_runs, n_seq_runs * sizeof(cbc_2bit_run_dev), hipMemcpyHostToDevice, sc), "H2D 2-bit runs");
+        tm.h2d_bytes = (uint64_t)nb * sizeof(cbc_block_desc) + hb->names_bytes + (seq_codes && !d_seq_ext ? n_seq_runs * sizeof(cbc_2bit_run_dev) : 0);
+        uint64_t words_done = 0;                                  /* 2-bit words expanded so far (chunks meet inside a word) */
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            const uint32_t c0 = cut[c], c1 = cut[c + 1];
+            const bool whole = !contiguous || n_chunks == 1;
+            const uint64_t r0 = whole ? 0 : B[c0].rec_base, r1 = whole ? hb->n_recs : B[c1 - 1].rec_base + B[c1 - 1].n_reads;
+            const uint64_t s0 = whole ? 0 : B[c0].seq_base, s1 = whole || c1 == nb ? hb->seq_bytes : B[c1].seq_base;
+            const uint64_t t0 = whole ? 0 : B[c0].tok_base, t1 = whole || c1 == nb ? hb->n_tok : B[c1].tok_base;
+            GO(hipMemcpyAsync(d_recs + r0 * 16, (const uint8_t *)hb->recs + r0 * 16, (r1 - r0) * 16, hipMemcpyHostToDevice, sc), "H2D recs");
+            tm.h2d_bytes += (r1 - r0) * 16;
+            uint64_t w0 = 0, w1 = 0;
+            if (d_seq_ext) { /* already resident */ }
+            else if (seq_codes) {                                  /* 2-bit transport: a quarter of the bytes cross PCIe, expanded on the device */
+                w0 = words_done; w1 = (s1 + 15) / 16; if (w1 < w0) w1 = w0;
+                if (w1 > w0) GO(hipMemcpyAsync(d_codes + w0, seq_codes + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, sc), "H2D 2-bit codes");
+                tm.h2d_bytes += (w1 - w0) * 4; words_done = w1;
+            } else if (s1 > s0) {
+                GO(hipMemcpyAsync(d_seq + s0, hb->seq + s0, s1 - s0, hipMemcpyHostToDevice, sc), "H2D seq");
+                tm.h2d_bytes += s1 - s0;
+            }
+            if (!d_tok_ext && t1 > t0) {
+                GO(hipMemcpyAsync(d_tok + t0, hb->tok + t0, (t1 - t0) * 4, hipMemcpyHostToDevice, sc), "H2D tok");
+                tm.h2d_bytes += (t1 - t0) * 4;
+            }
+            GO(hipEventRecord(ctx->ev_chunk[c], sc), "hipEventRecord");
+            hipStream_t ks = ctx->s_k[c % CBC_N_KSTREAMS];
+            GO(hipStreamWaitEvent(ks, ctx->ev_chunk[c], 0), "hipStreamWaitEvent");
+            if (seq_codes && !d_seq_ext && w1 > w0) {
+                if (w1 - w0 > 0x7fffffffull * 256ull) { rc = set_err(ctx, CBC_E_ARG, "2-bit transport: too many words", hipSuccess); goto done; }
+                hipLaunchKernelGGL(cbc_expand_2bit_kernel, dim3((unsigned)((w1 - w0 + 255) / 256)), dim3(256), 0, ks,
+                                   (const uint32_t *)(d_codes + w0), w1 - w0, d_seq + w0 * 16, hb->seq_bytes - w0 * 16);
+                GO(hipGetLastError(), "launch cbc_expand_2bit_kernel");
+                if (n_seq_runs) {
+                    hipLaunchKernelGGL(cbc_apply_runs_kernel, dim3((unsigned)n_seq_runs), dim3(256), 0, ks,
+                                       (const cbc_2bit_run_dev *)ctx->arena[A_RUNS].p, n_seq_runs, d_seq, hb->seq_bytes, w0 * 16, w1 * 16);
+                    GO(hipGetLastError(), "launch cbc_apply_runs_kernel");
+                }
+            }
+            cbc_device_batch db;
+            memset(&db, 0, sizeof db);
+            db.d_recs = (const cbc_read_rec *)d_recs; db.d_seq = d_seq_ext ? d_seq_ext : d_seq; db.d_tok = d_tok_ext ? d_tok_ext : d_tok;
+            db.d_names = (const uint8_t *)ctx->arena[A_NAMES].p; db.d_blocks = d_blocks + c0; db.n_blocks = c1 - c0;
+            db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_out = (uint8_t *)ctx->arena[A_OUT].p; db.out_bytes = scratch;
+            db.d_results = d_res + c0; db.seq_bytes = hb->seq_bytes; db.n_tok = ntok; db.n_recs = hb->n_recs;
+            db.caps = hb->caps;
+            rc = encode_blocks_launch(ctx, &db, ks, nb);
+            if (rc) goto done;
+        }
+        /* the context's own stream joins the kernel streams, then: sizes -> offsets -> compaction -> D2H */
+        for (int k = 0; k < CBC_N_KSTREAMS; k++) {
+            GO(hipEventRecord(ctx->ev_done[k], ctx->s_k[k]), "hipEventRecord");
+            GO(hipStreamWaitEvent(ctx->stream, ctx->ev_done[k], 0), "hipStreamWaitEvent");
+        }
+        tm.issue_s = wall_now() - T0;
+        hipLaunchKernelGGL(cbc_scan_sizes_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const cbc_block_result *)d_res,
+                           (uint64_t *)ctx->arena[A_OFF].p, nb);
+        GO(hipGetLastError(), "launch cbc_scan_sizes_kernel");
+        res = results ? results : (cbc_block_result *)malloc((size_t)nb * sizeof(cbc_block_result));
+        if (!res) { rc = CBC_E_NOMEM; goto done; }
+        GO(hipMemcpyAsync(res, d_res, (uint64_t)nb * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
+        GO(hipMemcpyAsync(out_offsets, ctx->arena[A_OFF].p, ((uint64_t)nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H offsets");
+        GO(hipStreamSynchronize(ctx->stream), "encode kernel");
+        tm.kernels_done_s = wall_now() - T0;
+        /* the compacted bitstreams (2 bytes per read) go where the batch's bases were: they are dead now, and a second
+         * worst-case-sized buffer would cost more to allocate than the whole call takes */
+        total = out_offsets[nb];
+        if (!d_seq_ext && total <= ctx->arena[A_SEQ].cap) d_compact = (uint8_t *)ctx->arena[A_SEQ].p;
+        else { NEED(A_PACKED, total + 16, "hipMalloc packed"); d_compact = (uint8_t *)ctx->arena[A_PACKED].p; }
+        if (total) {
+            hipLaunchKernelGGL(cbc_compact_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const uint8_t *)ctx->arena[A_OUT].p,
+                               (const cbc_block_desc *)d_blocks, (const uint64_t *)ctx->arena[A_OFF].p, d_compact, total, nb);
+            GO(hipGetLastError(), "launch cbc_compact_kernel");
+        }
+    }
     for (uint32_t b = 0; b < nb; b++) {
         if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
             snprintf(ctx->err, sizeof ctx->err, "block %u failed with status %u at record %u", b, res[b].status, res[b].fail_read);
             rc = CBC_E_BLOCK;
         }
     }
-    total = out_offsets[nb];
     if (total > out_cap) { rc = set_err(ctx, CBC_E_ARG, "out_cap too small for the compacted payloads", hipSuccess); goto done; }
     if (total) {
-        GO(hipMemcpyAsync(out, d_packed, total, hipMemcpyDeviceToHost, ctx->stream), "D2H payloads");
+        GO(hipMemcpyAsync(out, d_compact, total, hipMemcpyDeviceToHost, ctx->stream), "D2H payloads");
         GO(hipStreamSynchronize(ctx->stream), "D2H payloads");
     }
+    tm.d2h_bytes = total + (uint64_t)nb * (sizeof(cbc_block_result) + 8) + 8;
 done:
 #undef GO
+#undef NEED
+    if (rc && rc != CBC_E_BLOCK) (void)hipDeviceSynchronize();   /* nothing of a failed call may still be running over the arenas */
     if (res && res != results) free(res);
-    if (d_recs) (void)hipFree(d_recs); if (d_seq) (void)hipFree(d_seq); if (d_tok) (void)hipFree(d_tok);
-    if (d_names) (void)hipFree(d_names); if (d_blocks) (void)hipFree(d_blocks); if (d_out) (void)hipFree(d_out);
-    if (d_res) (void)hipFree(d_res); if (d_off) (void)hipFree(d_off); if (d_packed) (void)hipFree(d_packed);
-    if (d_codes) (void)hipFree(d_codes); if (d_runs) (void)hipFree(d_runs);
+    tm.total_s = wall_now() - T0;
+    ctx->last_e2e = tm;
     return rc;
+}
+
+API int cbc_gpu_last_e2e(cbc_gpu_ctx *ctx, cbc_e2e_times *out)
+{
+    if (!ctx || !out) return CBC_E_ARG;
+    *out = ctx->last_e2e;
+    return CBC_OK;
+}
+
+API int cbc_gpu_host_register(cbc_gpu_ctx *ctx, const void *p, uint64_t bytes)
+{
+    if (!ctx || !p || !bytes) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipHostRegister((void *)p, bytes, hipHostRegisterDefault), "hipHostRegister");
+    return CBC_OK;
+}
+API int cbc_gpu_host_unregister(cbc_gpu_ctx *ctx, const void *p)
+{
+    if (!ctx || !p) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    HIPCHK(hipHostUnregister((void *)p), "hipHostUnregister");
+    return CBC_OK;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -554,46 +739,134 @@ API int cbc_gpu_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device_batc
     return CBC_OK;
 }
 
-API int cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
+/* The host-buffer decode path as a pipeline, mirror of encode_blocks_impl: the payloads (2 bytes per read) go H2D at once;
+ * the blocks are decoded in chunks on the two kernel streams, and chunk c's records and bases (bytes, or 2-bit rows packed by
+ * cbc_pack_2bit_kernel) come back on the copy stream while the later chunks are still being decoded.  Device arrays are the
+ * context's arenas. */
+static int decode_blocks_impl(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
                               uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
-                              uint8_t *seq, uint64_t seq_bytes, cbc_block_result *results)
+                              uint8_t *seq, uint64_t seq_bytes, uint32_t *codes_out, uint64_t *exc_idx, uint8_t *exc_val,
+                              uint64_t exc_cap, uint64_t *n_exc, cbc_block_result *results)
 {
-    if (!ctx || !in || !blocks || !caps || !recs || !seq) return CBC_E_ARG;
-    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
-    if (n_blocks == 0) return CBC_OK;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    void *d_in = NULL, *d_blocks = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL, *d_vs = NULL;
+    const double T0 = wall_now();
+    cbc_e2e_times tm; memset(&tm, 0, sizeof tm);
+    const bool two_bit = codes_out != NULL;
+    const uint32_t stride = blocks[0].seq_stride;
     cbc_block_result *res = NULL;
     int rc = CBC_OK;
     const uint64_t vs_words = (uint64_t)n_blocks * caps->cap_var;
+    const uint64_t n_words = two_bit ? n_recs * (stride >> 4) : 0;
+    unsigned long long got = 0;
 #define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
-    GO(hipMalloc(&d_vs, vs_words * 4 + 16), "hipMalloc var scratch");
-    GO(hipMalloc(&d_in, in_bytes + 16), "hipMalloc in");
-    GO(hipMalloc(&d_blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc)), "hipMalloc blocks");
-    GO(hipMalloc(&d_recs, n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
-    GO(hipMalloc(&d_seq, seq_bytes + 16), "hipMalloc seq");
-    GO(hipMalloc(&d_res, (uint64_t)n_blocks * sizeof(cbc_block_result)), "hipMalloc results");
-    GO(hipMemsetAsync((uint8_t *)d_in + in_bytes, 0, 16, ctx->stream), "memset pad");
-    GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D payloads");
-    GO(hipMemcpyAsync(d_blocks, blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
-    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)n_blocks * sizeof(cbc_block_result), ctx->stream), "memset results");
-    GO(hipMemsetAsync(d_seq, 0, seq_bytes + 16, ctx->stream), "memset seq");
-    {
-        cbc_dec_device_batch db;
-        memset(&db, 0, sizeof db);
-        db.d_in = (const uint8_t *)d_in; db.in_bytes = in_bytes + 16; db.d_blocks = (const cbc_dec_block_desc *)d_blocks;
-        db.n_blocks = n_blocks; db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = (cbc_read_rec *)d_recs;
-        db.n_recs = n_recs; db.d_seq = (uint8_t *)d_seq; db.seq_bytes = seq_bytes + 16; db.d_results = (cbc_block_result *)d_res;
-        db.caps = *caps; db.d_var_scratch = (uint32_t *)d_vs; db.var_scratch_words = vs_words;
-        rc = cbc_gpu_decode_blocks_device(ctx, &db, CBC_CTX_STREAM);
-        if (rc) goto done;
+#define NEED(k, bytes, what) do { rc = arena_need(ctx, k, bytes, what); if (rc) goto done; } while (0)
+    NEED(A_VS, vs_words * 4 + 16, "hipMalloc var scratch");
+    NEED(A_IN, in_bytes + 16, "hipMalloc in");
+    NEED(A_BLOCKS, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc), "hipMalloc blocks");
+    NEED(A_RECS, n_recs * sizeof(cbc_read_rec) + 16, "hipMalloc recs");
+    NEED(A_SEQ, seq_bytes + 32, "hipMalloc seq");
+    NEED(A_RES, (uint64_t)n_blocks * sizeof(cbc_block_result), "hipMalloc results");
+    if (two_bit) {
+        NEED(A_CODES, n_words * 4 + 16, "hipMalloc codes");
+        NEED(A_EXC_I, (exc_cap ? exc_cap : 1) * 8, "hipMalloc exceptions");
+        NEED(A_EXC_V, (exc_cap ? exc_cap : 1), "hipMalloc exceptions");
+        NEED(A_CNT, 8, "hipMalloc counter");
     }
-    res = results ? results : (cbc_block_result *)malloc((size_t)n_blocks * sizeof(cbc_block_result));
-    if (!res) { rc = CBC_E_NOMEM; goto done; }
-    GO(hipMemcpyAsync(res, d_res, (uint64_t)n_blocks * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
-    GO(hipMemcpyAsync(recs, d_recs, n_recs * sizeof(cbc_read_rec), hipMemcpyDeviceToHost, ctx->stream), "D2H recs");
-    GO(hipMemcpyAsync(seq, d_seq, seq_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H seq");
-    GO(hipStreamSynchronize(ctx->stream), "decode kernel");
+    tm.alloc_s = wall_now() - T0;
+    {
+        uint8_t *d_in = (uint8_t *)ctx->arena[A_IN].p, *d_seq = (uint8_t *)ctx->arena[A_SEQ].p;
+        cbc_dec_block_desc *d_blocks = (cbc_dec_block_desc *)ctx->arena[A_BLOCKS].p;
+        cbc_read_rec *d_recs = (cbc_read_rec *)ctx->arena[A_RECS].p;
+        cbc_block_result *d_res = (cbc_block_result *)ctx->arena[A_RES].p;
+        hipStream_t sc = ctx->s_copy;
+        GO(hipMemsetAsync(d_in + in_bytes, 0, 16, sc), "memset pad");
+        GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, sc), "H2D payloads");
+        GO(hipMemcpyAsync(d_blocks, blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc), hipMemcpyHostToDevice, sc), "H2D blocks");
+        GO(hipMemsetAsync(d_res, 0xff, (uint64_t)n_blocks * sizeof(cbc_block_result), sc), "memset results");
+        if (two_bit) GO(hipMemsetAsync(ctx->arena[A_CNT].p, 0, 8, sc), "memset counter");
+        GO(hipEventRecord(ctx->ev_done[0], sc), "hipEventRecord");       /* inputs are on the device */
+        tm.h2d_bytes = in_bytes + (uint64_t)n_blocks * sizeof(cbc_dec_block_desc);
+        /* chunks of consecutive blocks whose outputs are consecutive too */
+        uint32_t n_chunks = 1, cut[CBC_MAX_CHUNKS + 1];
+        bool contiguous = true;
+        for (uint32_t b = 0; b + 1 < n_blocks && contiguous; b++)
+            contiguous = blocks[b + 1].rec_base == blocks[b].rec_base + blocks[b].n_reads && blocks[b + 1].seq_base >= blocks[b].seq_base;
+        contiguous = contiguous && blocks[n_blocks - 1].rec_base + blocks[n_blocks - 1].n_reads <= n_recs && blocks[n_blocks - 1].seq_base <= seq_bytes;
+        if (contiguous && n_blocks >= 512) {
+            uint64_t want = (n_recs * 16 + (two_bit ? n_words * 4 : seq_bytes)) / (64ull << 20);
+            if (want > CBC_MAX_CHUNKS) want = CBC_MAX_CHUNKS;
+            if (want > n_blocks / 256) want = n_blocks / 256;
+            if (want >= 2) n_chunks = (uint32_t)want;
+        }
+        cut[0] = 0; cut[n_chunks] = n_blocks;
+        for (uint32_t c = 1; c < n_chunks; c++) {
+            const uint64_t target = blocks[0].rec_base + (blocks[n_blocks - 1].rec_base + blocks[n_blocks - 1].n_reads - blocks[0].rec_base) * c / n_chunks;
+            uint32_t lo = cut[c - 1] + 1, hi = n_blocks - (n_chunks - c);
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (blocks[mid].rec_base < target) lo = mid + 1; else hi = mid; }
+            cut[c] = lo;
+        }
+        tm.n_chunks = n_chunks;
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            const uint32_t c0 = cut[c], c1 = cut[c + 1];
+            const bool whole = !contiguous || n_chunks == 1;
+            const uint64_t s0 = whole ? 0 : blocks[c0].seq_base, s1 = whole || c1 == n_blocks ? seq_bytes : blocks[c1].seq_base;
+            hipStream_t ks = ctx->s_k[c % CBC_N_KSTREAMS];
+            GO(hipStreamWaitEvent(ks, ctx->ev_done[0], 0), "hipStreamWaitEvent");
+            if (s1 > s0) GO(hipMemsetAsync(d_seq + s0, 0, s1 - s0 + (c1 == n_blocks || whole ? 32 : 0), ks), "memset seq");
+            cbc_dec_device_batch db;
+            memset(&db, 0, sizeof db);
+            db.d_in = d_in; db.in_bytes = in_bytes + 16; db.d_blocks = d_blocks + c0; db.n_blocks = c1 - c0;
+            db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = d_recs; db.n_recs = n_recs;
+            db.d_seq = d_seq; db.seq_bytes = seq_bytes + 32; db.d_results = d_res + c0;
+            db.caps = *caps; db.d_var_scratch = (uint32_t *)ctx->arena[A_VS].p + (uint64_t)c0 * caps->cap_var;
+            db.var_scratch_words = (uint64_t)(c1 - c0) * caps->cap_var;
+            rc = cbc_gpu_decode_blocks_device(ctx, &db, ks);
+            if (rc) goto done;
+            const uint64_t r0 = whole ? 0 : blocks[c0].rec_base, r1 = whole ? n_recs : blocks[c1 - 1].rec_base + blocks[c1 - 1].n_reads;
+            if (two_bit && r1 > r0) {
+                const uint64_t w0 = r0 * (stride >> 4), w1 = r1 * (stride >> 4);
+                hipLaunchKernelGGL(cbc_pack_2bit_kernel, dim3((unsigned)((w1 - w0 + 255) / 256)), dim3(256), 0, ks,
+                                   (const uint8_t *)d_seq, (const cbc_read_rec *)d_recs, r0, r1, stride, (uint32_t *)ctx->arena[A_CODES].p,
+                                   (uint64_t *)ctx->arena[A_EXC_I].p, (uint8_t *)ctx->arena[A_EXC_V].p, exc_cap, (unsigned long long *)ctx->arena[A_CNT].p);
+                GO(hipGetLastError(), "launch cbc_pack_2bit_kernel");
+            }
+            GO(hipEventRecord(ctx->ev_chunk[c], ks), "hipEventRecord");
+        }
+        tm.issue_s = wall_now() - T0;
+        for (uint32_t c = 0; c < n_chunks; c++) {                 /* the chunks come back in order while later ones are being decoded */
+            const uint32_t c0 = cut[c], c1 = cut[c + 1];
+            const bool whole = !contiguous || n_chunks == 1;
+            const uint64_t r0 = whole ? 0 : blocks[c0].rec_base, r1 = whole ? n_recs : blocks[c1 - 1].rec_base + blocks[c1 - 1].n_reads;
+            const uint64_t s0 = whole ? 0 : blocks[c0].seq_base, s1 = whole || c1 == n_blocks ? seq_bytes : blocks[c1].seq_base;
+            GO(hipStreamWaitEvent(sc, ctx->ev_chunk[c], 0), "hipStreamWaitEvent");
+            if (r1 > r0) GO(hipMemcpyAsync(recs + r0, d_recs + r0, (r1 - r0) * sizeof(cbc_read_rec), hipMemcpyDeviceToHost, sc), "D2H recs");
+            tm.d2h_bytes += (r1 - r0) * sizeof(cbc_read_rec);
+            if (two_bit) {
+                const uint64_t w0 = r0 * (stride >> 4), w1 = r1 * (stride >> 4);
+                if (w1 > w0) GO(hipMemcpyAsync(codes_out + w0, (uint32_t *)ctx->arena[A_CODES].p + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost, sc), "D2H codes");
+                tm.d2h_bytes += (w1 - w0) * 4;
+            } else if (s1 > s0) {
+                GO(hipMemcpyAsync(seq + s0, d_seq + s0, s1 - s0, hipMemcpyDeviceToHost, sc), "D2H seq");
+                tm.d2h_bytes += s1 - s0;
+            }
+        }
+        res = results ? results : (cbc_block_result *)malloc((size_t)n_blocks * sizeof(cbc_block_result));
+        if (!res) { rc = CBC_E_NOMEM; goto done; }
+        GO(hipMemcpyAsync(res, d_res, (uint64_t)n_blocks * sizeof(cbc_block_result), hipMemcpyDeviceToHost, sc), "D2H results");
+        if (two_bit) GO(hipMemcpyAsync(&got, ctx->arena[A_CNT].p, 8, hipMemcpyDeviceToHost, sc), "D2H counter");
+        GO(hipStreamSynchronize(sc), "decode kernel");
+        tm.kernels_done_s = wall_now() - T0;
+        if (two_bit) {
+            *n_exc = got;
+            if (got > exc_cap) { rc = set_err(ctx, CBC_E_ARG, "more non-ACGT bases than exc_cap", hipSuccess); goto done; }
+            if (got) {
+                GO(hipMemcpyAsync(exc_idx, ctx->arena[A_EXC_I].p, got * 8, hipMemcpyDeviceToHost, sc), "D2H exceptions");
+                GO(hipMemcpyAsync(exc_val, ctx->arena[A_EXC_V].p, got, hipMemcpyDeviceToHost, sc), "D2H exceptions");
+                GO(hipStreamSynchronize(sc), "D2H exceptions");
+                tm.d2h_bytes += got * 9;
+            }
+        }
+    }
     for (uint32_t b = 0; b < n_blocks; b++)
         if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
             snprintf(ctx->err, sizeof ctx->err, "block %u failed to decode with status %u at record %u", b, res[b].status, res[b].fail_read);
@@ -601,10 +874,22 @@ API int cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
         }
 done:
 #undef GO
+#undef NEED
+    if (rc && rc != CBC_E_BLOCK) (void)hipDeviceSynchronize();
     if (res && res != results) free(res);
-    if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
-    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vs) (void)hipFree(d_vs);
+    tm.total_s = wall_now() - T0;
+    ctx->last_e2e = tm;
     return rc;
+}
+
+API int cbc_gpu_decode_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, cbc_dec_block_desc *blocks,
+                              uint32_t n_blocks, const cbc_lds_caps *caps, cbc_read_rec *recs, uint64_t n_recs,
+                              uint8_t *seq, uint64_t seq_bytes, cbc_block_result *results)
+{
+    if (!ctx || !in || !blocks || !caps || !recs || !seq) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    if (n_blocks == 0) return CBC_OK;
+    return decode_blocks_impl(ctx, in, in_bytes, blocks, n_blocks, caps, recs, n_recs, seq, seq_bytes, NULL, NULL, NULL, 0, NULL, results);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -994,71 +1279,8 @@ API int cbc_gpu_decode_blocks_2bit(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t
     if (stride < 16 || stride > 256 || (stride & 15u)) return set_err(ctx, CBC_E_ARG, "2-bit decode wants seq_stride to be a multiple of 16", hipSuccess);
     for (uint32_t b = 0; b < n_blocks; b++) if (blocks[b].seq_stride != stride || blocks[b].seq_base != blocks[b].rec_base * stride)
         return set_err(ctx, CBC_E_ARG, "2-bit decode wants one stride and seq_base = rec_base * stride", hipSuccess);
-    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    void *d_in = NULL, *d_blocks = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL, *d_vs = NULL, *d_codes = NULL, *d_ei = NULL, *d_ev = NULL, *d_n = NULL;
-    cbc_block_result *res = NULL;
-    int rc = CBC_OK;
-    const uint64_t vs_words = (uint64_t)n_blocks * caps->cap_var, seq_bytes = n_recs * stride, n_words = n_recs * (stride >> 4);
-    unsigned long long got = 0;
-#define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
-    GO(hipMalloc(&d_vs, vs_words * 4 + 16), "hipMalloc var scratch");
-    GO(hipMalloc(&d_in, in_bytes + 16), "hipMalloc in");
-    GO(hipMalloc(&d_blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc)), "hipMalloc blocks");
-    GO(hipMalloc(&d_recs, n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
-    GO(hipMalloc(&d_seq, seq_bytes + 32), "hipMalloc seq");
-    GO(hipMalloc(&d_res, (uint64_t)n_blocks * sizeof(cbc_block_result)), "hipMalloc results");
-    GO(hipMalloc(&d_codes, n_words * 4 + 16), "hipMalloc codes");
-    GO(hipMalloc(&d_ei, (exc_cap ? exc_cap : 1) * 8), "hipMalloc exceptions");
-    GO(hipMalloc(&d_ev, (exc_cap ? exc_cap : 1)), "hipMalloc exceptions");
-    GO(hipMalloc(&d_n, 8), "hipMalloc counter");
-    GO(hipMemsetAsync(d_n, 0, 8, ctx->stream), "memset counter");
-    GO(hipMemsetAsync((uint8_t *)d_in + in_bytes, 0, 16, ctx->stream), "memset pad");
-    GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D payloads");
-    GO(hipMemcpyAsync(d_blocks, blocks, (uint64_t)n_blocks * sizeof(cbc_dec_block_desc), hipMemcpyHostToDevice, ctx->stream), "H2D blocks");
-    GO(hipMemsetAsync(d_res, 0xff, (uint64_t)n_blocks * sizeof(cbc_block_result), ctx->stream), "memset results");
-    GO(hipMemsetAsync(d_seq, 0, seq_bytes + 32, ctx->stream), "memset seq");
-    {
-        cbc_dec_device_batch db;
-        memset(&db, 0, sizeof db);
-        db.d_in = (const uint8_t *)d_in; db.in_bytes = in_bytes + 16; db.d_blocks = (const cbc_dec_block_desc *)d_blocks;
-        db.n_blocks = n_blocks; db.d_ref = ctx->d_ref; db.ref_bytes = ctx->ref_bytes; db.d_recs = (cbc_read_rec *)d_recs;
-        db.n_recs = n_recs; db.d_seq = (uint8_t *)d_seq; db.seq_bytes = seq_bytes + 32; db.d_results = (cbc_block_result *)d_res;
-        db.caps = *caps; db.d_var_scratch = (uint32_t *)d_vs; db.var_scratch_words = vs_words;
-        rc = cbc_gpu_decode_blocks_device(ctx, &db, CBC_CTX_STREAM);
-        if (rc) goto done;
-    }
-    if (n_words) {
-        hipLaunchKernelGGL(cbc_pack_2bit_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint8_t *)d_seq, (const cbc_read_rec *)d_recs, n_recs, stride, (uint32_t *)d_codes,
-                           (uint64_t *)d_ei, (uint8_t *)d_ev, exc_cap, (unsigned long long *)d_n);
-        GO(hipGetLastError(), "launch cbc_pack_2bit_kernel");
-    }
-    res = results ? results : (cbc_block_result *)malloc((size_t)n_blocks * sizeof(cbc_block_result));
-    if (!res) { rc = CBC_E_NOMEM; goto done; }
-    GO(hipMemcpyAsync(res, d_res, (uint64_t)n_blocks * sizeof(cbc_block_result), hipMemcpyDeviceToHost, ctx->stream), "D2H results");
-    GO(hipMemcpyAsync(recs, d_recs, n_recs * sizeof(cbc_read_rec), hipMemcpyDeviceToHost, ctx->stream), "D2H recs");
-    GO(hipMemcpyAsync(codes_out, d_codes, n_words * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H codes");
-    GO(hipMemcpyAsync(&got, d_n, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H counter");
-    GO(hipStreamSynchronize(ctx->stream), "decode kernel");
-    *n_exc = got;
-    if (got > exc_cap) { rc = set_err(ctx, CBC_E_ARG, "more non-ACGT bases than exc_cap", hipSuccess); goto done; }
-    if (got) {
-        GO(hipMemcpyAsync(exc_idx, d_ei, got * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H exceptions");
-        GO(hipMemcpyAsync(exc_val, d_ev, got, hipMemcpyDeviceToHost, ctx->stream), "D2H exceptions");
-        GO(hipStreamSynchronize(ctx->stream), "D2H exceptions");
-    }
-    for (uint32_t b = 0; b < n_blocks; b++)
-        if (res[b].status != CBC_ST_OK && rc == CBC_OK) {
-            snprintf(ctx->err, sizeof ctx->err, "block %u failed to decode with status %u at record %u", b, res[b].status, res[b].fail_read);
-            rc = CBC_E_BLOCK;
-        }
-done:
-#undef GO
-    if (res && res != results) free(res);
-    if (d_in) (void)hipFree(d_in); if (d_blocks) (void)hipFree(d_blocks); if (d_recs) (void)hipFree(d_recs);
-    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vs) (void)hipFree(d_vs);
-    if (d_codes) (void)hipFree(d_codes); if (d_ei) (void)hipFree(d_ei); if (d_ev) (void)hipFree(d_ev); if (d_n) (void)hipFree(d_n);
-    return rc;
+    return decode_blocks_impl(ctx, in, in_bytes, blocks, n_blocks, caps, recs, n_recs, NULL, n_recs * stride, codes_out, exc_idx, exc_val,
+                              exc_cap, n_exc, results);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -71,6 +71,11 @@ TOK_STATUS = {3: "the file needs the host packer (leading soft clip or a record 
               9: "MD inconsistent with CIGAR/SEQ", 10: "read length outside 1..252", 11: "POS < 1", 12: "too many CIGAR/MD tokens"}
 
 
+class E2ETimes(ctypes.Structure):
+    _fields_ = [("total_s", ctypes.c_double), ("alloc_s", ctypes.c_double), ("issue_s", ctypes.c_double), ("kernels_done_s", ctypes.c_double),
+                ("h2d_bytes", ctypes.c_uint64), ("d2h_bytes", ctypes.c_uint64), ("n_chunks", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
 class CbcGpuError(RuntimeError):
     pass
 
@@ -163,6 +168,14 @@ def lib():
         L.cbc_gpu_last_kernel_variant.argtypes = [ctypes.c_void_p]
         L.cbc_gpu_synchronize.restype = ctypes.c_int
         L.cbc_gpu_synchronize.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_upload_reference_parts.restype = ctypes.c_int
+        L.cbc_gpu_upload_reference_parts.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        L.cbc_gpu_last_e2e.restype = ctypes.c_int
+        L.cbc_gpu_last_e2e.argtypes = [ctypes.c_void_p, ctypes.POINTER(E2ETimes)]
+        L.cbc_gpu_host_register.restype = ctypes.c_int
+        L.cbc_gpu_host_register.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        L.cbc_gpu_host_unregister.restype = ctypes.c_int
+        L.cbc_gpu_host_unregister.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.cbc_gpu_checksum_device.restype = ctypes.c_int
         L.cbc_gpu_checksum_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         if L.cbc_gpu_abi_version() != 1:
@@ -180,7 +193,8 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_upload_reference_2bit", "cbc_gpu_encode_blocks_2bit", "cbc_gpu_decode_blocks_2bit",
            "cbc_gpu_long_plan_output", "cbc_gpu_long_lds_bytes", "cbc_gpu_long_encode_blocks_device",
            "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks",
-           "cbc_gpu_checksum_device"]
+           "cbc_gpu_checksum_device", "cbc_gpu_upload_reference_parts", "cbc_gpu_last_e2e", "cbc_gpu_host_register",
+           "cbc_gpu_host_unregister"]
 
 
 class Encoder:
@@ -309,7 +323,7 @@ class Encoder:
             bases.reshape(-1)[ei[:k].astype(np.int64)] = ev[:k]
         return recs, bases, res, c.nbytes + 9 * k
 
-    def encode_blocks(self, pb: "host.PackedBatch", which=None):
+    def encode_blocks(self, pb: "host.PackedBatch", which=None, want_payload_list=True):
         """Host-buffer path.  Returns (list of payload bytes per block, results array, out_offsets, flat payload bytes).
         which: optional list of block indices (a rank's share of the batch); the descriptors carry absolute bases into the
         batch's arrays, so any subset is a batch of its own."""
@@ -325,7 +339,7 @@ class Encoder:
                                          res.ctypes.data)
         if rc != 0 and rc != -4:
             self._check(rc, "cbc_gpu_encode_blocks")
-        payloads = [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)]
+        payloads = [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)] if want_payload_list else None
         return payloads, res, offs, out[:int(offs[nb])]
 
     def decode_blocks(self, plan: "host.UnpackPlan"):
@@ -441,6 +455,21 @@ class Encoder:
     def compact_device(self, d_scratch, d_blocks, d_results, n_blocks, d_offsets, d_packed, packed_cap, stream=None):
         self._check(lib().cbc_gpu_compact_device(self._ctx, d_scratch, d_blocks, d_results, n_blocks, d_offsets,
                                                  d_packed, packed_cap, stream), "cbc_gpu_compact_device")
+
+    def last_e2e(self):
+        """What the most recent host-buffer call did (cbc_gpu_last_e2e): stage times, bytes over PCIe, chunks."""
+        t = E2ETimes()
+        self._check(lib().cbc_gpu_last_e2e(self._ctx, ctypes.byref(t)), "cbc_gpu_last_e2e")
+        return {k: getattr(t, k) for k, _ in E2ETimes._fields_ if k != "reserved"}
+
+    def host_register(self, arr):
+        """Page-lock a numpy array the entry points read from / write to (cbc_gpu_host_register)."""
+        if arr.nbytes:
+            self._check(lib().cbc_gpu_host_register(self._ctx, arr.ctypes.data, arr.nbytes), "cbc_gpu_host_register")
+
+    def host_unregister(self, arr):
+        if arr.nbytes:
+            self._check(lib().cbc_gpu_host_unregister(self._ctx, arr.ctypes.data), "cbc_gpu_host_unregister")
 
     def checksum_device(self, d_bytes, n, d_sum, stream=None):
         """cbc_gpu_checksum_device: *d_sum (device, 8 bytes) = checksum of n device bytes, asynchronous on `stream`."""

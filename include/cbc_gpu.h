@@ -140,6 +140,9 @@ const char *cbc_gpu_last_error(cbc_gpu_ctx *ctx);
  * base, each contig followed by CBC_REF_PAD zero bytes (what store_reference_in_memory,
  * src/read_decompression.c:17-53, keeps in `reference[]`, for all contigs at once). */
 int  cbc_gpu_upload_reference(cbc_gpu_ctx *ctx, const uint8_t *bases, uint64_t nbytes);
+/* The same from several host pieces, laid end to end on the device in the order given (piece k starts at the sum of the
+ * sizes before it): a device that codes some contigs of a genome uploads those contigs, not all of it. */
+int  cbc_gpu_upload_reference_parts(cbc_gpu_ctx *ctx, const uint8_t *const *parts, const uint64_t *bytes, uint32_t n_parts);
 
 /* Host-buffer entry point: copies the batch to the device, codes every block, copies the payloads
  * back *compacted*: block b's payload is out[out_offsets[b] .. out_offsets[b+1]).  `blocks[].out_off`
@@ -156,6 +159,22 @@ typedef struct cbc_host_batch {
 int  cbc_gpu_encode_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *batch,
                            uint8_t *out, uint64_t out_cap, uint64_t *out_offsets /* n_blocks+1 */,
                            cbc_block_result *results /* n_blocks or NULL */);
+
+/* The host-buffer entry points run as a pipeline (chunked H2D on a copy stream overlapped with the launches of the chunks
+ * already on the device; device arrays kept in the context between calls).  What the most recent one did: */
+typedef struct cbc_e2e_times {
+    double   total_s;        /* whole call                                                                  */
+    double   alloc_s;        /* growing the context's device arenas (0 once they have their size)           */
+    double   issue_s;        /* until the last chunk's copies and launch had been handed to the runtime     */
+    double   kernels_done_s; /* until every block had been coded and the sizes were on the host            */
+    uint64_t h2d_bytes, d2h_bytes;
+    uint32_t n_chunks, reserved;
+} cbc_e2e_times;
+int  cbc_gpu_last_e2e(cbc_gpu_ctx *ctx, cbc_e2e_times *out);
+/* Page-lock caller-owned host memory the entry points read from or write to (hipHostRegister): DMA then runs at the link
+ * rate and asynchronously.  Worth it for buffers that are reused; the entry points accept pageable memory as well. */
+int  cbc_gpu_host_register(cbc_gpu_ctx *ctx, const void *p, uint64_t bytes);
+int  cbc_gpu_host_unregister(cbc_gpu_ctx *ctx, const void *p);
 
 /* Device-pointer entry point (what bench.py and the multi-GPU host use): every pointer is a
  * device address, the launch is asynchronous on `hip_stream`, a hipStream_t used exactly as given

@@ -581,17 +581,29 @@ def test_paired_end_flag_sets_of_more_than_64_values(enc, built):
     _gpu_roundtrip(enc, pb, sam, fa)
 
 
-def test_checksum_kernel_equals_host_twin(enc, built):
+def test_checksum_kernel_equals_host_twin(built):
     """cbc_gpu_checksum_device == cbc_checksum64 (what the two sides of the bitstream gather compute), on aligned and
-    unaligned device ranges, empty input included."""
-    import ctypes
-    import torch
-    rng = np.random.default_rng(3)
-    a = rng.integers(0, 256, 5_000_011, dtype=np.uint8)
-    t = torch.from_numpy(a).cuda()
-    d_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
-    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for off, n in ((0, len(a)), (0, 4096), (1, 100_000), (7, 17), (16, 0), (3, 1)):
-        enc.checksum_device(t.data_ptr() + off, n, d_sum.data_ptr(), s)
-        torch.cuda.synchronize()
-        assert int(d_sum.item()) & (2 ** 64 - 1) == host.checksum64(a[off:off + n]), (off, n)
+    unaligned device ranges, empty input included.  In a child process: torch owns the device memory there and has to
+    initialise HIP before the library does (as in bench.py), which this process's Encoder fixture has already done."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, ctypes
+        sys.path.insert(0, %r)
+        import numpy as np, torch
+        torch.cuda.init()
+        from cbc_amd import gpu, host
+        enc = gpu.Encoder(0)
+        rng = np.random.default_rng(3)
+        a = rng.integers(0, 256, 5_000_011, dtype=np.uint8)
+        t = torch.from_numpy(a).cuda()
+        d_sum = torch.zeros(1, dtype=torch.int64, device="cuda")
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for off, n in ((0, len(a)), (0, 4096), (1, 100_000), (7, 17), (16, 0), (3, 1)):
+            enc.checksum_device(t.data_ptr() + off, n, d_sum.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert int(d_sum.item()) & (2 ** 64 - 1) == host.checksum64(a[off:off + n]), (off, n)
+        print("CHECKSUM_OK")
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "CHECKSUM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
