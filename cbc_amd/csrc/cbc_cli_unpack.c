@@ -35,15 +35,19 @@ static int decompress_stream(const uint8_t *blob, size_t blob_len, const char *f
     int rc = cbc_gpu_init(device, &ctx);
     if (rc) { fprintf(stderr, "cbc: no usable MI355X (cbc_gpu_init = %d); there is no CPU fallback\n", rc); return 1; }
     if (cbc_gpu_upload_reference(ctx, R->bases, R->n_bytes)) { fprintf(stderr, "cbc: %s\n", cbc_gpu_last_error(ctx)); return 1; }
-    const uint32_t stride = 256;
-    uint64_t cap = blob_len * 2 + 65536;
+    /* rows of the header read length rounded up to 4 (the decoder refuses a longer read: quirk Q7 makes fixed-length input
+     * the only kind that decodes), room for one record per stream byte to begin with (files run at 1.4 - 2 bytes per read),
+     * doubled while the kernel reports OUT_FULL; the record count is capped where rec_cap stops fitting 32 bits */
+    const uint32_t stride = ((L0 < 4 ? 4 : L0) + 3u) & ~3u;
+    uint64_t cap = (uint64_t)blob_len + 65536;
     for (;;) {
+        if (cap > 0xffffffffull) cap = 0xffffffffull;
         cbc_read_rec *recs = (cbc_read_rec *)malloc((size_t)cap * sizeof(cbc_read_rec));
         uint8_t *seq = (uint8_t *)malloc((size_t)(cap * stride + 8));
         if (!recs || !seq) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
         cbc_stream_result sr; memset(&sr, 0, sizeof sr);
         rc = cbc_gpu_decode_stream(ctx, blob, blob_len, R->contig_off, R->contig_len, R->n_contigs, recs, cap, seq, cap * stride + 8, stride, &sr);
-        if (rc == CBC_E_BLOCK && sr.status == CBC_ST_OUT_FULL && cap < 0x7fffffffull) { free(recs); free(seq); cap *= 4; continue; }
+        if (rc == CBC_E_BLOCK && sr.status == CBC_ST_OUT_FULL && cap < 0xffffffffull) { free(recs); free(seq); cap *= 2; continue; }
         if (rc) { fprintf(stderr, "cbc: decode failed: %s\n", cbc_gpu_last_error(ctx)); return 1; }
         FILE *fo = fopen(out, "wb");
         if (!fo) { fprintf(stderr, "cbc: cannot write %s\n", out); return 1; }

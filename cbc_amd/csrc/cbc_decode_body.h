@@ -85,6 +85,10 @@ struct CbcDec {
     uint32_t fcount, fn, hc0, hc1, hc2, hc3, hn0, hn1, hn2, hn3;
     uint32_t *lds, *evp;
     uint32_t *rname_key, *rname_exc, *histp, *pos_valp, *pos_cntp, *vtab; uint32_t rn_cap;   /* set by the stream function */
+    /* GEN (whole-file stream): the global-memory sides of flag, pos and pos_alpha -- see CbcEnc */
+    uint32_t *fsp_key, *fsp_exc; uint32_t fsp_count;
+    uint32_t *pos_ov_valp, *pos_ov_cntp; uint32_t pos_lds_cap;
+    uint32_t *palpha; uint32_t pa_n0, pa_n1, pa_n2, pa_n3;
     uint32_t rlen_n, rl123_c0, rl123_n, snps_n, indels_n, rn_count, pos_card, pos_n, cap_pos, nev, nev1, cap_var, L0;
     uint32_t prevPos, prevM, prevChar;
     uint32_t rl_memo_x, rl_memo_lo, rl_memo_cnt, rl_last_x;
@@ -345,6 +349,82 @@ struct CbcDec {
 
     /* ---- dense-excess tables in LDS: 4 consecutive symbols per lane, one wave scan ---- */
     /* symbols 4*lane .. 4*lane+3 with excess e0..e3: find the one whose interval holds tg */
+    /* ---- flag in its general form (decompress_flag read_decompression.c:120-139; CbcEnc::flag_gen_code): register pairs
+     * + pairs in global memory.  A value seen before, held in registers, with nothing spilled: the search by scaled
+     * bounds (regsparse_fast).  Anything else: cum(s) = s + the excess of all smaller values seen is increasing in s, so the
+     * symbol is found by bisection over s on the target (17 evaluations of cum, each one pass over the pairs). ---- */
+    CBC_MFN uint32_t flag_cum(uint32_t sv)
+    {
+        const V32 ln = W::lane();
+        V32 acc = W::select((ln < fcount) & (fkey < sv), fexc, W::splat(0u));
+        const uint32_t nb = W::uni(fsp_count);
+        for (uint32_t b = 0; b < nb; b += 64u) {
+            const V32 i = ln + b; const Mask m = i < fsp_count;
+            const V32 k = W::load32_list(fsp_key, i, m, 0xffffffffu), e = W::load32_list(fsp_exc, i, m, 0u);
+            acc = acc + W::select(m & (k < sv), e, W::splat(0u));
+        }
+        return sv + W::reduce_add(acc);
+    }
+    CBC_MFN uint32_t flag_gen_dec()
+    {
+        uint32_t x = 0;
+        if (fsp_count == 0u && regsparse_fast(fkey, fexc, 0u, fcount, fn, 65536u, 8u, x)) return x;
+        const V32 ln = W::lane();
+        const uint32_t tg = target(fn);
+        if (status != CBC_ST_OK) return 0u;
+        if (fsp_count) W::list_fence();
+        uint32_t lo_s = 0u, hi_s = 65535u;
+        while (lo_s < hi_s) {                                 /* the largest s with cum(s) <= target */
+            const uint32_t mid = (lo_s + hi_s + 1u) >> 1;
+            if (flag_cum(mid) <= tg) lo_s = mid; else hi_s = mid - 1u;
+        }
+        x = lo_s;
+        const uint32_t cum = flag_cum(x);
+        uint32_t cnt = 1u, idx = 0, sp_idx = CBC_NOMEMO;
+        const uint64_t eq = W::ballot((ln < fcount) & (fkey == x));
+        if (eq) { idx = W::ctz64(eq); cnt = 1u + W::readlane(fexc, idx); }
+        else {
+            const uint32_t nb = W::uni(fsp_count);
+            for (uint32_t b = 0; b < nb; b += 64u) {
+                const V32 i = ln + b; const Mask m = i < fsp_count;
+                const V32 k = W::load32_list(fsp_key, i, m, 0xffffffffu);
+                const uint64_t hit = W::ballot(m & (k == x));
+                if (hit) { sp_idx = b + W::ctz64(hit); cnt = 1u + W::readlane(W::load32_list(fsp_exc, W::splat(sp_idx), W::all(), 0u), 0u); }
+            }
+        }
+        if (tg < cum || tg - cum >= cnt) { fail(CBC_ST_ASSERT); return 0u; }
+        step(cum, cnt, fn);
+        if (eq) fexc = W::select(ln == idx, fexc + 8u, fexc);
+        else if (sp_idx != CBC_NOMEMO) W::append_list(fsp_exc, sp_idx, cnt - 1u + 8u);
+        else if (fcount < CBC_CAP_FLAG) {
+            fkey = W::select(ln == fcount, W::splat(x), fkey);
+            fexc = W::select(ln == fcount, W::splat(8u), fexc);
+            fcount++;
+        } else {
+            if (fsp_key == nullptr || fsp_count >= 65536u) { fail(CBC_ST_CAP_FLAG); return 0u; }
+            W::append_list(fsp_key, fsp_count, x); W::append_list(fsp_exc, fsp_count, 8u);
+            fsp_count++;
+        }
+        fn += 8u;
+        if (fn >= CBC_RESCALE) {
+            const Mask live = ln < fcount;
+            fexc = W::select(live, (fexc + 1u) >> 1, fexc);
+            V32 a = W::select(live, fexc, W::splat(0u));
+            if (fsp_count) {
+                W::list_fence();
+                const uint32_t nb = W::uni(fsp_count);
+                for (uint32_t b = 0; b < nb; b += 64u) {
+                    const V32 i = ln + b; const Mask m = i < fsp_count;
+                    const V32 e = (W::load32_list(fsp_exc, i, m, 0u) + 1u) >> 1;
+                    W::store32_list(fsp_exc, i, e, m);
+                    a = a + W::select(m, e, W::splat(0u));
+                }
+            }
+            fn = 65536u + W::reduce_add(a);
+        }
+        return x;
+    }
+
     CBC_MFN uint32_t search4(V32 e0, V32 e1, V32 e2, V32 e3, uint32_t card, uint32_t tg, uint32_t &lo, uint32_t &cnt)
     {
         V32 s0 = W::lane() * 4u;
@@ -500,7 +580,29 @@ struct CbcDec {
         return x;
     }
 
-    /* ---- pos: literal counts, two tiers (cf. CbcEnc::pos_code) ---- */
+    /* ---- pos: literal counts, two tiers (cf. CbcEnc::pos_code); entries from pos_lds_cap on live in the global overflow
+     * arrays (CbcEnc::ptab_*) ---- */
+    CBC_MFN V32 ptab_ld(const uint32_t *t_lds, const uint32_t *t_ov, uint32_t b, V32 i, Mask m, uint32_t other)
+    {
+        if (b < pos_lds_cap) return W::load32(t_lds, i, m, other);
+        return W::load32_list(t_ov, i - pos_lds_cap, m, other);
+    }
+    CBC_MFN void ptab_st(uint32_t *t_lds, uint32_t *t_ov, uint32_t b, V32 i, V32 v, Mask m)
+    {
+        if (b < pos_lds_cap) W::store32(t_lds, i, v, m);
+        else W::store32_list(t_ov, i - pos_lds_cap, v, m);
+    }
+    CBC_MFN uint32_t ptab_rd(const uint32_t *t_lds, const uint32_t *t_ov, uint32_t idx)
+    {
+        if (idx < pos_lds_cap) return W::read_uni(t_lds, idx);
+        W::list_fence();
+        return W::readlane(W::load32_list(t_ov, W::splat(idx - pos_lds_cap), W::all(), 0u), 0u);
+    }
+    CBC_MFN void ptab_wr(uint32_t *t_lds, uint32_t *t_ov, uint32_t idx, uint32_t v)
+    {
+        if (idx < pos_lds_cap) W::write_uni(t_lds, idx, v);
+        else W::append_list(t_ov, idx - pos_lds_cap, v);
+    }
     CBC_MFN void pos_rescale()
     {
         V32 ln = W::lane();
@@ -508,10 +610,11 @@ struct CbcDec {
         pcnt = W::select(m0, (pcnt >> 1) + 1u, pcnt);
         V32 a = W::select(m0, pcnt, W::splat(0u));
         const uint32_t pc = W::uni(pos_card);
+        if (pos_card > pos_lds_cap) W::list_fence();
         for (uint32_t b = 64u; b < pc; b += 64u) {
             V32 i = ln + b; Mask m = i < pos_card;
-            V32 c = (W::load32(pos_cnt_p(), i, m, 0u) >> 1) + 1u;
-            W::store32(pos_cnt_p(), i, c, m);
+            V32 c = (ptab_ld(pos_cnt_p(), pos_ov_cntp, b, i, m, 0u) >> 1) + 1u;
+            ptab_st(pos_cnt_p(), pos_ov_cntp, b, i, c, m);
             a = a + W::select(m, c, W::splat(0u));
         }
         pos_n = W::reduce_add(a);
@@ -519,12 +622,17 @@ struct CbcDec {
     CBC_MFN void pos_update(uint32_t idx)
     {
         if (idx < 64u) pcnt = W::select(W::lane() == idx, pcnt + 10u, pcnt);
-        else W::write_uni(pos_cnt_p(), idx, W::read_uni(pos_cnt_p(), idx) + 10u);
+        else ptab_wr(pos_cnt_p(), pos_ov_cntp, idx, ptab_rd(pos_cnt_p(), pos_ov_cntp, idx) + 10u);
         pos_n += 10u;
         if (pos_n >= CBC_RESCALE) pos_rescale();
     }
     CBC_MFN uint32_t pos_alpha_dec(uint32_t k)           /* one byte of decompress_pos_alpha :144-181 */
     {
+        if (palpha) {                                        /* the general form: four dense models with their rescale */
+            uint32_t *t = palpha + 256u * k;
+            return k == 0u ? dense_dec(t, 256u, 10u, pa_n0) : k == 1u ? dense_dec(t, 256u, 10u, pa_n1)
+                 : k == 2u ? dense_dec(t, 256u, 10u, pa_n2) : dense_dec(t, 256u, 10u, pa_n3);
+        }
         uint32_t n = 256u + 10u * (pos_card - 1u);
         if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return 0u; }
         uint32_t tg = target(n), lo, cnt;
@@ -539,6 +647,7 @@ struct CbcDec {
     }
     CBC_MFN void hist_inc(uint32_t k, uint32_t b)
     {
+        if (palpha) return;                                   /* dense tables carry their own counts */
         uint32_t *h = histp + 128u * k;
         W::write_uni(h, b >> 1, W::read_uni(h, b >> 1) + (1u << ((b & 1u) * 16u)));
     }
@@ -557,9 +666,10 @@ struct CbcDec {
             uint32_t lo = 0, cnt = 0, found = 0;
             uint32_t base_sum = W::readlane(inc, 63u);
             const uint32_t pc = W::uni(pos_card);
+            if (pos_card > pos_lds_cap) W::list_fence();
             for (uint32_t b = 64u; b < pc && !found; b += 64u) {
                 V32 i = ln + b; Mask m = i < pos_card;
-                V32 cc = W::load32(pos_cnt_p(), i, m, 0u);
+                V32 cc = ptab_ld(pos_cnt_p(), pos_ov_cntp, b, i, m, 0u);
                 V32 ic = W::scan_incl_add(cc) + base_sum;
                 uint64_t h2 = W::ballot(m & ((ic - cc) <= tg) & (tg < ic));
                 if (h2) { uint32_t hl = W::ctz64(h2); idx = b + hl; lo = W::readlane(ic, hl) - W::readlane(cc, hl); cnt = W::readlane(cc, hl); found = 1; }
@@ -571,7 +681,7 @@ struct CbcDec {
         pos_update(idx);
         return idx;
     }
-    CBC_MFN uint32_t pos_value(uint32_t idx) { return idx < 64u ? W::readlane(pval, idx) : W::read_uni(pos_val_p(), idx); }
+    CBC_MFN uint32_t pos_value(uint32_t idx) { return idx < 64u ? W::readlane(pval, idx) : ptab_rd(pos_val_p(), pos_ov_valp, idx); }
     /* after an escape: the four bytes of the new delta, which joins the alphabet (decompress_pos :126-141) */
     CBC_MFN uint32_t pos_escape()
     {
@@ -585,8 +695,8 @@ struct CbcDec {
             pval = W::select(ln == pos_card, W::splat(x), pval);
             pcnt = W::select(ln == pos_card, W::splat(0u), pcnt);
         } else {
-            W::write_uni(pos_val_p(), pos_card, x);
-            W::write_uni(pos_cnt_p(), pos_card, 0u);
+            ptab_wr(pos_val_p(), pos_ov_valp, pos_card, x);
+            ptab_wr(pos_cnt_p(), pos_ov_cntp, pos_card, 0u);
         }
         pos_card++;
         pos_update(pos_card - 1u);
@@ -885,6 +995,7 @@ CBC_FN void cbc_decode_stream(const cbc_dec_args &A, uint32_t blk, uint32_t *lds
     D.evp = A.var_scratch + (uint64_t)blk * A.cap_var;
     D.rname_key = lds + CBC_LDS_RNKEY; D.rname_exc = lds + CBC_LDS_RNEXC; D.rn_cap = CBC_CAP_NAME; D.histp = lds + CBC_DLDS_HIST;
     D.pos_valp = lds + CBC_DLDS_FIXED; D.pos_cntp = lds + CBC_DLDS_FIXED + A.cap_pos; D.vtab = nullptr;
+    D.fsp_key = D.fsp_exc = nullptr; D.fsp_count = 0; D.pos_ov_valp = D.pos_ov_cntp = nullptr; D.pos_lds_cap = 0xffffffc0u; D.palpha = nullptr;
     /* the payload buffer must leave 3 spare bytes after the last payload (whole-dword reads) */
     /* every range test is written without the sum base + length, which a crafted descriptor could make wrap */
     bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&

@@ -263,6 +263,14 @@ struct CbcEnc {
     uint32_t snps_n, indels_n;
     uint32_t rn_count, rn_cap;               /* contig-name pairs in use / capacity (CBC_CAP_NAME in the block kernels) */
     uint32_t *vtab;                          /* GEN: var excess table in global memory, row = context, L0 words per row */
+    /* GEN (whole-file stream): what no LDS budget bounds lives in global memory, as the var table does --
+     *   flag: values beyond the CBC_CAP_FLAG register pairs, unsorted (value, excess) pairs (sam_models.c:96-130 has 65536);
+     *   pos:  alphabet entries beyond the pos_lds_cap held in LDS (MAX_CARDINALITY, sam_block.h:55);
+     *   pos_alpha: the four byte models as dense excess tables with their rescale (the derived form of pos_alpha() stops
+     *   at ~104 k registered values, where those models first rescale).  nullptr / cap_pos in the other kernels. */
+    uint32_t *fsp_key, *fsp_exc; uint32_t fsp_count;
+    uint32_t *pos_ov_val, *pos_ov_occ; uint32_t pos_lds_cap;      /* pos_lds_cap: a multiple of 64 (chunks never straddle) */
+    uint32_t *palpha; uint32_t pa_n0, pa_n1, pa_n2, pa_n3;
     uint32_t pos_card, cap_pos;              /* pos alphabet: value / occurrences / prefix by index, in LDS */
     uint32_t nev, nev1, cap_var;             /* var events of strand 0 (from the bottom of the area) / strand 1 (from the top) */
     V32 p0cnt; uint32_t p0over;              /* p = 0 contexts: events held per (strand, d & 7) bucket, lane = strand * 8 + bucket; bit = that bucket spilled to the global list */
@@ -855,6 +863,92 @@ struct CbcEnc {
         }
     }
 
+    /* ---- pos tables: entry i < pos_lds_cap in LDS, the rest in the global overflow arrays (one wavefront appends to and
+     * re-reads them: the list accessors of the var events).  `b` = the 64-aligned base of the chunk `i` belongs to. ---- */
+    CBC_MFN V32 ptab_ld(const uint32_t *t_lds, const uint32_t *t_ov, uint32_t b, V32 i, Mask m, uint32_t other)
+    {
+        if (b < pos_lds_cap) return W::load32(t_lds, i, m, other);
+        return W::load32_list(t_ov, i - pos_lds_cap, m, other);
+    }
+    CBC_MFN void ptab_st(uint32_t *t_lds, uint32_t *t_ov, uint32_t b, V32 i, V32 v, Mask m)
+    {
+        if (b < pos_lds_cap) W::store32(t_lds, i, v, m);
+        else W::store32_list(t_ov, i - pos_lds_cap, v, m);
+    }
+    CBC_MFN uint32_t ptab_rd(const uint32_t *t_lds, const uint32_t *t_ov, uint32_t idx)
+    {
+        if (idx < pos_lds_cap) return W::read_uni(t_lds, idx);
+        W::list_fence();
+        return W::readlane(W::load32_list(t_ov, W::splat(idx - pos_lds_cap), W::all(), 0u), 0u);
+    }
+    CBC_MFN void ptab_wr(uint32_t *t_lds, uint32_t *t_ov, uint32_t idx, uint32_t v)
+    {
+        if (idx < pos_lds_cap) W::write_uni(t_lds, idx, v);
+        else W::append_list(t_ov, idx - pos_lds_cap, v);
+    }
+    /* compress_pos_alpha in its general form: four dense 256-symbol models, step 10 (sam_models.c:164-202) */
+    CBC_MFN void pos_alpha_dense(uint32_t x)
+    {
+        dense_code(palpha, 256u, 10u, x >> 24, pa_n0);
+        dense_code(palpha + 256u, 256u, 10u, (x >> 16) & 0xffu, pa_n1);
+        dense_code(palpha + 512u, 256u, 10u, (x >> 8) & 0xffu, pa_n2);
+        dense_code(palpha + 768u, 256u, 10u, x & 0xffu, pa_n3);
+    }
+
+    /* ---- flag in its general form (compress_flag read_compression.c:50-70; the whole-file stream): the first CBC_CAP_FLAG
+     * distinct values as (value, excess) register pairs, any further ones as pairs in global memory; cum(x) = x + the excess
+     * of every smaller value seen, whichever side holds it ---- */
+    CBC_MFN void flag_gen_code(uint32_t x, uint32_t &n)
+    {
+        const V32 ln = W::lane();
+        Mask live = ln < fcount;
+        V32 acc = W::select(live & (fkey < x), fexc, W::splat(0u));
+        const uint64_t eq = W::ballot(live & (fkey == x));
+        uint32_t idx = 0, cnt = 1u, sp_idx = CBC_NOMEMO;
+        if (eq) { idx = W::ctz64(eq); cnt = 1u + W::readlane(fexc, idx); }
+        if (fsp_count) {
+            W::list_fence();
+            const uint32_t nb = W::uni(fsp_count);
+            for (uint32_t b = 0; b < nb; b += 64u) {
+                const V32 i = ln + b; const Mask m = i < fsp_count;
+                const V32 k = W::load32_list(fsp_key, i, m, 0xffffffffu), e = W::load32_list(fsp_exc, i, m, 0u);
+                acc = acc + W::select(m & (k < x), e, W::splat(0u));
+                const uint64_t hit = W::ballot(m & (k == x));
+                if (hit) { const uint32_t hl = W::ctz64(hit); sp_idx = b + hl; cnt = 1u + W::readlane(e, hl); }
+            }
+        }
+        if (x >= 65536u) { fail(CBC_ST_ASSERT); return; }
+        encode(x + W::reduce_add(acc), cnt, n);
+        if (eq) fexc = W::select(ln == idx, fexc + 8u, fexc);
+        else if (sp_idx != CBC_NOMEMO) W::append_list(fsp_exc, sp_idx, cnt - 1u + 8u);
+        else if (fcount < CBC_CAP_FLAG) {
+            fkey = W::select(ln == fcount, W::splat(x), fkey);
+            fexc = W::select(ln == fcount, W::splat(8u), fexc);
+            fcount++;
+        } else {
+            if (fsp_key == nullptr || fsp_count >= 65536u) { fail(CBC_ST_CAP_FLAG); return; }
+            W::append_list(fsp_key, fsp_count, x); W::append_list(fsp_exc, fsp_count, 8u);
+            fsp_count++;
+        }
+        n += 8u;
+        if (n >= CBC_RESCALE) {                               /* update_model stream_model.c:41-48 on e = count - 1 */
+            live = ln < fcount;
+            fexc = W::select(live, (fexc + 1u) >> 1, fexc);
+            V32 a = W::select(live, fexc, W::splat(0u));
+            if (fsp_count) {
+                W::list_fence();
+                const uint32_t nb = W::uni(fsp_count);
+                for (uint32_t b = 0; b < nb; b += 64u) {
+                    const V32 i = ln + b; const Mask m = i < fsp_count;
+                    const V32 e = (W::load32_list(fsp_exc, i, m, 0u) + 1u) >> 1;
+                    W::store32_list(fsp_exc, i, e, m);
+                    a = a + W::select(m, e, W::splat(0u));
+                }
+            }
+            n = 65536u + W::reduce_add(a);
+        }
+    }
+
     /* ---- pos alphabet bytes: compress_pos_alpha (read_compression.c:75-108).  The four 256-symbol
      * models only ever see the bytes of the values already registered in the alphabet, so their state
      * is recomputed from it: count(b) = 1 + 10 * #{registered v : byte_k(v) == b}.  `card` is the
@@ -890,15 +984,16 @@ struct CbcEnc {
     CBC_MFN void pos_lit_update(uint32_t idx, uint32_t &pos_n)
     {
         const V32 ln = W::lane();
-        W::write_uni(pos_occ, idx, W::read_uni(pos_occ, idx) + 10u);
+        ptab_wr(pos_occ, pos_ov_occ, idx, ptab_rd(pos_occ, pos_ov_occ, idx) + 10u);
         pos_n += 10u;
         if (pos_n >= CBC_RESCALE) {
             V32 a = W::splat(0u);
             const uint32_t cb = W::uni(pos_card);
+            if (pos_card > pos_lds_cap) W::list_fence();
             for (uint32_t b = 0; b < cb; b += 64u) {
                 V32 i = ln + b; Mask m = i < pos_card;
-                V32 c = (W::load32(pos_occ, i, m, 0u) >> 1) + 1u;
-                W::store32(pos_occ, i, c, m);
+                V32 c = (ptab_ld(pos_occ, pos_ov_occ, b, i, m, 0u) >> 1) + 1u;
+                ptab_st(pos_occ, pos_ov_occ, b, i, c, m);
                 a = a + W::select(m, c, W::splat(0u));
             }
             pos_n = W::reduce_add(a);
@@ -909,25 +1004,27 @@ struct CbcEnc {
         const V32 ln = W::lane();
         uint32_t idx = 0;
         const uint32_t cb = W::uni(pos_card);
+        if (pos_card > pos_lds_cap) W::list_fence();
         for (uint32_t b = 0; b < cb; b += 64u) {
             V32 i = ln + b;
-            V32 v = W::load32(pos_val, i, (i != 0u) & (i < pos_card), 0xffffffffu);
+            V32 v = ptab_ld(pos_val, pos_ov_val, b, i, (i != 0u) & (i < pos_card), 0xffffffffu);
             uint64_t hit = W::ballot(v == x);
             if (hit) { idx = b + W::ctz64(hit); break; }
         }
         if (idx) {
             V32 a = W::splat(0u);
             const uint32_t ib = W::uni(idx);
-            for (uint32_t b = 0; b < ib; b += 64u) { V32 i = ln + b; a = a + W::load32(pos_occ, i, i < idx, 0u); }
-            encode(W::reduce_add(a), W::read_uni(pos_occ, idx), pos_n);
+            for (uint32_t b = 0; b < ib; b += 64u) { V32 i = ln + b; a = a + ptab_ld(pos_occ, pos_ov_occ, b, i, i < idx, 0u); }
+            encode(W::reduce_add(a), ptab_rd(pos_occ, pos_ov_occ, idx), pos_n);
             pos_lit_update(idx, pos_n);
             return;
         }
         if (pos_card >= cap_pos) { fail(CBC_ST_CAP_POS); return; }
         encode(0u, W::read_uni(pos_occ, 0u), pos_n);
         pos_lit_update(0u, pos_n);
-        pos_alpha(x, pos_card);                                /* the four byte models, derived from the registered values */
-        W::write_uni(pos_val, pos_card, x); W::write_uni(pos_occ, pos_card, 0u);
+        if (palpha) pos_alpha_dense(x);                         /* the four byte models: dense with their rescale (whole-file stream) */
+        else pos_alpha(x, pos_card);                           /* ... or derived from the registered values */
+        ptab_wr(pos_val, pos_ov_val, pos_card, x); ptab_wr(pos_occ, pos_ov_occ, pos_card, 0u);
         pos_card++;
         pos_lit_update(pos_card - 1u, pos_n);                  /* update_model(P, alphabetCard++) without a send (:153) */
     }
@@ -1425,6 +1522,7 @@ CBC_FN void cbc_encode_stream(const cbc_enc_args &A, uint32_t blk, uint32_t *lds
     E.rname_key = lds + CBC_LDS_RNKEY; E.rname_exc = lds + CBC_LDS_RNEXC;
     E.bloom = lds + CBC_LDS_BLOOM; E.p0ev = lds + CBC_LDS_P0;
     E.pos_val = lds + CBC_LDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = E.pos_occ + A.cap_pos;
+    E.fsp_key = E.fsp_exc = nullptr; E.fsp_count = 0; E.pos_ov_val = E.pos_ov_occ = nullptr; E.pos_lds_cap = 0xffffffc0u; E.palpha = nullptr;
     E.pos_idx = E.pos_pre + A.cap_pos;
     E.cap_pos = A.cap_pos;
     if (ROLE != CBC_ROLE_MODEL) {

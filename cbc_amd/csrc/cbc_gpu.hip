@@ -936,9 +936,10 @@ static int stream_encode(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, int per_seg
     cbc_stream_caps caps; caps.cap_pos = hb->caps.cap_pos < 64 ? 64 : hb->caps.cap_pos; caps.cap_name = hb->names_bytes + 2u * (per_segment ? 1u : nb) + 16u;
     const uint32_t lds = cbc_stream_lds_bytes(&caps);
     int rc = CBC_OK;
-    void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_segs = NULL, *d_out = NULL, *d_res = NULL, *d_vtab = NULL;
+    void *d_recs = NULL, *d_seq = NULL, *d_tok = NULL, *d_names = NULL, *d_segs = NULL, *d_out = NULL, *d_res = NULL, *d_vtab = NULL, *d_aux = NULL;
     const uint64_t ntok = hb->n_tok ? hb->n_tok : 1;
     uint32_t grid = n_streams < 32u ? n_streams : 32u;            /* pool of var tables: 67 MB each */
+    if (caps.cap_pos > CBC_STREAM_POS_MAX) { free(segs); free(res); return set_err(ctx, CBC_E_ARG, "cap_pos beyond MAX_ALPHA", hipSuccess); }
     if (lds > 160u * 1024u) { free(segs); free(res); return set_err(ctx, CBC_E_ARG, "stream tables need more than 160 KiB of LDS", hipSuccess); }
 #define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
     GO(hipMalloc(&d_recs, hb->n_recs * sizeof(cbc_read_rec) + 16), "hipMalloc recs");
@@ -950,6 +951,7 @@ static int stream_encode(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, int per_seg
     GO(hipMalloc(&d_res, (uint64_t)n_streams * sizeof(cbc_block_result)), "hipMalloc results");
     GO(hipMalloc(&d_vtab, (uint64_t)grid * CBC_VTAB_WORDS * 4), "hipMalloc var tables");
     GO(hipMemsetAsync(d_vtab, 0, (uint64_t)grid * CBC_VTAB_WORDS * 4, ctx->stream), "memset var tables");
+    GO(hipMalloc(&d_aux, (uint64_t)grid * cbc_stream_aux_words(caps.cap_pos) * 4), "hipMalloc flag / pos overflow tables");
     GO(hipMemcpyAsync(d_recs, hb->recs, hb->n_recs * sizeof(cbc_read_rec), hipMemcpyHostToDevice, ctx->stream), "H2D recs");
     GO(hipMemcpyAsync(d_seq, hb->seq, hb->seq_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D seq");
     GO(hipMemcpyAsync(d_tok, hb->tok, hb->n_tok * 4, hipMemcpyHostToDevice, ctx->stream), "H2D tok");
@@ -961,7 +963,7 @@ static int stream_encode(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, int per_seg
         memset(&A, 0, sizeof A);
         A.recs = (const cbc_read_rec *)d_recs; A.seq = (const uint8_t *)d_seq; A.tok = (const uint32_t *)d_tok;
         A.names = (const uint8_t *)d_names; A.segs = (const cbc_block_desc *)d_segs; A.ref = ctx->d_ref;
-        A.out = (uint8_t *)d_out; A.results = (cbc_block_result *)d_res; A.vtab = (uint32_t *)d_vtab;
+        A.out = (uint8_t *)d_out; A.results = (cbc_block_result *)d_res; A.vtab = (uint32_t *)d_vtab; A.aux = (uint32_t *)d_aux;
         A.ref_bytes = ctx->ref_bytes; A.out_bytes = scratch; A.seq_bytes = hb->seq_bytes; A.n_tok = ntok; A.n_recs = hb->n_recs;
         A.n_segs = nb; A.cap_pos = caps.cap_pos; A.cap_name = caps.cap_name; A.names_bytes = hb->names_bytes;
         A.per_segment = per_segment ? 1u : 0u; A.n_vtab = grid;
@@ -995,7 +997,7 @@ done:
     free(segs); free(res);
     if (d_recs) (void)hipFree(d_recs); if (d_seq) (void)hipFree(d_seq); if (d_tok) (void)hipFree(d_tok);
     if (d_names) (void)hipFree(d_names); if (d_segs) (void)hipFree(d_segs); if (d_out) (void)hipFree(d_out);
-    if (d_res) (void)hipFree(d_res); if (d_vtab) (void)hipFree(d_vtab);
+    if (d_res) (void)hipFree(d_res); if (d_vtab) (void)hipFree(d_vtab); if (d_aux) (void)hipFree(d_aux);
     return rc;
 }
 
@@ -1021,9 +1023,11 @@ API int cbc_gpu_decode_stream(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
     if (L0 < 1 || L0 > 256 || seq_stride < 4 || seq_stride > 256 || (seq_stride & 3u) || rec_cap == 0 || rec_cap > 0xffffffffull ||
         seq_bytes < rec_cap * seq_stride + 8) return set_err(ctx, CBC_E_ARG, "bad stream header or buffer sizes", hipSuccess);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
-    cbc_stream_caps caps; caps.cap_pos = 8192; caps.cap_name = 2048;
+    /* the stream does not say how many distinct POS steps it holds: room for the reference's whole alphabet (MAX_ALPHA),
+     * CBC_STREAM_POS_LDS entries of it in LDS, the rest in the aux area (40 MB) */
+    cbc_stream_caps caps; caps.cap_pos = CBC_STREAM_POS_MAX; caps.cap_name = 2048;
     const uint32_t lds = cbc_stream_lds_bytes(&caps);
-    void *d_in = NULL, *d_co = NULL, *d_cl = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL, *d_vtab = NULL;
+    void *d_in = NULL, *d_co = NULL, *d_cl = NULL, *d_recs = NULL, *d_seq = NULL, *d_res = NULL, *d_vtab = NULL, *d_aux = NULL;
     cbc_block_result res; memset(&res, 0xff, sizeof res);
     int rc = CBC_OK;
 #define GO(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = set_err(ctx, CBC_E_NODEV, what, e_); goto done; } } while (0)
@@ -1035,6 +1039,7 @@ API int cbc_gpu_decode_stream(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
     GO(hipMalloc(&d_res, sizeof(cbc_block_result)), "hipMalloc result");
     GO(hipMalloc(&d_vtab, CBC_VTAB_WORDS * 4), "hipMalloc var table");
     GO(hipMemsetAsync(d_vtab, 0, CBC_VTAB_WORDS * 4, ctx->stream), "memset var table");
+    GO(hipMalloc(&d_aux, cbc_stream_aux_words(caps.cap_pos) * 4), "hipMalloc flag / pos overflow tables");
     GO(hipMemsetAsync((uint8_t *)d_in + in_bytes, 0, 16, ctx->stream), "memset pad");
     GO(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D stream");
     GO(hipMemcpyAsync(d_co, contig_off, (uint64_t)n_contigs * 8, hipMemcpyHostToDevice, ctx->stream), "H2D contigs");
@@ -1045,6 +1050,7 @@ API int cbc_gpu_decode_stream(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
         memset(&A, 0, sizeof A);
         A.in = (const uint8_t *)d_in; A.ref = ctx->d_ref; A.contig_off = (const uint64_t *)d_co; A.contig_len = (const uint64_t *)d_cl;
         A.recs = (cbc_read_rec *)d_recs; A.seq = (uint8_t *)d_seq; A.results = (cbc_block_result *)d_res; A.vtab = (uint32_t *)d_vtab;
+        A.aux = (uint32_t *)d_aux;
         A.in_bytes = in_bytes; A.ref_bytes = ctx->ref_bytes; A.rec_cap = rec_cap; A.seq_bytes = seq_bytes + 16;
         A.n_contigs = n_contigs; A.cap_pos = caps.cap_pos; A.cap_name = caps.cap_name; A.seq_stride = seq_stride; A.read_length = L0;
         GO(hipEventRecord(ctx->ev0, ctx->stream), "hipEventRecord");
@@ -1068,7 +1074,7 @@ API int cbc_gpu_decode_stream(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_b
 done:
 #undef GO
     if (d_in) (void)hipFree(d_in); if (d_co) (void)hipFree(d_co); if (d_cl) (void)hipFree(d_cl); if (d_recs) (void)hipFree(d_recs);
-    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vtab) (void)hipFree(d_vtab);
+    if (d_seq) (void)hipFree(d_seq); if (d_res) (void)hipFree(d_res); if (d_vtab) (void)hipFree(d_vtab); if (d_aux) (void)hipFree(d_aux);
     return rc;
 }
 

@@ -88,6 +88,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     E.rlen_exc = lds + CBC_LLDS_LEN; E.snps_exc = nullptr; E.indels_exc = nullptr;
     E.rname_key = lds + CBC_LLDS_RNKEY; E.rname_exc = lds + CBC_LLDS_RNEXC; E.rn_cap = CBC_CAP_NAME; E.rn_count = 0;
     E.pos_val = lds + CBC_LLDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = nullptr; E.cap_pos = A.cap_pos;
+    E.fsp_key = E.fsp_exc = nullptr; E.fsp_count = 0; E.pos_ov_val = E.pos_ov_occ = nullptr; E.pos_lds_cap = 0xffffffc0u; E.palpha = nullptr;
     E.bloom = nullptr; E.var_ev = nullptr; E.nev = E.nev1 = 0; E.cap_var = 0; E.vtab = nullptr; E.p0ev = nullptr;
     E.p0cnt = W::splat(0u); E.p0over = 0;
     for (uint32_t b = 0; b < CBC_LLDS_RING + CBC_RING_WORDS; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
@@ -263,6 +264,7 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = 0; D.L0 = 256u; D.evp = nullptr; D.vtab = nullptr;
     D.rname_key = lds + CBC_LLDS_RNKEY; D.rname_exc = lds + CBC_LLDS_RNEXC; D.rn_cap = CBC_CAP_NAME; D.histp = lds + CBC_LLDS_HIST;
     D.pos_valp = lds + CBC_LLDS_FIXED; D.pos_cntp = D.pos_valp + A.cap_pos;
+    D.fsp_key = D.fsp_exc = nullptr; D.fsp_count = 0; D.pos_ov_valp = D.pos_ov_cntp = nullptr; D.pos_lds_cap = 0xffffffc0u; D.palpha = nullptr;
     bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
                    cbc_fits64(seq_base, (uint64_t)blk_bases + 8u, A.seq_bytes) && cbc_le64(ref_off, A.ref_bytes) && A.cap_pos >= 2u;
     D.nwords_in = (in_bytes + 3u) >> 2;

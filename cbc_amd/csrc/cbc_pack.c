@@ -66,6 +66,7 @@ typedef struct {
     int seg_continues;             /* whole-file mode: the segment being opened continues the previous one's contig */
     uint64_t blk_bases;
     uint16_t blk_flags[CBC_CAP_FLAG];
+    uint8_t *wf_seen;                                  /* whole-file mode: one bit per POS step below MAX_ALPHA seen so far */
     uint32_t *dset; uint32_t *dstamp; uint32_t dmask, depoch;   /* distinct-delta hash set */
     char edits[2 * LINE_BUF];      /* persists across records like read_line_t.edits */
     uint32_t tokbuf[4 * LINE_BUF];
@@ -507,13 +508,11 @@ static int place_record(packer_t *S, uint32_t pos, uint32_t flag, size_t rl, uin
         if (x >= 5000000u)
             return fail(S, CBC_E_INPUT, "POS step of 5 000 000 or more at %s:%lld: outside the reference's pos alphabet (MAX_ALPHA); use block mode", rname, pos);
         if (need_new) { close_block(S); int rc = open_block(S, pos); if (rc) return rc; }
-        if (!delta_seen(S, x, 1)) { S->blk_ndelta++; if (S->blk_ndelta + 3 > S->o.max_cap_pos) return fail(S, CBC_E_INPUT, "more than %s%lld distinct POS steps in one file: beyond the whole-file stream kernel's table; use block mode", "", (long long)S->o.max_cap_pos - 3); }
-        int newflag = 1;
-        for (uint32_t i = 0; i < S->blk_nflags; i++) if (S->blk_flags[i] == (uint16_t)flag) { newflag = 0; break; }
-        if (newflag) {
-            if (S->blk_nflags >= CBC_CAP_FLAG) return fail(S, CBC_E_INPUT, "more than %s%lld distinct FLAG values in one file; use block mode", "", (long long)CBC_CAP_FLAG);
-            S->blk_flags[S->blk_nflags++] = (uint16_t)flag;
-        }
+        /* every POS step below MAX_ALPHA and every 16-bit FLAG is in the reference's tables (sam_block.h:54-55,
+         * sam_models.c:96-130), so the whole-file stream takes them all: the stream kernels keep what does not fit their
+         * registers / LDS in global memory.  The distinct steps are counted exactly (one bit per possible step): the
+         * count sizes the kernels' pos tables. */
+        if (!(S->wf_seen[x >> 3] & (1u << (x & 7u)))) { S->wf_seen[x >> 3] |= (uint8_t)(1u << (x & 7u)); S->blk_ndelta++; }
         goto record;
     }
     if (S->blk_open) {
@@ -697,7 +696,7 @@ static int packer_init(packer_t *S, const cbc_pack_opts *opts, char *errbuf, siz
     if (S->o.block_reads > CBC_MAX_BLOCK_READS) S->o.block_reads = CBC_MAX_BLOCK_READS;
     if (S->o.max_cap_pos < 64) S->o.max_cap_pos = 2048;
     if (S->o.max_cap_var < 64) S->o.max_cap_var = 8192;
-    if (S->o.whole_file) S->o.max_cap_pos = 8192;                  /* the stream kernel's pos table (cbc_stream_body.h) */
+    if (S->o.whole_file) S->o.max_cap_pos = 8192;                  /* (sizes the hash set below, which whole-file mode does not use) */
     if (S->o.max_cap_pos > 4096 && !S->o.whole_file) S->o.max_cap_pos = 4096;
     if (S->o.max_cap_var > 32768) S->o.max_cap_var = 32768;       /* keeps L0 + 10*uses < 2^20 */
     S->err = errbuf; S->errlen = errlen;
@@ -710,9 +709,13 @@ static int packer_init(packer_t *S, const cbc_pack_opts *opts, char *errbuf, siz
     S->dstamp = (uint32_t *)calloc(sz, sizeof(uint32_t));
     if (!S->dset || !S->dstamp) return CBC_E_NOMEM;
     S->depoch = 1;                                  /* stamps start at 0 = "never used" */
+    if (S->o.whole_file) {
+        S->wf_seen = (uint8_t *)calloc(5000000u / 8u + 1u, 1);
+        if (!S->wf_seen) return CBC_E_NOMEM;
+    }
     return 0;
 }
-static void packer_release(packer_t *S) { free(S->dset); free(S->dstamp); }
+static void packer_release(packer_t *S) { free(S->dset); free(S->dstamp); free(S->wf_seen); }
 
 API void cbc_pack_default_opts(cbc_pack_opts *o)
 {

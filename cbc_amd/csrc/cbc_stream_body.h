@@ -44,10 +44,25 @@
 #define CBC_SLDS_DEC_DELS (768u + 80u)
 #define CBC_SLDS_DEC_INS  (768u + 336u)
 #define CBC_SLDS_DEC_HIST (768u + 592u)
-#define CBC_SLDS_FIXED   (768u + 1104u)
+#define CBC_SLDS_PALPHA  (768u + 1104u)   /* 1024: the four pos_alpha byte models as dense excess tables */
+#define CBC_SLDS_FIXED   (768u + 1104u + 1024u)
 
+/* What the reference's tables hold and no LDS budget does lives in global memory ("aux", one area per stream slot):
+ *   flag   65536 (value, excess) pairs beyond the register pairs           (sam_models.c:96-130: a 65536-entry table)
+ *   pos    alphabet entries beyond the CBC_STREAM_POS_LDS held in LDS      (sam_block.h:54-55: MAX_ALPHA / MAX_CARDINALITY)
+ * aux layout, in words: [flag value 65536][flag excess 65536][pos value pos_ov][pos count pos_ov] */
+#define CBC_STREAM_POS_LDS 8192u          /* pos alphabet entries in LDS (a multiple of 64); the packer's cap_pos may exceed it */
+#define CBC_STREAM_POS_MAX 5000000u       /* MAX_ALPHA: no POS step, hence no alphabet entry, beyond it */
 struct cbc_stream_caps { uint32_t cap_pos, cap_name; };
-static inline uint32_t cbc_stream_lds_bytes(const cbc_stream_caps *c) { return 4u * (CBC_SLDS_FIXED + 2u * c->cap_name + 2u * c->cap_pos); }
+#ifdef __HIPCC__
+#define CBC_SHD __host__ __device__ static inline
+#else
+#define CBC_SHD static inline
+#endif
+CBC_SHD uint32_t cbc_stream_pos_lds(uint32_t cap_pos) { return cap_pos < CBC_STREAM_POS_LDS ? ((cap_pos + 63u) & ~63u) : CBC_STREAM_POS_LDS; }
+CBC_SHD uint32_t cbc_stream_pos_ov(uint32_t cap_pos) { return cap_pos > CBC_STREAM_POS_LDS ? cap_pos - CBC_STREAM_POS_LDS : 0u; }
+CBC_SHD uint64_t cbc_stream_aux_words(uint32_t cap_pos) { return 2ull * 65536ull + 2ull * cbc_stream_pos_ov(cap_pos) + 64ull; }
+static inline uint32_t cbc_stream_lds_bytes(const cbc_stream_caps *c) { return 4u * (CBC_SLDS_FIXED + 2u * c->cap_name + 2u * cbc_stream_pos_lds(c->cap_pos)); }
 
 struct cbc_stream_args {
     const cbc_read_rec   *recs;
@@ -59,6 +74,7 @@ struct cbc_stream_args {
     uint8_t              *out;
     cbc_block_result     *results;      /* one per stream */
     uint32_t             *vtab;         /* n_vtab tables of 65535 * 256 words, zero-filled by the caller */
+    uint32_t             *aux;          /* n_vtab areas of cbc_stream_aux_words(cap_pos) words (no initial content needed) */
     uint64_t ref_bytes, out_bytes, seq_bytes, n_tok, n_recs;
     uint32_t n_segs, cap_pos, cap_name, names_bytes, per_segment, n_vtab;
 };
@@ -87,17 +103,26 @@ CBC_FN void cbc_encode_whole(const cbc_stream_args &A, uint32_t stream, uint32_t
     E.out32 = (uint32_t *)(A.out + out_off);
     E.cap_words = out_cap >> 2;
     bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0u) && (L0 >= 1u && L0 <= 256u) &&
-                   (slot < A.n_vtab) && (A.cap_pos >= 2u) && (A.cap_name >= 4u) && (seg0 < A.n_segs);
+                   (slot < A.n_vtab) && (A.cap_pos >= 2u) && (A.cap_pos <= CBC_STREAM_POS_MAX) && (A.cap_name >= 4u) && (seg0 < A.n_segs) &&
+                   (A.aux != nullptr);
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
 
     /* ---- model tables ---- */
     E.L0 = L0;
     E.rlen_exc = lds + CBC_SLDS_RLEN; E.snps_exc = lds + CBC_SLDS_SNPS; E.indels_exc = lds + CBC_SLDS_INDELS;
     E.rname_key = lds + CBC_SLDS_FIXED; E.rname_exc = E.rname_key + A.cap_name; E.rn_cap = A.cap_name; E.rn_count = 0;
-    E.pos_val = E.rname_exc + A.cap_name; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = nullptr; E.cap_pos = A.cap_pos;
+    const uint32_t pos_lds = cbc_stream_pos_lds(A.cap_pos);
+    E.pos_val = E.rname_exc + A.cap_name; E.pos_occ = E.pos_val + pos_lds; E.pos_pre = nullptr; E.cap_pos = A.cap_pos;
+    {   /* the global-memory sides of flag and pos (this stream's aux area), the dense pos_alpha tables */
+        uint32_t *aux = A.aux + (uint64_t)slot * cbc_stream_aux_words(A.cap_pos);
+        E.fsp_key = aux; E.fsp_exc = aux + 65536u; E.fsp_count = 0;
+        E.pos_ov_val = aux + 131072u; E.pos_ov_occ = E.pos_ov_val + cbc_stream_pos_ov(A.cap_pos); E.pos_lds_cap = pos_lds;
+        E.palpha = lds + CBC_SLDS_PALPHA; E.pa_n0 = E.pa_n1 = E.pa_n2 = E.pa_n3 = 256u;
+    }
     E.bloom = nullptr; E.var_ev = nullptr; E.nev = E.nev1 = 0; E.cap_var = 0;
     E.vtab = A.vtab + (uint64_t)slot * CBC_VTAB_WORDS;
     for (uint32_t b = 0; b < CBC_SLDS_RING + CBC_RING_WORDS; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
+    for (uint32_t b = 0; b < 1024u; b += 64u) W::store32(lds + CBC_SLDS_PALPHA, ln + b, W::splat(0u), W::all());
     W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);      /* the escape: counts[0] = 1 (sam_models.c:132-162) */
     E.p0cnt = W::splat(0u); E.p0over = 0; E.p0ev = nullptr;
     E.snps_n = L0; E.indels_n = L0;
@@ -215,7 +240,7 @@ CBC_FN void cbc_encode_whole(const cbc_stream_args &A, uint32_t stream, uint32_t
                 E.pos_lit_code(x, pos_n);
                 E.prevPos = pos;
                 /* -- compress_flag, compress_match -- */
-                E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);
+                E.flag_gen_code(flw & 0xffffu, flag_n);
                 const uint32_t imperfect = (uint32_t)((neq >> j) & 1ull);
                 E.small_code(CBC_LT_MATCH + (((x == 1u) ? 2u : 0u) | E.prevM) * 2u, 2u, 1u, imperfect ^ 1u);
                 E.prevM = imperfect ^ 1u;
@@ -260,6 +285,7 @@ struct cbc_dstream_args {
     uint8_t        *seq;
     cbc_block_result *results;
     uint32_t       *vtab;
+    uint32_t       *aux;                       /* cbc_stream_aux_words(cap_pos) words */
     uint64_t in_bytes, ref_bytes, rec_cap, seq_bytes;
     uint32_t n_contigs, cap_pos, cap_name, seq_stride, read_length;
 };
@@ -278,10 +304,14 @@ CBC_FN void cbc_decode_whole(const cbc_dstream_args &A, uint32_t *lds)
     D.inb = A.in;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = 0; D.L0 = L0; D.evp = nullptr;
     D.rname_key = lds + CBC_SLDS_FIXED; D.rname_exc = D.rname_key + A.cap_name; D.rn_cap = A.cap_name;
-    D.pos_valp = D.rname_exc + A.cap_name; D.pos_cntp = D.pos_valp + A.cap_pos; D.histp = lds + CBC_SLDS_DEC_HIST;
+    const uint32_t pos_lds = cbc_stream_pos_lds(A.cap_pos);
+    D.pos_valp = D.rname_exc + A.cap_name; D.pos_cntp = D.pos_valp + pos_lds; D.histp = lds + CBC_SLDS_DEC_HIST;
+    D.fsp_key = A.aux; D.fsp_exc = A.aux + 65536u; D.fsp_count = 0;
+    D.pos_ov_valp = A.aux + 131072u; D.pos_ov_cntp = D.pos_ov_valp + cbc_stream_pos_ov(A.cap_pos); D.pos_lds_cap = pos_lds;
+    D.palpha = lds + CBC_SLDS_PALPHA; D.pa_n0 = D.pa_n1 = D.pa_n2 = D.pa_n3 = 256u;
     D.vtab = A.vtab;
     bool args_ok = (L0 >= 1u && L0 <= 256u) && (stride >= 4u && stride <= 256u && (stride & 3u) == 0u) && A.n_contigs >= 1u &&
-                   A.cap_pos >= 2u && A.cap_name >= 4u && cbc_le64(A.in_bytes, 0x3fffffff0ull) &&
+                   A.cap_pos >= 2u && A.cap_pos <= CBC_STREAM_POS_MAX && A.aux != nullptr && A.cap_name >= 4u && cbc_le64(A.in_bytes, 0x3fffffff0ull) &&
                    cbc_le64(A.rec_cap, 0xffffffffull) && cbc_le64(A.rec_cap * (uint64_t)stride + 8u, A.seq_bytes);
     D.nwords_in = (uint32_t)((A.in_bytes + 3u) >> 2);
     D.tail_valid = (uint32_t)A.in_bytes & 3u;
@@ -378,7 +408,7 @@ CBC_FN void cbc_decode_whole(const cbc_dstream_args &A, uint32_t *lds)
         if (pos < D.prevPos) { D.fail(CBC_ST_ASSERT); break; }
         D.win_shift(x - 1u > 256u ? 256u : x - 1u);
         D.prevPos = pos;
-        uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
+        uint32_t flag = D.flag_gen_dec();
         if (D.status != CBC_ST_OK) break;
         const uint32_t strand = (flag >> 4) & 1u;
         if (pos == 0u || pos > ref_lim || ref_lim - pos < rl + 3u + 256u) { D.fail(CBC_ST_ASSERT); break; }

@@ -391,25 +391,25 @@ class Encoder:
         """Decode a whole-file stream against the uploaded reference; contigs = the packer's contig table
         (ref_off / length in FASTA order).  Retries with larger buffers while the kernel reports OUT_FULL."""
         L0 = int(lib().cbc_stream_read_length(stream, len(stream)))
-        stride = (max(L0, 4) + 3) // 4 * 4
-        stride = min(256, max(stride, 256 if L0 > 252 else stride))
+        stride = min(256, (max(L0, 4) + 3) // 4 * 4)                # rows of the header read length (quirk Q7: fixed-length input)
         buf = np.frombuffer(stream, dtype=np.uint8)
         co = np.ascontiguousarray(contigs["ref_off"], dtype=np.uint64)
         cl = np.ascontiguousarray(contigs["length"], dtype=np.uint64)
-        cap = int(rec_cap) if rec_cap else max(1 << 16, 2 * len(stream))
+        cap = int(rec_cap) if rec_cap else max(1 << 16, len(stream))   # files run at 1.4 - 2 bytes per read
         while True:
+            cap = min(cap, 0xffffffff)
             recs = np.zeros(cap, dtype=host.REC_DTYPE)
-            seq = np.zeros(cap * 256 + 8, dtype=np.uint8)
+            seq = np.zeros(cap * stride + 8, dtype=np.uint8)
             sr = StreamResult()
             rc = lib().cbc_gpu_decode_stream(self._ctx, buf.ctypes.data, buf.size, co.ctypes.data, cl.ctypes.data, len(co),
-                                             recs.ctypes.data, cap, seq.ctypes.data, seq.size, 256, ctypes.byref(sr))
-            if rc == -4 and sr.status == 1 and cap < (1 << 31):      # OUT_FULL: more records than the buffers hold
-                cap *= 4
+                                             recs.ctypes.data, cap, seq.ctypes.data, seq.size, stride, ctypes.byref(sr))
+            if rc == -4 and sr.status == 1 and cap < 0xffffffff:     # OUT_FULL: more records than the buffers hold
+                cap *= 2
                 continue
             if rc != 0 and rc != -4:
                 self._check(rc, "cbc_gpu_decode_stream")
             n = int(sr.nbytes) if sr.status == 0 else 0
-            return recs[:n], seq[:n * 256].reshape(n, 256), sr
+            return recs[:n], seq[:n * stride].reshape(n, stride), sr
 
     def encode_long_blocks(self, pb: "host.PackedBatch"):
         """Long-read format (pb packed with long_reads=True).  Returns (payload list, results, offsets, flat)."""

@@ -159,11 +159,19 @@ def mapped_sam_lines(sam: bytes):
     return out
 
 
+STREAM_POS_LDS, STREAM_POS_MAX = 8192, 5_000_000         # cbc_stream_body.h
+
+
+def stream_aux_words(cap_pos):
+    """cbc_stream_aux_words(): flag pairs + the pos alphabet beyond the LDS part, per stream slot."""
+    return 2 * 65536 + 2 * max(cap_pos - STREAM_POS_LDS, 0) + 64
+
+
 class StreamArgs(ctypes.Structure):
     """cbc_stream_args of cbc_amd/csrc/cbc_stream_body.h."""
     _fields_ = [("recs", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("tok", ctypes.c_void_p), ("names", ctypes.c_void_p),
                 ("segs", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("out", ctypes.c_void_p), ("results", ctypes.c_void_p),
-                ("vtab", ctypes.c_void_p),
+                ("vtab", ctypes.c_void_p), ("aux", ctypes.c_void_p),
                 ("ref_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64), ("seq_bytes", ctypes.c_uint64),
                 ("n_tok", ctypes.c_uint64), ("n_recs", ctypes.c_uint64),
                 ("n_segs", ctypes.c_uint32), ("cap_pos", ctypes.c_uint32), ("cap_name", ctypes.c_uint32),
@@ -188,10 +196,12 @@ def emu_encode_stream(pb, per_segment=False):
     out = np.full(off, 0xAA, dtype=np.uint8)
     res = np.zeros(n_streams, dtype=host.RESULT_DTYPE)
     vtab = np.zeros(65535 * 256, dtype=np.uint32)
+    cap_pos = max(pb.cap_pos, 64)
+    aux = np.full(stream_aux_words(cap_pos), 0xA5A5A5A5, dtype=np.uint32)      # needs no initial content
     a = StreamArgs(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data, segs.ctypes.data,
-                   pb.ref.ctypes.data, out.ctypes.data, res.ctypes.data, vtab.ctypes.data,
+                   pb.ref.ctypes.data, out.ctypes.data, res.ctypes.data, vtab.ctypes.data, aux.ctypes.data,
                    len(pb.ref), off, len(pb.seq), pb.n_tok, pb.n_recs,
-                   pb.n_blocks, max(pb.cap_pos, 64), len(pb.names) + 2 * pb.n_blocks + 16, len(pb.names), 1 if per_segment else 0, 1)
+                   pb.n_blocks, cap_pos, len(pb.names) + 2 * pb.n_blocks + 16, len(pb.names), 1 if per_segment else 0, 1)
     if L.emu_encode_stream(ctypes.byref(a)) != 0:
         raise RuntimeError("emulation reported an invariant violation")
     payloads = []
@@ -205,12 +215,13 @@ class DStreamArgs(ctypes.Structure):
     """cbc_dstream_args of cbc_amd/csrc/cbc_stream_body.h."""
     _fields_ = [("in_", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("contig_off", ctypes.c_void_p), ("contig_len", ctypes.c_void_p),
                 ("recs", ctypes.c_void_p), ("seq", ctypes.c_void_p), ("results", ctypes.c_void_p), ("vtab", ctypes.c_void_p),
+                ("aux", ctypes.c_void_p),
                 ("in_bytes", ctypes.c_uint64), ("ref_bytes", ctypes.c_uint64), ("rec_cap", ctypes.c_uint64), ("seq_bytes", ctypes.c_uint64),
                 ("n_contigs", ctypes.c_uint32), ("cap_pos", ctypes.c_uint32), ("cap_name", ctypes.c_uint32),
                 ("seq_stride", ctypes.c_uint32), ("read_length", ctypes.c_uint32)]
 
 
-def emu_decode_stream(stream: bytes, ref, contigs, rec_cap, cap_pos=8192, cap_name=2048):
+def emu_decode_stream(stream: bytes, ref, contigs, rec_cap, cap_pos=STREAM_POS_MAX, cap_name=2048):
     """The whole-file stream decoder body on the CPU wave emulation.  ref/contigs: the packer's reference layout
     (pb.ref, pb.contigs).  Returns (recs, bases[n, stride], result)."""
     L = emu_lib()
@@ -224,8 +235,9 @@ def emu_decode_stream(stream: bytes, ref, contigs, rec_cap, cap_pos=8192, cap_na
     seq = np.zeros(rec_cap * stride + 16, dtype=np.uint8)
     res = np.zeros(1, dtype=host.RESULT_DTYPE)
     vtab = np.zeros(65535 * 256, dtype=np.uint32)
+    aux = np.empty(stream_aux_words(cap_pos), dtype=np.uint32)
     a = DStreamArgs(pay.ctypes.data, ref.ctypes.data, co.ctypes.data, cl.ctypes.data, recs.ctypes.data, seq.ctypes.data,
-                    res.ctypes.data, vtab.ctypes.data, len(stream), len(ref), rec_cap, seq.size, len(co), cap_pos, cap_name, stride, L0)
+                    res.ctypes.data, vtab.ctypes.data, aux.ctypes.data, len(stream), len(ref), rec_cap, seq.size, len(co), cap_pos, cap_name, stride, L0)
     if L.emu_decode_stream(ctypes.byref(a)) != 0:
         raise RuntimeError("emulation reported an invariant violation")
     n = int(res[0]["nbytes"])

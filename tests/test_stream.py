@@ -228,3 +228,92 @@ def test_cli_compat_round_trip(built, tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "reads.txt").read_bytes() == b"".join(w + b"\n" for w in _seq_column(sam))
+
+
+# ------------------------------------------------------------------ what the reference's tables hold and no register / LDS budget does
+PAIRED_FLAGS = tuple(sorted({f | x for f in (65, 81, 83, 97, 99, 113, 129, 145, 147, 161, 163, 177)
+                             for x in (0, 256, 1024, 2048, 512, 1280, 2304, 3072, 768)}))
+
+
+def _with_many_flags(sam, n_first=0):
+    """Rewrite the FLAG column with the 108 paired-end / secondary / supplementary / duplicate combinations above (no flag
+    with bit 4 = unmapped).  The first n_first records keep the generator's two flags so that the register pairs fill
+    with the common values first, as in a real file."""
+    out = []
+    k = 0
+    for ln in sam.splitlines(keepends=True):
+        if ln.startswith(b"@") or not ln.strip():
+            out.append(ln); continue
+        f = ln.split(b"\t")
+        if k >= n_first:
+            f[1] = str(PAIRED_FLAGS[(k * 2654435761 >> 7) % len(PAIRED_FLAGS)]).encode()
+        k += 1
+        out.append(b"\t".join(f))
+    return b"".join(out)
+
+
+def _many_flags_input():
+    """> 122 880 records (the flag model's first rescale, sam_models.c:96-130 + stream_model.c:41-48) with 110 FLAG values."""
+    pb0, sam, fa = host.synth(35, 1_200_000, 126_000, 100, 0.003, 0.02, want_text=True)
+    pb0.close()
+    sam = _with_many_flags(sam, n_first=500)
+    assert len(_seq_column(sam)) > 122_880 + 1000
+    return sam, fa
+
+
+def _many_pos_steps_input():
+    """> 104 858 records (the pos model's first rescale) whose POS steps take > 10 000 distinct values: more than the
+    8192 alphabet entries the stream kernels keep in LDS."""
+    pb0, sam, fa = host.synth(36, 290_000_000, 112_000, 100, 0.003, 0.02, want_text=True)
+    pb0.close()
+    return sam, fa
+
+
+def test_whole_file_stream_takes_what_the_reference_takes(built):
+    """More than CBC_CAP_FLAG distinct FLAG values and more distinct POS steps than the LDS alphabet holds, each across the
+    model's rescale: the packer accepts them in whole-file mode (it used to refuse) and the stream body == the oracle,
+    encode and decode (emulation of the kernel body)."""
+    assert len(PAIRED_FLAGS) >= 100
+    sam, fa = _many_flags_input()
+    pb = host.pack_sam(sam, fa, whole_file=True)
+    assert len({int(f) for f in pb.recs["flag"]}) >= 100
+    expect, st = oracle.encode(sam, fa, return_stats=True)
+    payloads, res = blockref.emu_encode_stream(pb)
+    assert int(res[0]["status"]) == 0 and payloads[0] == expect and int(res[0]["n_symbols"]) == st.n_symbols
+    recs, bases, dres = blockref.emu_decode_stream(expect, pb.ref, pb.contigs, pb.n_recs + 3)
+    want = _seq_column(sam)
+    assert int(dres["status"]) == 0 and len(recs) == len(want) and int(dres["n_symbols"]) == st.n_symbols
+    assert all(bases[i, :len(w)].tobytes() == w for i, w in enumerate(want)) and (recs["flag"] == pb.recs["flag"]).all()
+    pb.close()
+
+    sam, fa = _many_pos_steps_input()
+    pb = host.pack_sam(sam, fa, whole_file=True)
+    pos = pb.recs["pos"].astype(np.int64)
+    n_steps = len(set(np.diff(np.concatenate([[0], pos])).tolist()))
+    assert n_steps > 10_000 and pb.cap_pos > blockref.STREAM_POS_LDS + 1500 and pb.n_recs > 104_858 + 1000, (n_steps, pb.cap_pos)
+    expect, st = oracle.encode(sam, fa, return_stats=True)
+    payloads, res = blockref.emu_encode_stream(pb)
+    assert int(res[0]["status"]) == 0 and payloads[0] == expect and int(res[0]["n_symbols"]) == st.n_symbols
+    recs, bases, dres = blockref.emu_decode_stream(expect, pb.ref, pb.contigs, pb.n_recs + 3)
+    want = _seq_column(sam)
+    assert int(dres["status"]) == 0 and len(recs) == len(want) and int(dres["n_symbols"]) == st.n_symbols
+    assert (recs["pos"] == pb.recs["pos"]).all() and all(bases[i, :len(w)].tobytes() == w for i, w in enumerate(want))
+
+
+@pytest.mark.gpu
+def test_gpu_whole_file_stream_takes_what_the_reference_takes(enc, built):
+    """The same two inputs on the HIP path: `cbc_gpu_encode_stream` bytes == the oracle's whole-file encode, the oracle's
+    decoder reads the GPU's file, and `cbc_gpu_decode_stream` returns the reads."""
+    for make in (_many_flags_input, _many_pos_steps_input):
+        sam, fa = make()
+        pb = host.pack_sam(sam, fa, whole_file=True)
+        expect, st = oracle.encode(sam, fa, return_stats=True)
+        enc.upload_reference(pb.ref)
+        stream, sr = enc.encode_stream(pb)
+        assert sr.status == 0 and stream == expect and sr.n_symbols == st.n_symbols
+        recs, bases, dr = enc.decode_stream(stream, pb.contigs)
+        want = _seq_column(sam)
+        assert dr.status == 0 and len(recs) == len(want) and dr.n_symbols == st.n_symbols
+        assert (recs["pos"] == pb.recs["pos"]).all() and (recs["flag"] == pb.recs["flag"]).all()
+        assert all(bases[i, :len(w)].tobytes() == w for i, w in enumerate(want))
+        pb.close()
