@@ -558,6 +558,27 @@ struct CbcEnc {
             }
         }
     }
+    /* coder wave as a pure consumer (the long-read encoder): every batch, every entry, until the batch flagged LAST.  A
+     * failure on this side (full output area) or the model's (it travels in the batch header) ends the coding, not the
+     * pulling: the model wavefront must always find a free slot for its LAST batch. */
+    CBC_MFN void consume_all()
+    {
+        while (!seen_last) {
+            pull();
+            if (status != CBC_ST_OK) continue;
+            const uint32_t kend = b_stop < b_len ? b_stop : b_len;
+            for (uint32_t k = 0; k < kend; k++) {
+                Uv rec, k3;
+                code1_lazy(W::readlane(b_fl, k), W::readlane(b_fh, k), [&]() -> uint32_t { return W::readlane(b_lo, k); },
+                           [&]() -> uint32_t { return W::readlane(b_hi, k); }, [&]() -> uint32_t { return W::readlane(b_n, k); }, rec, k3);
+                W::set_lane_uv(rec_a, rec_n, rec);
+                W::set_lane_uv(rec_s, rec_n, k3);
+                nsym++;
+                if (++rec_n >= CBC_REC_PACK_AT) { pack(rec_a, rec_s, rec_n); rec_n = 0; }
+            }
+            if (b_stop < b_len) fail(CBC_ST_ASSERT);                          /* zero count / total: stream_model.c:71 */
+        }
+    }
     /* ---- the match test runs in the CODER wavefront (it has the idle time at cfg2: stamps in profiles/r02_final_stamps.log)
      * one group ahead of its coding, and reaches the model wavefront through a mailbox in LDS: ctl[2] = groups posted
      * (release / acquire like the batch counters), ctl[3] = 1 once the coder refused a group, ctl[4..7] = two slots of

@@ -85,8 +85,14 @@ __global__ void __launch_bounds__(64)
 cbc_decode_whole_kernel(cbc_dstream_args A) { cbc_decode_whole<WaveGPU>(A, cbc_lds); }
 
 /* long-read format (cbc_long_body.h): one wavefront per block */
-__global__ void __launch_bounds__(64)
-cbc_long_encode_kernel(cbc_long_args A) { if (blockIdx.x < A.n_blocks) cbc_long_encode<WaveGPU>(A, blockIdx.x, cbc_lds); }
+__global__ void __launch_bounds__(128)
+cbc_long_encode_kernel(cbc_long_args A)
+{
+    if (blockIdx.x >= A.n_blocks) return;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wid == 0u) cbc_long_encode<WaveGPU, CBC_ROLE_MODEL>(A, blockIdx.x, cbc_lds);
+    else cbc_long_encode<WaveGPU, CBC_ROLE_CODER>(A, blockIdx.x, cbc_lds);
+}
 __global__ void __launch_bounds__(64)
 cbc_long_decode_kernel(cbc_dec_args A) { if (blockIdx.x < A.n_blocks) cbc_long_decode<WaveGPU>(A, blockIdx.x, cbc_lds); }
 
@@ -351,7 +357,27 @@ API uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks, cons
 {
     return cbc_plan_output(blocks, n_blocks, recs, tok);
 }
+API uint64_t cbc_gpu_plan_output_caps(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_lds_caps *caps)
+{
+    return (blocks && caps) ? cbc_plan_output_caps(blocks, n_blocks, caps) : 0;
+}
 API uint32_t cbc_gpu_lds_bytes(const cbc_lds_caps *caps) { return caps ? cbc_plan_lds_bytes(caps) : 0; }
+
+/* grow the context's arenas for a batch of this shape before the batch exists (a CLI does it while the host still parses) */
+API int cbc_gpu_reserve_encode(cbc_gpu_ctx *ctx, uint64_t n_recs, uint64_t seq_bytes, uint64_t n_tok, uint32_t n_blocks, uint64_t scratch_bytes)
+{
+    if (!ctx) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    int rc;
+    if ((rc = arena_need(ctx, A_RECS, n_recs * sizeof(cbc_read_rec) + 16, "hipMalloc recs"))) return rc;
+    if ((rc = arena_need(ctx, A_SEQ, seq_bytes + 32, "hipMalloc seq"))) return rc;
+    if ((rc = arena_need(ctx, A_TOK, (n_tok ? n_tok : 1) * 4 + 16, "hipMalloc tok"))) return rc;
+    if ((rc = arena_need(ctx, A_BLOCKS, (uint64_t)(n_blocks ? n_blocks : 1) * sizeof(cbc_block_desc), "hipMalloc blocks"))) return rc;
+    if ((rc = arena_need(ctx, A_RES, (uint64_t)(n_blocks ? n_blocks : 1) * sizeof(cbc_block_result), "hipMalloc results"))) return rc;
+    if ((rc = arena_need(ctx, A_OFF, ((uint64_t)n_blocks + 1) * 8, "hipMalloc offsets"))) return rc;
+    if ((rc = arena_need(ctx, A_OUT, scratch_bytes ? scratch_bytes : 1, "hipMalloc out scratch"))) return rc;
+    return CBC_OK;
+}
 
 static int encode_blocks_launch(cbc_gpu_ctx *ctx, const cbc_device_batch *b, void *hip_stream, uint64_t resident_blocks);
 API int cbc_gpu_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_batch *b, void *hip_stream)
@@ -532,7 +558,9 @@ static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const 
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     const double T0 = wall_now();
     cbc_e2e_times tm; memset(&tm, 0, sizeof tm);
-    const uint64_t scratch = sums ? plan_output_from_summaries(hb->blocks, nb, sums) : cbc_plan_output(hb->blocks, nb, hb->recs, hb->tok);
+    /* payload areas from the caps alone (O(blocks)); a batch whose cap_var is not a bound -- not from the packers -- gets
+     * OUT_FULL / CAP_VAR statuses from the kernel, never a wrong byte */
+    const uint64_t scratch = sums ? plan_output_from_summaries(hb->blocks, nb, sums) : cbc_plan_output_caps(hb->blocks, nb, &hb->caps);
     cbc_block_result *res = NULL;
     uint8_t *d_compact = NULL;
     int rc = CBC_OK;
@@ -1115,7 +1143,7 @@ API int cbc_gpu_long_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_bat
     A.ref_bytes = b->ref_bytes; A.out_bytes = b->out_bytes; A.seq_bytes = b->seq_bytes; A.n_tok = b->n_tok;
     A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.names_bytes = 0x7fffffffu;
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
-    hipLaunchKernelGGL(cbc_long_encode_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
+    hipLaunchKernelGGL(cbc_long_encode_kernel, dim3(b->n_blocks), dim3(128), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_long_encode_kernel");
     HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
     ctx->have_timing = 1; ctx->last_variant = 0;

@@ -26,23 +26,30 @@
 #include "cbc_decode_body.h"
 
 #define CBC_LONG_MAGIC 0x43424C03u
-/* LDS words: 16 dense tables, the bit ring (encode) / nothing (decode), contig-name pairs, then pos value / count */
-#define CBC_LLDS_LEN    0u         /* 4 x 256 */
-#define CBC_LLDS_NE     1024u      /* 2 x 256 */
-#define CBC_LLDS_GAP    1536u      /* 8 x 256 */
-#define CBC_LLDS_GX     3584u      /* 2 x 256 */
-#define CBC_LLDS_RING   4096u      /* CBC_RING_WORDS (encode); decode: 512 pos_alpha histograms start here */
-#define CBC_LLDS_HIST   4096u
-#define CBC_LLDS_RNKEY  4608u      /* CBC_CAP_NAME */
-#define CBC_LLDS_RNEXC  (4608u + CBC_CAP_NAME)
-#define CBC_LLDS_FIXED  (4608u + 2u * CBC_CAP_NAME)
+/* LDS words.  Both directions: the 10 dense tables that can see thousands of symbols per block (gap x 8, gx x 2), the six
+ * tables that see at most ONE symbol per read (len x 4, ne x 2) as sparse (value << 24 | excess) lists of 64 words each --
+ * a block holds at most 64 reads, so such a list cannot overflow and its model cannot reach the rescale point
+ * (n <= 256 + 10 * 64) --, the contig-name pairs.  Then per direction: encode = output bit ring + the hand-off ring of the
+ * two wavefronts and its counters; decode = the four pos_alpha histograms.  Then pos value / count.
+ * 16.5 KB per block at cap_pos 128 (round 2: 20 KB with sixteen dense tables): nine blocks per CU. */
+#define CBC_LLDS_GAP    0u         /* 8 x 256 */
+#define CBC_LLDS_GX     2048u      /* 2 x 256 */
+#define CBC_LLDS_SP     2560u      /* 6 x 64: len[0..3], ne[0..1] */
+#define CBC_LLDS_RNKEY  2944u      /* CBC_CAP_NAME */
+#define CBC_LLDS_RNEXC  (2944u + CBC_CAP_NAME)
+#define CBC_LLDS_ROLE   (2944u + 2u * CBC_CAP_NAME)
+#define CBC_LLDS_RING   CBC_LLDS_ROLE                               /* encode: CBC_RING_WORDS */
+#define CBC_LLDS_BATCH  (CBC_LLDS_ROLE + CBC_RING_WORDS)            /* encode: CBC_BATCH_SLOTS x CBC_BATCH_WORDS */
+#define CBC_LLDS_CTL    (CBC_LLDS_BATCH + CBC_BATCH_SLOTS * CBC_BATCH_WORDS)   /* encode: 8 */
+#define CBC_LLDS_HIST   CBC_LLDS_ROLE                               /* decode: 512 */
+#define CBC_LLDS_FIXED  (CBC_LLDS_CTL + 8u)
 static inline uint32_t cbc_long_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_LLDS_FIXED + 2u * cap_pos); }
 
-/* lanes of the "totals" register: the n of each dense table */
-#define CBC_LN_LEN 0u
-#define CBC_LN_NE  4u
-#define CBC_LN_GAP 6u
-#define CBC_LN_GX  14u
+/* dense tables: index 0..7 gap (2 * prev_kind + strand), 8..9 gx; sparse lists: 0..3 len, 4..5 ne */
+#define CBC_LT_GAP 0u
+#define CBC_LT_GX  8u
+#define CBC_LS_LEN 0u
+#define CBC_LS_NE  4u
 /* kind model (4 contexts x 3, init 1, step 8) in the free lanes of the small lane table: 0-2, 3-5, 10-12, 13-15 */
 CBC_FN uint32_t cbc_long_kind_base(uint32_t pk) { return pk < 2u ? pk * 3u : 10u + (pk - 2u) * 3u; }
 
@@ -59,7 +66,13 @@ struct cbc_long_args {
     uint32_t n_blocks, cap_pos, names_bytes;
 };
 
-template <class W>
+/* One block = one stream, coded by TWO wavefronts (round 3; ROLE = CBC_ROLE_MODEL / CBC_ROLE_CODER, as in the block encoder;
+ * CBC_ROLE_FUSED = both in one, the CPU emulation): the model wavefront finds the edits (read vs reference along the CIGAR,
+ * 256 bases per compare: 4 per lane, the next chunk's loads in flight) and turns them into (cum, count, total) triples of
+ * the adaptive models; the coder wavefront runs the range coder and the bit packer over them.  The triples travel through
+ * the LDS ring of the block encoder (CbcEnc::publish / pull); the model wavefront ends with a batch flagged LAST that
+ * carries its status, the coder takes batches until it has seen it, whatever happens on either side. */
+template <class W, uint32_t ROLE>
 CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
 {
     typedef typename W::V32 V32;
@@ -75,23 +88,44 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     E.l = W::uv(0u); E.set_l_forms(); E.rng = W::uv(CBC_M26 + 1u); E.scale3 = 0u; E.bitpos = 0; E.flushed = 0;
     E.ring = lds + CBC_LLDS_RING;
     E.q_lo = W::splat(0u); E.q_cnt = W::splat(0u); E.q_n = W::splat(0u); E.q_len = 0;
+    E.b_lo = W::splat(0u); E.b_hi = W::splat(0u); E.b_n = W::splat(1u); E.b_fl = W::splat(0u); E.b_fh = W::splat(0u);
     E.rec_a = W::splat(0u); E.rec_s = W::splat(0u); E.rec_n = 0;
-    E.role = CBC_ROLE_FUSED; E.batch_i = 0; E.batch = nullptr; E.ctl = nullptr;
+    E.role = ROLE; E.batch_i = 0; E.batch = lds + CBC_LLDS_BATCH; E.ctl = lds + CBC_LLDS_CTL;
     E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
+    if (ROLE != CBC_ROLE_FUSED) {                            /* the only barrier: the hand-off counters start at zero for both */
+        if (ROLE == CBC_ROLE_MODEL) { W::write_uni(E.ctl, 0u, 0u); W::write_uni(E.ctl, 1u, 0u); }
+        W::barrier();
+    }
     E.out32 = (uint32_t *)(A.out + out_off);
     E.cap_words = out_cap >> 2;
     bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0u) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
-                   cbc_fits64(tok_base, n_tok_blk, A.n_tok) && (name_off < A.names_bytes) && A.cap_pos >= 2u;
+                   cbc_fits64(tok_base, n_tok_blk, A.n_tok) && (name_off < A.names_bytes) && A.cap_pos >= 2u && n_reads <= 64u;
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
 
+    /* ================================ coder wavefront ======================================= */
+    if (ROLE == CBC_ROLE_CODER) {
+        W::prio(CBC_PRIO_CODER);
+        for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
+        E.consume_all();
+        uint32_t nbytes = 0;
+        if (E.status == CBC_ST_OK) { E.flush_recs(); nbytes = E.finish(); }
+        if (E.status != CBC_ST_OK) nbytes = 0;
+        V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),
+                   W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
+        W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);
+        return;
+    }
+
+    /* ================================ model wavefront (or both, fused) ====================== */
     E.L0 = 256u;                                              /* alphabet of the dense tables (var is not used) */
-    E.rlen_exc = lds + CBC_LLDS_LEN; E.snps_exc = nullptr; E.indels_exc = nullptr;
+    E.rlen_exc = nullptr; E.snps_exc = nullptr; E.indels_exc = nullptr;
     E.rname_key = lds + CBC_LLDS_RNKEY; E.rname_exc = lds + CBC_LLDS_RNEXC; E.rn_cap = CBC_CAP_NAME; E.rn_count = 0;
     E.pos_val = lds + CBC_LLDS_FIXED; E.pos_occ = E.pos_val + A.cap_pos; E.pos_pre = nullptr; E.cap_pos = A.cap_pos;
     E.fsp_key = E.fsp_exc = nullptr; E.fsp_count = 0; E.pos_ov_val = E.pos_ov_occ = nullptr; E.pos_lds_cap = 0xffffffc0u; E.palpha = nullptr;
     E.bloom = nullptr; E.var_ev = nullptr; E.nev = E.nev1 = 0; E.cap_var = 0; E.vtab = nullptr; E.p0ev = nullptr;
     E.p0cnt = W::splat(0u); E.p0over = 0;
-    for (uint32_t b = 0; b < CBC_LLDS_RING + CBC_RING_WORDS; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());
+    for (uint32_t b = 0; b < CBC_LLDS_SP; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());        /* the dense tables */
+    if (ROLE == CBC_ROLE_FUSED) for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
     W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);
     E.snps_n = 0; E.indels_n = 0; E.pos_card = 1u;
     E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
@@ -108,13 +142,30 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         E.small = W::select(inch, cv, sm);
     }
     E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0; E.win_clear();
-    V32 ntab = W::splat(256u);                                /* totals of the 16 dense tables, lane = table */
+    V32 ntab = W::splat(256u);                                /* totals of the 10 dense tables, lane = table */
     uint32_t flag_n = 65536u, pos_n = 1u;
+    V32 spc = W::splat(0u);                                    /* entries of the six sparse lists, lane = list */
 
-    auto tab_code = [&](uint32_t table, uint32_t x) {          /* table: 0-3 len, 4-5 ne, 6-13 gap, 14-15 gx */
+    auto tab_code = [&](uint32_t table, uint32_t x) {          /* dense: 0-7 gap, 8-9 gx */
         uint32_t n = W::readlane(ntab, table);
         E.dense_code(lds + 256u * table, 256u, 10u, x, n);
         ntab = W::select(ln == table, W::splat(n), ntab);
+    };
+    /* the six models that see one symbol per read: all six have coded r symbols when record r comes, n = 256 + 10 r */
+    auto sp_code = [&](uint32_t list, uint32_t x, uint32_t r) {
+        uint32_t *tab = lds + CBC_LLDS_SP + 64u * list;
+        const uint32_t count = W::readlane(spc, list);
+        const Mask live = ln < count;
+        const V32 w = W::load32(tab, ln, live, 0u);
+        const V32 k = w >> 24, e = w & 0xffffffu;
+        const uint32_t lo = x + W::reduce_add(W::select(live & (k < x), e, W::splat(0u)));
+        const uint64_t eq = W::ballot(live & (k == x));
+        uint32_t cnt = 1u, idx = count;
+        if (eq) { idx = W::ctz64(eq); cnt = 1u + W::readlane(e, idx); }
+        E.encode(lo, cnt, 256u + 10u * r);
+        if (idx >= 64u) { E.fail(CBC_ST_ASSERT); return; }     /* more than 64 reads: refused above */
+        W::write_uni(tab, idx, (x << 24) | (cnt - 1u + 10u));
+        if (!eq) spc = W::select(ln == list, W::splat(count + 1u), spc);
     };
     auto code_int = [&](uint32_t v) {
         E.regsparse_code(E.hkey, E.hexc, 0u, 8u, E.hc0, E.hn0, 256u, 1u, v >> 24, CBC_ST_ASSERT);
@@ -122,7 +173,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
         E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
     };
-    if (E.status == CBC_ST_OK) { code_int(CBC_LONG_MAGIC); code_int(8u); E.drain_q(); }
+    if (E.status == CBC_ST_OK) { code_int(CBC_LONG_MAGIC); code_int(8u); E.drain(); }
 
     const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
     const uint8_t *seqb = A.seq + seq_base;
@@ -131,111 +182,154 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     const uint64_t seq_avail = cbc_le64(seq_base, A.seq_bytes) ? A.seq_bytes - seq_base : 0;
     const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
     const uint32_t seq_lim = cbc_avail32(seq_avail, 0u), ref_lim = cbc_avail32(ref_avail, 0u);
+    const V32 bo = ln * 4u;
+    /* bytes [0, c) of a 256-byte chunk, 4 per lane: which of a lane's four are inside */
+    auto chunk_mask = [&](uint32_t c) -> V32 {
+        return W::select(bo + 4u <= c, W::splat(0xffffffffu), W::select(bo < c, (W::splat(1u) << ((W::splat(c) - bo) * 8u)) - 1u, W::splat(0u)));
+    };
 
-    for (uint32_t c0 = 0; c0 < n_reads && E.status == CBC_ST_OK; c0 += 64u) {
-        V32 r_pos, r_fl, r_seq, r_tok;
-        const uint32_t cn = n_reads - c0 < 64u ? n_reads - c0 : 64u;
-        W::load_rec(recs4, ln + c0, (ln + c0) < n_reads, r_pos, r_fl, r_seq, r_tok);
+    V32 r_pos = W::splat(0u), r_fl = W::splat(0u), r_seq = W::splat(0u), r_tok = W::splat(0u);
+    if (E.status == CBC_ST_OK) {
+        W::load_rec(recs4, ln, ln < n_reads, r_pos, r_fl, r_seq, r_tok);
+        V32 vrl = r_fl >> 16;
+        Mask live = ln < n_reads;
+        /* the compares read dwords: 3 readable bytes past a read's last base (the batch's 8 pad bytes) and past the reference run */
+        Mask bad = live & ((vrl == 0u) | (r_pos == 0u) | (r_seq > seq_lim) | ((seq_lim - r_seq) < (vrl + 3u)) | (r_pos > ref_lim) | (r_tok >= n_tok_blk));
+        uint64_t bb = W::ballot(bad);
+        if (bb) { E.cur_read = W::ctz64(bb); E.fail(CBC_ST_ASSERT); }
+    }
+    for (uint32_t r = 0; r < n_reads && E.status == CBC_ST_OK; r++) {
+        E.cur_read = r;
+        if (E.q_len >= 32u) E.drain();
+        if (r == 0u) {
+            E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+            for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
+                uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
+                E.rname_code(E.prevChar, ch);
+                if ((q & 31u) == 31u) E.drain();
+                if (ch == 0u) break;
+                E.prevChar = ch;
+            }
+            E.drain();
+        } else E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
+        const uint32_t pos = W::readlane(r_pos, r), flw = W::readlane(r_fl, r), rl = flw >> 16, strand = (flw >> 4) & 1u;
+        const uint32_t so = W::readlane(r_seq, r), to = W::readlane(r_tok, r);
+        const uint8_t *rdb = seqb + so;
+        for (uint32_t k = 0; k < 4u; k++) sp_code(CBC_LS_LEN + k, (rl >> (8u * (3u - k))) & 0xffu, r);
+        /* -- pos: the reference's model (compress_pos read_compression.c:113-159), any 31-bit step -- */
+        if (pos < E.prevPos) { E.fail(CBC_ST_ASSERT); break; }
+        E.pos_lit_code(pos - E.prevPos + 1u, pos_n);
+        E.prevPos = pos;
+        E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);
+        if (E.status != CBC_ST_OK) break;
+
+        const uint32_t hdr = W::read_uni(tokb, to), n_cig = hdr & 0xffffu;
+        if (to + 2u + n_cig > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
+
+        /* -- pass 0: the number of edits, which the stream carries before them.  Nothing serial: mismatches are counted by
+         *    four ballots per 256 bases, I / S / D runs by their length -- */
+        uint32_t ne = 0;
         {
-            V32 vrl = r_fl >> 16;
-            Mask live = (ln + c0) < n_reads;
-            Mask bad = live & ((vrl == 0u) | (r_pos == 0u) | (r_seq > seq_lim) | ((seq_lim - r_seq) < vrl) | (r_pos > ref_lim) | (r_tok >= n_tok_blk));
-            uint64_t bb = W::ballot(bad);
-            if (bb) { E.cur_read = c0 + W::ctz64(bb); E.fail(CBC_ST_ASSERT); break; }
-        }
-        for (uint32_t j = 0; j < cn && E.status == CBC_ST_OK; j++) {
-            const uint32_t r = c0 + j;
-            E.cur_read = r;
-            if (E.q_len >= 32u) E.drain_q();
-            if (r == 0u) {
-                E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
-                for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
-                    uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
-                    E.rname_code(E.prevChar, ch);
-                    if ((q & 31u) == 31u) E.drain_q();
-                    if (ch == 0u) break;
-                    E.prevChar = ch;
-                }
-                E.drain_q();
-            } else E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
-            const uint32_t pos = W::readlane(r_pos, j), flw = W::readlane(r_fl, j), rl = flw >> 16, strand = (flw >> 4) & 1u;
-            const uint32_t so = W::readlane(r_seq, j), to = W::readlane(r_tok, j);
-            for (uint32_t k = 0; k < 4u; k++) tab_code(CBC_LN_LEN + k, (rl >> (8u * (3u - k))) & 0xffu);
-            /* -- pos: the reference's model (compress_pos read_compression.c:113-159), any 31-bit step -- */
-            if (pos < E.prevPos) { E.fail(CBC_ST_ASSERT); break; }
-            E.pos_lit_code(pos - E.prevPos + 1u, pos_n);
-            E.prevPos = pos;
-            E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);
-            if (E.status != CBC_ST_OK) break;
-
-            /* -- the edits, in read order: pass 0 counts them, pass 1 codes them -- */
-            const uint32_t hdr = W::read_uni(tokb, to), n_cig = hdr & 0xffffu;
-            if (to + 2u + n_cig > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
-            uint32_t ne = 0;
-            for (uint32_t pass = 0; pass < 2u && E.status == CBC_ST_OK; pass++) {
-                const bool emit = pass == 1u;
-                if (emit) {
-                    if (ne > 0xffffu) { E.fail(CBC_ST_ASSERT); break; }
-                    tab_code(CBC_LN_NE, ne >> 8); tab_code(CBC_LN_NE + 1u, ne & 0xffu);
-                }
-                uint32_t i = 0, since = 0, n = 0, pk = 3u; uint32_t jr = pos - 1u;       /* read index, matched run, edits, previous kind, reference index */
-                V32 tokv = W::splat(0u);
-                auto edit = [&](uint32_t kind, uint32_t row, uint32_t base) {
-                    if (++n > 0xffffu) { E.fail(CBC_ST_ASSERT); return; }      /* the edit count is a u16 in the stream */
-                    if (emit) {
-                        if (E.q_len >= 56u) E.drain_q();
-                        const uint32_t g = since;
-                        tab_code(CBC_LN_GAP + 2u * pk + strand, g < 255u ? g : 255u);
-                        if (g >= 255u) { tab_code(CBC_LN_GX, ((g - 255u) >> 8) & 0xffu); tab_code(CBC_LN_GX + 1u, (g - 255u) & 0xffu); }
-                        E.small_code(cbc_long_kind_base(pk), 3u, 8u, kind);
-                        if (kind != 2u) E.small_code(CBC_LT_CHARS + row * 8u, 5u, 8u, base);
-                        pk = kind;
+            uint32_t i = 0, jr = pos - 1u;
+            V32 tokv = W::splat(0u);
+            for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
+                if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
+                const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
+                if (op == CBC_OP_M) {
+                    if (len > rl - i || jr > ref_lim || len > ref_lim - jr || ref_lim - jr - len < 3u) { E.fail(CBC_ST_ASSERT); break; }
+                    const uint32_t lb = W::uni(len);
+                    uint32_t nm = 0;
+                    for (uint32_t b = 0; b < lb; b += 512u) {           /* two chunks per trip: four loads in flight */
+                        const uint32_t c0 = len - b < 256u ? len - b : 256u, c1 = len - b > 256u ? (len - b - 256u < 256u ? len - b - 256u : 256u) : 0u;
+                        const V32 rd0 = W::load32_bytes(rdb + (i + b), bo, bo < c0), rf0 = W::load32_bytes(refb + (jr + b), bo, bo < c0);
+                        const V32 rd1 = W::load32_bytes(rdb + (i + b + 256u), bo, bo < c1), rf1 = W::load32_bytes(refb + (jr + b + 256u), bo, bo < c1);
+                        const V32 x0 = (rd0 ^ rf0) & chunk_mask(c0), x1 = (rd1 ^ rf1) & chunk_mask(c1);
+                        nm += W::popc64(W::ballot((x0 & 0xffu) != 0u)) + W::popc64(W::ballot((x0 & 0xff00u) != 0u)) +
+                              W::popc64(W::ballot((x0 & 0xff0000u) != 0u)) + W::popc64(W::ballot((x0 >> 24) != 0u));
+                        nm += W::popc64(W::ballot((x1 & 0xffu) != 0u)) + W::popc64(W::ballot((x1 & 0xff00u) != 0u)) +
+                              W::popc64(W::ballot((x1 & 0xff0000u) != 0u)) + W::popc64(W::ballot((x1 >> 24) != 0u));
                     }
-                    since = 0;
-                };
-                for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
-                    if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
-                    const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
-                    if (op == CBC_OP_M) {
-                        if (len > rl - i || jr > ref_lim || len > ref_lim - jr) { E.fail(CBC_ST_ASSERT); break; }
-                        const uint32_t lb = W::uni(len);
-                        for (uint32_t b = 0; b < lb; b += 64u) {
-                            const uint32_t c = len - b < 64u ? len - b : 64u;
-                            const V32 rd = W::load8(seqb + so, ln + (i + b), ln < c), rf = W::load8(refb, ln + (jr + b), ln < c);
-                            uint64_t mm = W::ballot((rd != rf) & (ln < c));
-                            uint32_t next = 0;                              /* first base of the chunk not yet accounted for */
-                            while (mm && E.status == CBC_ST_OK) {
-                                const uint32_t k = W::ctz64(mm); mm &= mm - 1ull;
-                                since += k - next; next = k + 1u;
-                                edit(0u, cbc_basepair(W::readlane(rf, k)), cbc_basepair(W::readlane(rd, k)));
-                            }
-                            since += c - next;
+                    ne += nm; i += len; jr += len;
+                } else if (op == CBC_OP_I || op == CBC_OP_S) {
+                    if (len > rl - i) { E.fail(CBC_ST_ASSERT); break; }
+                    ne += len; i += len;
+                } else if (op == CBC_OP_D) {
+                    if (jr > ref_lim || len > ref_lim - jr) { E.fail(CBC_ST_ASSERT); break; }
+                    ne += len; jr += len;
+                } else { E.fail(CBC_ST_UNSUPPORTED); break; }
+                if (ne > 0xffffu) { E.fail(CBC_ST_ASSERT); break; }                /* the edit count is a u16 in the stream */
+            }
+            if (E.status == CBC_ST_OK && i != rl) E.fail(CBC_ST_ASSERT);          /* the CIGAR must consume the read exactly */
+        }
+        if (E.status != CBC_ST_OK) break;
+        sp_code(CBC_LS_NE, ne >> 8, r); sp_code(CBC_LS_NE + 1u, ne & 0xffu, r);
+
+        /* -- pass 1: the edits, in read order -- */
+        uint32_t i = 0, since = 0, pk = 3u; uint32_t jr = pos - 1u;           /* read index, matched run, previous kind, reference index */
+        auto edit = [&](uint32_t kind, uint32_t row, uint32_t base) {
+            if (E.q_len >= 56u) E.drain();
+            const uint32_t g = since;
+            tab_code(CBC_LT_GAP + 2u * pk + strand, g < 255u ? g : 255u);
+            if (g >= 255u) { tab_code(CBC_LT_GX, ((g - 255u) >> 8) & 0xffu); tab_code(CBC_LT_GX + 1u, (g - 255u) & 0xffu); }
+            E.small_code(cbc_long_kind_base(pk), 3u, 8u, kind);
+            if (kind != 2u) E.small_code(CBC_LT_CHARS + row * 8u, 5u, 8u, base);
+            pk = kind;
+            since = 0;
+        };
+        V32 tokv = W::splat(0u);
+        for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
+            if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
+            const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
+            if (op == CBC_OP_M) {
+                const uint32_t lb = W::uni(len);
+                uint32_t cn = len < 256u ? len : 256u;
+                V32 rd_n = W::load32_bytes(rdb + i, bo, bo < cn), rf_n = W::load32_bytes(refb + jr, bo, bo < cn);
+                for (uint32_t b = 0; b < lb; b += 256u) {
+                    const uint32_t c = cn;
+                    const V32 rd = rd_n, rf = rf_n;
+                    if (b + 256u < len) {                                  /* the next chunk's loads go out before this one is walked */
+                        cn = len - b - 256u < 256u ? len - b - 256u : 256u;
+                        rd_n = W::load32_bytes(rdb + (i + b + 256u), bo, bo < cn); rf_n = W::load32_bytes(refb + (jr + b + 256u), bo, bo < cn);
+                    }
+                    const V32 x = (rd ^ rf) & chunk_mask(c);
+                    uint64_t mm = W::ballot(x != 0u);
+                    uint32_t next = 0;                                     /* first base of the chunk not yet accounted for */
+                    while (mm && E.status == CBC_ST_OK) {
+                        const uint32_t k = W::ctz64(mm); mm &= mm - 1ull;
+                        const uint32_t xk = W::readlane(x, k), rdk = W::readlane(rd, k), rfk = W::readlane(rf, k);
+                        for (uint32_t q = 0; q < 4u; q++) if ((xk >> (8u * q)) & 0xffu) {
+                            const uint32_t p = 4u * k + q;
+                            since += p - next; next = p + 1u;
+                            edit(0u, cbc_basepair((rfk >> (8u * q)) & 0xffu), cbc_basepair((rdk >> (8u * q)) & 0xffu));
                         }
-                        i += len; jr += len;
-                    } else if (op == CBC_OP_I || op == CBC_OP_S) {
-                        if (len > rl - i) { E.fail(CBC_ST_ASSERT); break; }
-                        for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) edit(1u, 5u, cbc_basepair(W::read_uni8(seqb + so, i + c)));
-                        i += len;
-                    } else if (op == CBC_OP_D) {
-                        if (jr > ref_lim || len > ref_lim - jr) { E.fail(CBC_ST_ASSERT); break; }
-                        for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) edit(2u, 0u, 0u);
-                        jr += len;
-                    } else { E.fail(CBC_ST_UNSUPPORTED); break; }
+                    }
+                    since += c - next;
                 }
-                if (E.status == CBC_ST_OK && i != rl) E.fail(CBC_ST_ASSERT);   /* the CIGAR must consume the read exactly */
-                if (!emit) ne = n;
+                i += len; jr += len;
+            } else if (op == CBC_OP_I || op == CBC_OP_S) {
+                const uint32_t lb = W::uni(len);
+                for (uint32_t b = 0; b < lb && E.status == CBC_ST_OK; b += 64u) {        /* the inserted bases, 64 per load */
+                    const uint32_t c = len - b < 64u ? len - b : 64u;
+                    const V32 ib = W::load8(rdb, ln + (i + b), ln < c);
+                    for (uint32_t q = 0; q < c && E.status == CBC_ST_OK; q++) edit(1u, 5u, cbc_basepair(W::readlane(ib, q)));
+                }
+                i += len;
+            } else {                                                       /* D (pass 0 refused everything else) */
+                for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) edit(2u, 0u, 0u);
+                jr += len;
             }
         }
     }
-    uint32_t nbytes = 0;
     if (E.status == CBC_ST_OK) {
         E.cur_read = n_reads;
-        if (E.q_len >= 32u) E.drain_q();
+        if (E.q_len >= 32u) E.drain();
         E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
         E.rname_code(E.prevChar, (uint32_t)'\n');
         E.rname_code((uint32_t)'\n', 0u);
-        E.drain_q();
     }
+    if (ROLE == CBC_ROLE_MODEL) { E.publish(CBC_BF_LAST, 0ull); return; }   /* with whatever is still queued, and this wavefront's status */
+    uint32_t nbytes = 0;
+    if (E.status == CBC_ST_OK) E.drain_q();
     if (E.status == CBC_ST_OK) { E.flush_recs(); nbytes = E.finish(); }
     if (E.status != CBC_ST_OK) nbytes = 0;
     V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),
@@ -266,7 +360,8 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.pos_valp = lds + CBC_LLDS_FIXED; D.pos_cntp = D.pos_valp + A.cap_pos;
     D.fsp_key = D.fsp_exc = nullptr; D.fsp_count = 0; D.pos_ov_valp = D.pos_ov_cntp = nullptr; D.pos_lds_cap = 0xffffffc0u; D.palpha = nullptr;
     bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
-                   cbc_fits64(seq_base, (uint64_t)blk_bases + 8u, A.seq_bytes) && cbc_le64(ref_off, A.ref_bytes) && A.cap_pos >= 2u;
+                   cbc_fits64(seq_base, (uint64_t)blk_bases + 8u, A.seq_bytes) && cbc_le64(ref_off, A.ref_bytes) && A.cap_pos >= 2u &&
+                   n_reads <= 64u;
     D.nwords_in = (in_bytes + 3u) >> 2;
     D.tail_valid = in_bytes & 3u;
     if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
@@ -290,11 +385,27 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
     D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
     D.p0cnt = W::splat(0u); D.p0over = 0;
-    V32 ntab = W::splat(256u);
-    auto tab_dec = [&](uint32_t table) -> uint32_t {
+    V32 ntab = W::splat(256u), spc = W::splat(0u);
+    auto tab_dec = [&](uint32_t table) -> uint32_t {          /* dense: 0-7 gap, 8-9 gx */
         uint32_t n = W::readlane(ntab, table);
         uint32_t x = D.dense_dec(lds + 256u * table, 256u, 10u, n);
         ntab = W::select(ln == table, W::splat(n), ntab);
+        return x;
+    };
+    /* the six models that see one symbol per read (cbc_long_encode: sp_code): sparse (value << 24 | excess) lists */
+    auto sp_dec = [&](uint32_t list, uint32_t r) -> uint32_t {
+        uint32_t *tab = lds + CBC_LLDS_SP + 64u * list;
+        const uint32_t count = W::readlane(spc, list), n = 256u + 10u * r;
+        const Mask live = ln < count;
+        const V32 w = W::load32(tab, ln, live, 0u);
+        const uint32_t tg = D.target(n);
+        if (D.status != CBC_ST_OK) return 0u;
+        uint32_t lo, cnt, hl; bool hit;
+        const uint32_t x = D.pairs_search(w >> 24, w & 0xffffffu, live, 0u, count, tg, lo, cnt, hl, hit);
+        if (x >= 256u || (!hit && count >= 64u)) { D.fail(CBC_ST_ASSERT); return 0u; }
+        D.step(lo, cnt, n);
+        W::write_uni(tab, hit ? hl : count, (x << 24) | (cnt - 1u + 10u));
+        if (!hit) spc = W::select(ln == list, W::splat(count + 1u), spc);
         return x;
     };
     auto dec_int = [&]() -> uint32_t {
@@ -337,7 +448,7 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
             if (D.status != CBC_ST_OK) break;
         }
         uint32_t rl = 0;
-        for (uint32_t k = 0; k < 4u && D.status == CBC_ST_OK; k++) rl = (rl << 8) | tab_dec(CBC_LN_LEN + k);
+        for (uint32_t k = 0; k < 4u && D.status == CBC_ST_OK; k++) rl = (rl << 8) | sp_dec(CBC_LS_LEN + k, r);
         if (D.status != CBC_ST_OK) break;
         if (rl == 0u || rl > 65535u || rl > blk_bases - so) { D.fail(CBC_ST_ASSERT); break; }
         uint32_t x = D.pos_dec();
@@ -348,12 +459,12 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
         D.prevPos = pos;
         uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
         const uint32_t strand = (flag >> 4) & 1u;
-        uint32_t ne = tab_dec(CBC_LN_NE) << 8; ne |= tab_dec(CBC_LN_NE + 1u);
+        uint32_t ne = sp_dec(CBC_LS_NE, r) << 8; ne |= sp_dec(CBC_LS_NE + 1u, r);
         if (D.status != CBC_ST_OK) break;
         uint32_t i = 0, jr = pos - 1u, pk = 3u;
         for (uint32_t k = 0; k < ne && D.status == CBC_ST_OK; k++) {
-            uint32_t g = tab_dec(CBC_LN_GAP + 2u * pk + strand);
-            if (g == 255u) { uint32_t hi = tab_dec(CBC_LN_GX); g = 255u + ((hi << 8) | tab_dec(CBC_LN_GX + 1u)); }
+            uint32_t g = tab_dec(CBC_LT_GAP + 2u * pk + strand);
+            if (g == 255u) { uint32_t hi = tab_dec(CBC_LT_GX); g = 255u + ((hi << 8) | tab_dec(CBC_LT_GX + 1u)); }
             uint32_t kind = D.small_dec(cbc_long_kind_base(pk), 3u, 8u);
             if (D.status != CBC_ST_OK) break;
             if (g > rl - i || jr > ref_lim || g > ref_lim - jr) { D.fail(CBC_ST_ASSERT); break; }

@@ -136,7 +136,7 @@ static void *dev_encode(void *arg)
         hb.recs = p->recs + r0; hb.n_recs = r1 - r0; hb.seq = p->seq + s0; hb.seq_bytes = s1 - s0 + 8;   /* 8 readable pad bytes follow */
         hb.tok = p->tok + t0k; hb.n_tok = t1k - t0k; hb.names = p->names; hb.names_bytes = p->names_bytes;
         hb.blocks = bl; hb.n_blocks = nb; hb.caps = p->caps;
-        uint64_t cap = cbc_gpu_plan_output(bl, nb, hb.recs, hb.tok);
+        uint64_t cap = cbc_gpu_plan_output_caps(bl, nb, &hb.caps);
         uint8_t *pay = (uint8_t *)malloc(cap ? cap : 1);
         if (!pay) { J->rc = CBC_E_NOMEM; free(bl); free(offs); break; }
         J->rc = cbc_gpu_encode_blocks(ctx, &hb, pay, cap, offs, NULL);
@@ -208,14 +208,34 @@ static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, c
 }
 
 /* cbc_gpu_init (HIP runtime start-up, ~0.1 s) on its own thread while the host parses the text */
-typedef struct { int device; cbc_gpu_ctx *ctx; int rc; double seconds; } init_job;
+typedef struct { int device; cbc_gpu_ctx *ctx; int rc; double seconds; uint64_t est_recs, est_seq, est_tok, est_scratch; uint32_t est_blocks; } init_job;
 static void *init_thread(void *arg)
 {
     init_job *J = (init_job *)arg;
     double t = now_s();
     J->rc = cbc_gpu_init(J->device, &J->ctx);
+    /* the device buffers of the encode call too, sized from an estimate of the file (they grow if it was short) */
+    if (!J->rc && J->est_recs) (void)cbc_gpu_reserve_encode(J->ctx, J->est_recs, J->est_seq, J->est_tok, J->est_blocks, J->est_scratch);
     J->seconds = now_s() - t;
     return NULL;
+}
+/* records, bases and tokens a SAM text will pack into, from its first record line (uniform line lengths assumed) */
+static void estimate_batch(const char *sam, size_t sam_len, uint32_t block_reads, init_job *J)
+{
+    size_t off = (size_t)cbc_sam_body_offset(sam, sam_len);
+    if (off >= sam_len) return;
+    const char *nl = (const char *)memchr(sam + off, '\n', sam_len - off);
+    const size_t ll = nl ? (size_t)(nl - (sam + off)) + 1 : sam_len - off;
+    if (ll < 20) return;
+    size_t col = 0, seq_len = 0;
+    for (size_t i = off; i < off + ll; i++) { if (sam[i] == '\t') { col++; continue; } if (col == 9) seq_len++; }
+    if (seq_len == 0 || seq_len > 70000) return;
+    const uint32_t br = block_reads ? block_reads : 4096u;
+    J->est_recs = (uint64_t)((double)(sam_len - off) / (double)ll * 1.02) + 1024;
+    J->est_seq = J->est_recs * seq_len + 64;
+    J->est_tok = J->est_recs * 5;
+    J->est_blocks = (uint32_t)(J->est_recs / br + J->est_recs / br / 8 + 16);
+    J->est_scratch = (uint64_t)J->est_blocks * (3ull * (392ull + 16ull * br + 2ull * 8192ull) + 512ull + 4ull * (8192ull + 64ull) + 256ull);
 }
 
 static double g_main_t0;
@@ -227,10 +247,12 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     double t0 = now_s();
     init_job IJ; pthread_t init_th; int init_started = 0;
     memset(&IJ, 0, sizeof IJ); IJ.device = device;
-    if (!(device_parse && !compat && !long_reads && ndev <= 1) && ndev <= 1)
-        init_started = pthread_create(&init_th, NULL, init_thread, &IJ) == 0;
     const char *sam = map_file(in, &sam_len), *fa = map_file(ref, &fa_len);
     if (!sam || !fa) return 1;
+    if (!(device_parse && !compat && !long_reads && ndev <= 1) && ndev <= 1) {
+        if (!compat && !long_reads) estimate_batch(sam, sam_len, block_reads, &IJ);
+        init_started = pthread_create(&init_th, NULL, init_thread, &IJ) == 0;
+    }
     printf("Compressing...\n");                                   /* src/compression.c:120 */
     char err[512];
     cbc_pack_opts po; cbc_pack_default_opts(&po);
@@ -297,7 +319,7 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
         return 0;
     }
     uint64_t cap = tokenised ? 4096ull * p->n_blocks + 48ull * p->n_recs + 16ull * p->n_tok
-                             : cbc_gpu_plan_output(p->blocks, p->n_blocks, p->recs, p->tok);
+                             : cbc_gpu_plan_output_caps(p->blocks, p->n_blocks, &p->caps);
     uint8_t *payloads = (uint8_t *)malloc(cap ? cap : 1);
     uint64_t *offs = (uint64_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint64_t));
     if (!payloads || !offs) { fprintf(stderr, "cbc: out of memory\n"); return 1; }

@@ -690,7 +690,7 @@ static int packer_init(packer_t *S, const cbc_pack_opts *opts, char *errbuf, siz
     if (opts) S->o = *opts; else cbc_pack_default_opts(&S->o);
     if (S->o.long_reads) {                                  /* blocks are cut by bases: 64 reads of 10 kb fill one */
         S->o.whole_file = 0;
-        if (S->o.block_reads == 0 || S->o.block_reads > 1024) S->o.block_reads = 64;
+        if (S->o.block_reads == 0 || S->o.block_reads > 64) S->o.block_reads = 64;   /* format limit: the per-read models keep <= 64 entries */
     }
     if (S->o.block_reads == 0) S->o.block_reads = 4096;
     if (S->o.block_reads > CBC_MAX_BLOCK_READS) S->o.block_reads = CBC_MAX_BLOCK_READS;

@@ -79,4 +79,23 @@ static inline uint64_t cbc_plan_output(cbc_block_desc *blocks, uint32_t n_blocks
     return off;
 }
 
+/* The same bound without reading a single record: the packer cuts blocks so that none holds more than caps->cap_var - 1
+ * edit events, so cap_var bounds every block's event count.  O(blocks) instead of O(records + tokens) on the host -- the
+ * per-record form cost more than the whole device pipeline of a cfg2-sized call (2 x 15 ms of 48, round 3). */
+static inline uint64_t cbc_plan_output_caps(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_lds_caps *caps)
+{
+    uint64_t off = 0;
+    const uint64_t nev = caps->cap_var;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        cbc_block_desc *bd = &blocks[b];
+        const uint64_t nsym = 136u + 2u * CBC_CAP_NAME + 16ull * bd->n_reads + 2 * nev;
+        uint64_t payload_cap = (3 * nsym + 256 + 255) & ~255ull;
+        uint64_t cap = payload_cap + ((4 * (nev + 64) + 255) & ~255ull);
+        if (cap > 0xffffff00ull) { cap = 0xffffff00ull; payload_cap = cap / 2; payload_cap &= ~255ull; }
+        bd->out_off = off; bd->out_cap = (uint32_t)cap; bd->reserved = (uint32_t)payload_cap;
+        off += cap;
+    }
+    return off;
+}
+
 #endif

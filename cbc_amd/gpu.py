@@ -119,6 +119,10 @@ def lib():
         L.cbc_gpu_decode_lds_bytes.argtypes = [ctypes.POINTER(host.LdsCaps)]
         L.cbc_gpu_plan_output.restype = ctypes.c_uint64
         L.cbc_gpu_plan_output.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_gpu_plan_output_caps.restype = ctypes.c_uint64
+        L.cbc_gpu_plan_output_caps.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(host.LdsCaps)]
+        L.cbc_gpu_reserve_encode.restype = ctypes.c_int
+        L.cbc_gpu_reserve_encode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
         L.cbc_gpu_lds_bytes.restype = ctypes.c_uint32
         L.cbc_gpu_lds_bytes.argtypes = [ctypes.POINTER(host.LdsCaps)]
         L.cbc_gpu_last_kernel_ms.restype = ctypes.c_int
@@ -194,7 +198,7 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_long_plan_output", "cbc_gpu_long_lds_bytes", "cbc_gpu_long_encode_blocks_device",
            "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks",
            "cbc_gpu_checksum_device", "cbc_gpu_upload_reference_parts", "cbc_gpu_last_e2e", "cbc_gpu_host_register",
-           "cbc_gpu_host_unregister"]
+           "cbc_gpu_host_unregister", "cbc_gpu_plan_output_caps", "cbc_gpu_reserve_encode"]
 
 
 class Encoder:
@@ -282,7 +286,7 @@ class Encoder:
         nb = pb.n_blocks
         hb, blocks = self._host_batch(pb)
         hb.seq = None
-        total = lib().cbc_gpu_plan_output(blocks.ctypes.data, nb, pb.recs.ctypes.data, pb.tok.ctypes.data)
+        total = lib().cbc_gpu_plan_output_caps(blocks.ctypes.data, nb, ctypes.byref(hb.caps))
         out = np.zeros(int(total), dtype=np.uint8)
         offs = np.zeros(nb + 1, dtype=np.uint64)
         res = np.zeros(nb, dtype=host.RESULT_DTYPE)
@@ -331,7 +335,7 @@ class Encoder:
         nb = len(blocks)
         hb = HostBatch(pb.recs.ctypes.data, pb.n_recs, pb.seq.ctypes.data, len(pb.seq), pb.tok.ctypes.data, pb.n_tok,
                        pb.names.ctypes.data, len(pb.names), blocks.ctypes.data, nb, host.LdsCaps(pb.cap_pos, pb.cap_var))
-        total = lib().cbc_gpu_plan_output(blocks.ctypes.data, nb, pb.recs.ctypes.data, pb.tok.ctypes.data)
+        total = lib().cbc_gpu_plan_output_caps(blocks.ctypes.data, nb, ctypes.byref(hb.caps))
         out = np.zeros(int(total), dtype=np.uint8)
         offs = np.zeros(nb + 1, dtype=np.uint64)
         res = np.zeros(nb, dtype=host.RESULT_DTYPE)

@@ -218,6 +218,14 @@ int  cbc_gpu_checksum_device(cbc_gpu_ctx *ctx, const uint8_t *d_bytes, uint64_t 
 uint64_t cbc_gpu_plan_output(cbc_block_desc *blocks, uint32_t n_blocks,
                              const cbc_read_rec *recs, const uint32_t *tok);
 
+/* The same bound from the caps alone, without reading the records: no block holds more than caps->cap_var - 1 edit
+ * events (the packers cut blocks that way).  O(blocks); what the host-buffer entry points use, and what sizes their `out`. */
+uint64_t cbc_gpu_plan_output_caps(cbc_block_desc *blocks, uint32_t n_blocks, const cbc_lds_caps *caps);
+/* Grow the context's device buffers for a batch of this shape before the batch exists (allocation of gigabytes takes
+ * tens of milliseconds the first time: a CLI does it on the device-init thread while the host still parses the text). */
+int  cbc_gpu_reserve_encode(cbc_gpu_ctx *ctx, uint64_t n_recs, uint64_t seq_bytes, uint64_t n_tok, uint32_t n_blocks,
+                            uint64_t scratch_bytes);
+
 /* Dynamic LDS bytes one block's workgroup needs for `caps` (workgroups per CU = 160 KiB / this). */
 uint32_t cbc_gpu_lds_bytes(const cbc_lds_caps *caps);
 

@@ -147,7 +147,7 @@ int emu_long_encode_blocks(const cbc_long_args *A)
     g_emu_errors = 0;
     for (uint32_t blk = 0; blk < A->n_blocks; blk++) {
         std::vector<uint32_t> lds(cbc_long_lds_bytes(A->cap_pos) / 4, 0xdeadbeefu);
-        cbc_long_encode<WaveEmu>(*A, blk, lds.data());
+        cbc_long_encode<WaveEmu, CBC_ROLE_FUSED>(*A, blk, lds.data());
     }
     return g_emu_errors ? -100 : 0;
 }
