@@ -66,39 +66,6 @@ struct cbc_long_args {
     uint32_t n_blocks, cap_pos, names_bytes;
 };
 
-/* 512 consecutive bytes of a byte array in two vector registers (4 bytes per lane: [base, base + 256) and the 256 after
- * them, loaded one window ahead), read as unaligned dwords per lane by two lane gathers and a funnel shift -- no memory
- * access.  The long-read kernels walk a read and its reference through such windows: a 10 kb read with 5 % edits has
- * ~340 CIGAR runs of ~30 bases, and a global-memory round trip per run (round 2, and the first two-wavefront form) was
- * most of the encoder's model time. */
-template <class W>
-struct CbcLWin {
-    typedef typename W::V32 V32;
-    V32 cur, nxt; uint32_t base, lim; const uint8_t *p;
-    CBC_MFN V32 ld(uint32_t b)
-    {
-        const V32 bo = W::lane() * 4u;
-        return W::load32_bytes(p + b, bo, (bo + b < lim) & ((lim - b - bo) >= 4u));      /* bytes past `lim` read as 0 */
-    }
-    CBC_MFN void reset(const uint8_t *p_, uint32_t lim_, uint32_t pos) { p = p_; lim = lim_; base = pos & ~3u; cur = ld(base); nxt = ld(base + 256u); }
-    CBC_MFN void to(uint32_t pos)                              /* afterwards base <= pos < base + 256 */
-    {
-        if (pos - base < 256u) return;
-        if (pos - base < 512u) { cur = nxt; base += 256u; }
-        else { base = pos & ~3u; cur = ld(base); }
-        nxt = ld(base + 256u);
-    }
-    /* lane l: bytes [pos + 4l, pos + 4l + 4); wants base <= pos < base + 256; bytes from base + 512 on are garbage */
-    CBC_MFN V32 dwords(uint32_t pos)
-    {
-        const uint32_t off = pos - base;
-        const V32 wi = W::lane() + (off >> 2);
-        const V32 lo = W::select(wi < 64u, W::lane_gather(cur, wi), W::lane_gather(nxt, wi));
-        const V32 hi = W::select(wi + 1u < 64u, W::lane_gather(cur, wi + 1u), W::lane_gather(nxt, wi + 1u));
-        return W::funnel_shr(hi, lo, (off & 3u) * 8u);
-    }
-};
-
 /* One block = one stream, coded by TWO wavefronts (round 3; ROLE = CBC_ROLE_MODEL / CBC_ROLE_CODER, as in the block encoder;
  * CBC_ROLE_FUSED = both in one, the CPU emulation): the model wavefront finds the edits (read vs reference along the CIGAR,
  * 256 bases per compare: 4 per lane, the next chunk's loads in flight) and turns them into (cum, count, total) triples of
@@ -259,38 +226,28 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         const uint32_t hdr = W::read_uni(tokb, to), n_cig = hdr & 0xffffu;
         if (to + 2u + n_cig > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
 
-        /* -- pass 0: the number of edits, which the stream carries before them.  Nothing serial and no memory access per
-         *    CIGAR run: read and reference come through register windows, mismatches are counted by four ballots per piece of
-         *    an M run, I / S / D runs by their length -- */
+        /* -- pass 0: the number of edits, which the stream carries before them.  Nothing serial: mismatches are counted by
+         *    four ballots per 256 bases, I / S / D runs by their length -- */
         uint32_t ne = 0;
-        CbcLWin<W> rw, fw;
-        /* a piece of an M run: at most 256 bases, all of them inside both 512-byte windows (+ 3 bytes of dword slack) */
-        auto m_piece = [&](uint32_t ri, uint32_t fj, uint32_t left, V32 &rd, V32 &rf) -> uint32_t {
-            rw.to(ri); fw.to(fj);
-            uint32_t c = left < 256u ? left : 256u;
-            const uint32_t room_r = 509u - (ri - rw.base), room_f = 509u - (fj - fw.base);
-            if (c > room_r) c = room_r;
-            if (c > room_f) c = room_f;
-            rd = rw.dwords(ri); rf = fw.dwords(fj);
-            return c;
-        };
         {
             uint32_t i = 0, jr = pos - 1u;
-            rw.reset(rdb, rl + 3u, 0u); fw.reset(refb, ref_lim, jr);
             V32 tokv = W::splat(0u);
             for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
                 if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
                 const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
                 if (op == CBC_OP_M) {
                     if (len > rl - i || jr > ref_lim || len > ref_lim - jr || ref_lim - jr - len < 3u) { E.fail(CBC_ST_ASSERT); break; }
+                    const uint32_t lb = W::uni(len);
                     uint32_t nm = 0;
-                    for (uint32_t b = 0; b < len; ) {
-                        V32 rd, rf;
-                        const uint32_t c = m_piece(i + b, jr + b, len - b, rd, rf);
-                        const V32 x = (rd ^ rf) & chunk_mask(c);
-                        nm += W::popc64(W::ballot((x & 0xffu) != 0u)) + W::popc64(W::ballot((x & 0xff00u) != 0u)) +
-                              W::popc64(W::ballot((x & 0xff0000u) != 0u)) + W::popc64(W::ballot((x >> 24) != 0u));
-                        b += c;
+                    for (uint32_t b = 0; b < lb; b += 512u) {           /* two chunks per trip: four loads in flight */
+                        const uint32_t c0 = len - b < 256u ? len - b : 256u, c1 = len - b > 256u ? (len - b - 256u < 256u ? len - b - 256u : 256u) : 0u;
+                        const V32 rd0 = W::load32_bytes(rdb + (i + b), bo, bo < c0), rf0 = W::load32_bytes(refb + (jr + b), bo, bo < c0);
+                        const V32 rd1 = W::load32_bytes(rdb + (i + b + 256u), bo, bo < c1), rf1 = W::load32_bytes(refb + (jr + b + 256u), bo, bo < c1);
+                        const V32 x0 = (rd0 ^ rf0) & chunk_mask(c0), x1 = (rd1 ^ rf1) & chunk_mask(c1);
+                        nm += W::popc64(W::ballot((x0 & 0xffu) != 0u)) + W::popc64(W::ballot((x0 & 0xff00u) != 0u)) +
+                              W::popc64(W::ballot((x0 & 0xff0000u) != 0u)) + W::popc64(W::ballot((x0 >> 24) != 0u));
+                        nm += W::popc64(W::ballot((x1 & 0xffu) != 0u)) + W::popc64(W::ballot((x1 & 0xff00u) != 0u)) +
+                              W::popc64(W::ballot((x1 & 0xff0000u) != 0u)) + W::popc64(W::ballot((x1 >> 24) != 0u));
                     }
                     ne += nm; i += len; jr += len;
                 } else if (op == CBC_OP_I || op == CBC_OP_S) {
@@ -319,18 +276,24 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
             pk = kind;
             since = 0;
         };
-        rw.reset(rdb, rl + 3u, 0u); fw.reset(refb, ref_lim, jr);
         V32 tokv = W::splat(0u);
         for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
             if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
             const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
             if (op == CBC_OP_M) {
-                for (uint32_t b = 0; b < len && E.status == CBC_ST_OK; ) {
-                    V32 rd, rf;
-                    const uint32_t c = m_piece(i + b, jr + b, len - b, rd, rf);
+                const uint32_t lb = W::uni(len);
+                uint32_t cn = len < 256u ? len : 256u;
+                V32 rd_n = W::load32_bytes(rdb + i, bo, bo < cn), rf_n = W::load32_bytes(refb + jr, bo, bo < cn);
+                for (uint32_t b = 0; b < lb; b += 256u) {
+                    const uint32_t c = cn;
+                    const V32 rd = rd_n, rf = rf_n;
+                    if (b + 256u < len) {                                  /* the next chunk's loads go out before this one is walked */
+                        cn = len - b - 256u < 256u ? len - b - 256u : 256u;
+                        rd_n = W::load32_bytes(rdb + (i + b + 256u), bo, bo < cn); rf_n = W::load32_bytes(refb + (jr + b + 256u), bo, bo < cn);
+                    }
                     const V32 x = (rd ^ rf) & chunk_mask(c);
                     uint64_t mm = W::ballot(x != 0u);
-                    uint32_t next = 0;                                     /* first base of the piece not yet accounted for */
+                    uint32_t next = 0;                                     /* first base of the chunk not yet accounted for */
                     while (mm && E.status == CBC_ST_OK) {
                         const uint32_t k = W::ctz64(mm); mm &= mm - 1ull;
                         const uint32_t xk = W::readlane(x, k), rdk = W::readlane(rd, k), rfk = W::readlane(rf, k);
@@ -341,19 +304,14 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                         }
                     }
                     since += c - next;
-                    b += c;
                 }
                 i += len; jr += len;
             } else if (op == CBC_OP_I || op == CBC_OP_S) {
-                for (uint32_t b = 0; b < len && E.status == CBC_ST_OK; ) {              /* the inserted bases, through the read window */
-                    rw.to(i + b);
-                    uint32_t c = len - b < 256u ? len - b : 256u;
-                    const uint32_t room = 509u - (i + b - rw.base);
-                    if (c > room) c = room;
-                    const V32 ib = rw.dwords(i + b);
-                    for (uint32_t q = 0; q < c && E.status == CBC_ST_OK; q++)
-                        edit(1u, 5u, cbc_basepair((W::readlane(ib, q >> 2) >> (8u * (q & 3u))) & 0xffu));
-                    b += c;
+                const uint32_t lb = W::uni(len);
+                for (uint32_t b = 0; b < lb && E.status == CBC_ST_OK; b += 64u) {        /* the inserted bases, 64 per load */
+                    const uint32_t c = len - b < 64u ? len - b : 64u;
+                    const V32 ib = W::load8(rdb, ln + (i + b), ln < c);
+                    for (uint32_t q = 0; q < c && E.status == CBC_ST_OK; q++) edit(1u, 5u, cbc_basepair(W::readlane(ib, q)));
                 }
                 i += len;
             } else {                                                       /* D (pass 0 refused everything else) */
@@ -467,37 +425,12 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     const uint64_t ref_avail = cbc_le64(ref_off, A.ref_bytes) ? A.ref_bytes - ref_off : 0;
     const uint32_t ref_lim = cbc_avail32(ref_avail, 0u);
     uint32_t so = 0;                                             /* bases written so far in this block */
-    /* The reference along the read lives in two vector registers: 256 bytes from `wb` (4 per lane) and the 256 after them,
-     * loaded one window ahead.  A run of matched bases is the reference itself: its bytes go from the window straight to the
-     * output (four masked byte stores per piece, nothing to wait for), and the reference base a substitution's chars context
-     * needs is a lane read.  Round 2 loaded every run, and every context base, from global memory inside the serial chain:
-     * a round trip of ~1 us per edit, two thirds of the decoder's time (profiles/r03_long_*). */
-    uint32_t wb = 0xfffffc00u;                                   /* window base (a multiple of 4); far from any index: first use reloads */
-    V32 wv = W::splat(0u), wn = W::splat(0u);
-    const V32 bo = ln * 4u;
-    auto win_load = [&](uint32_t base) -> V32 {                  /* bytes past the reference's end (never inside a valid run) read as 0 */
-        return W::load32_bytes(refb + base, bo, (bo + base < ref_lim) & ((ref_lim - base - bo) >= 4u));
-    };
-    auto win_to = [&](uint32_t jr) {                             /* afterwards wb <= jr < wb + 256 */
-        if (jr - wb < 256u) return;
-        if (jr - wb < 512u) { wv = wn; wb += 256u; }
-        else { wb = jr & ~3u; wv = win_load(wb); }
-        wn = win_load(wb + 256u);
-    };
-    auto ref_base = [&](uint32_t jr) -> uint32_t {
-        win_to(jr);
-        const uint32_t w = jr - wb;
-        return (W::readlane(wv, w >> 2) >> (8u * (w & 3u))) & 0xffu;
-    };
-    auto copy_run = [&](uint32_t at, uint32_t jr, uint32_t g) {  /* g bytes of the reference from jr to seqo + at */
-        while (g) {
-            win_to(jr);
-            const uint32_t off = jr - wb, take = g < 256u - off ? g : 256u - off;
-            for (uint32_t q = 0; q < 4u; q++) {
-                const V32 w = bo + q;                              /* window byte of this lane's q-th */
-                W::store8(seqo, w + (at - off), (wv >> (8u * q)) & 0xffu, (w >= off) & (w < off + take));
-            }
-            at += take; jr += take; g -= take;
+    /* a run of matched bases is the reference itself: g bytes from refb + jr to seqo + at, 64 per step */
+    auto copy_run = [&](uint32_t at, uint32_t jr, uint32_t g) {
+        const uint32_t gb = W::uni(g);
+        for (uint32_t b = 0; b < gb; b += 64u) {
+            const V32 v = W::load8(refb, ln + (jr + b), (ln + b) < g);
+            W::store8(seqo, ln + (at + b), v, (ln + b) < g);
         }
     };
     for (uint32_t r = 0; r < n_reads && D.status == CBC_ST_OK; r++) {
@@ -524,7 +457,6 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
         uint32_t pos = D.prevPos + x - 1u;
         if (pos < D.prevPos || pos == 0u || pos > ref_lim) { D.fail(CBC_ST_ASSERT); break; }
         D.prevPos = pos;
-        win_to(pos - 1u);                                        /* the read's first window: its loads go out before the flag is decoded */
         uint32_t flag = D.regsparse_dec(D.fkey, D.fexc, 0u, CBC_CAP_FLAG, D.fcount, D.fn, 65536u, 8u, CBC_ST_CAP_FLAG);
         const uint32_t strand = (flag >> 4) & 1u;
         uint32_t ne = sp_dec(CBC_LS_NE, r) << 8; ne |= sp_dec(CBC_LS_NE + 1u, r);
@@ -540,7 +472,7 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
             i += g; jr += g;
             if (kind == 0u) {
                 if (i >= rl || jr >= ref_lim) { D.fail(CBC_ST_ASSERT); break; }
-                uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(ref_base(jr)) * 8u, 5u, 8u);
+                uint32_t alt = D.small_dec(CBC_LT_CHARS + cbc_basepair(W::read_uni8(refb, jr)) * 8u, 5u, 8u);
                 W::store8(seqo, W::splat(so + i), W::splat(cbc_basechar(alt)), ln == 0u);
                 i++; jr++;
             } else if (kind == 1u) {
