@@ -216,7 +216,7 @@ cbc_checksum_kernel(const uint8_t *__restrict__ p, uint64_t n, unsigned long lon
 /* grow-only device buffer owned by the context: the host-buffer entry points keep their device arrays between calls
  * (a hipMalloc / hipFree pair per array and call cost more than the copies they framed: profiles/r02_final_pcie.log) */
 struct cbc_arena { void *p; uint64_t cap; };
-enum { A_RECS, A_SEQ, A_TOK, A_NAMES, A_BLOCKS, A_OUT, A_RES, A_OFF, A_PACKED, A_CODES, A_RUNS, A_VS, A_IN, A_EXC_I, A_EXC_V, A_CNT, A_COUNT };
+enum { A_RECS, A_SEQ, A_TOK, A_NAMES, A_BLOCKS, A_OUT, A_RES, A_OFF, A_PACKED, A_CODES, A_RUNS, A_VS, A_IN, A_EXC_I, A_EXC_V, A_CNT, A_LSCR, A_COUNT };
 #define CBC_MAX_CHUNKS 8
 #define CBC_N_KSTREAMS 8           /* every chunk's launch on a stream of its own: launches of different chunks share the chip */
 
@@ -1106,6 +1106,39 @@ done:
     return rc;
 }
 
+/* The decode twin of cbc_gpu_encode_stream_blocks: every block's payload is a stream of its own in the general (rescaling)
+ * form of the models -- what a block of more than CBC_MAX_BLOCK_READS records needs, and what the block decoder refuses.
+ * A block is decoded as a one-contig file whose contig is the block's reference window (decompress(), src/compression.c:
+ * 173-216; the models never rescale-free here: src/stream_model.c:78-117).  One launch per block: a rare path. */
+API int cbc_gpu_decode_stream_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, const cbc_dec_block_desc *blocks,
+                                     uint32_t n_blocks, cbc_read_rec *recs, uint64_t n_recs, uint8_t *seq, uint64_t seq_bytes,
+                                     cbc_block_result *results)
+{
+    if (!ctx || !in || !blocks || !recs || !seq) return CBC_E_ARG;
+    if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
+    int rc = CBC_OK;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        const cbc_dec_block_desc *bd = &blocks[b];
+        cbc_stream_result sr; memset(&sr, 0, sizeof sr);
+        int one = CBC_E_ARG;
+        if (bd->in_off <= in_bytes && bd->in_bytes <= in_bytes - bd->in_off && bd->rec_base <= n_recs && bd->n_reads <= n_recs - bd->rec_base &&
+            bd->seq_stride >= 4 && bd->seq_stride <= 256 && (bd->seq_stride & 3u) == 0 && bd->seq_base <= seq_bytes &&
+            (uint64_t)bd->n_reads * bd->seq_stride + 8 <= seq_bytes - bd->seq_base && bd->ref_off + CBC_REF_PAD < ctx->ref_bytes) {
+            const uint64_t co = bd->ref_off, cl = ctx->ref_bytes - bd->ref_off - CBC_REF_PAD;      /* the window: from POS 1 of the block to the end */
+            one = cbc_gpu_decode_stream(ctx, in + bd->in_off, bd->in_bytes, &co, &cl, 1, recs + bd->rec_base, bd->n_reads,
+                                        seq + bd->seq_base, (uint64_t)bd->n_reads * bd->seq_stride + 8, bd->seq_stride, &sr);
+            if (one == CBC_OK && sr.nbytes != bd->n_reads) { sr.status = CBC_ST_ASSERT; one = CBC_E_BLOCK; }     /* the index and the stream disagree */
+        }
+        if (results) { results[b].nbytes = (uint32_t)sr.nbytes; results[b].status = one == CBC_E_ARG ? CBC_ST_ASSERT : sr.status;
+                       results[b].n_symbols = (uint32_t)sr.n_symbols; results[b].fail_read = sr.fail_read; }
+        if (one != CBC_OK && rc == CBC_OK) {
+            rc = one == CBC_E_ARG ? CBC_E_ARG : CBC_E_BLOCK;
+            if (one == CBC_E_ARG) (void)set_err(ctx, CBC_E_ARG, "block descriptor outside the buffers", hipSuccess);
+        }
+    }
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * long-read format extension
  * ---------------------------------------------------------------------------------------------- */
@@ -1142,6 +1175,10 @@ API int cbc_gpu_long_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_bat
     A.ref = b->d_ref; A.out = b->d_out; A.results = b->d_results;
     A.ref_bytes = b->ref_bytes; A.out_bytes = b->out_bytes; A.seq_bytes = b->seq_bytes; A.n_tok = b->n_tok;
     A.n_recs = b->n_recs; A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.names_bytes = 0x7fffffffu;
+    /* the blocks' global-memory table parts (gap symbols 64.., gx): a buffer of the context, grown when a larger batch
+     * comes (which waits for the device once); the kernel zeroes what it uses */
+    { int rc_ = arena_need(ctx, A_LSCR, (uint64_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS * 4 + 256, "hipMalloc long-read table scratch"); if (rc_) return rc_; }
+    A.scratch = (uint32_t *)ctx->arena[A_LSCR].p;
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
     hipLaunchKernelGGL(cbc_long_encode_kernel, dim3(b->n_blocks), dim3(128), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_long_encode_kernel");
@@ -1165,6 +1202,9 @@ API int cbc_gpu_long_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device
     A.in = b->d_in; A.blocks = b->d_blocks; A.ref = b->d_ref; A.recs = b->d_recs; A.seq = b->d_seq; A.results = b->d_results;
     A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
     A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = 0;
+    /* the blocks' global-memory table parts (cbc_long_body.h): the context's own buffer -- batch->d_var_scratch is not used */
+    { int rc_ = arena_need(ctx, A_LSCR, (uint64_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS * 4 + 256, "hipMalloc long-read table scratch"); if (rc_) return rc_; }
+    A.var_scratch = (uint32_t *)ctx->arena[A_LSCR].p; A.var_scratch_words = (uint64_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS;
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
     hipLaunchKernelGGL(cbc_long_decode_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_long_decode_kernel");

@@ -26,28 +26,31 @@
 #include "cbc_decode_body.h"
 
 #define CBC_LONG_MAGIC 0x43424C03u
-/* LDS words.  Both directions: the 10 dense tables that can see thousands of symbols per block (gap x 8, gx x 2), the six
- * tables that see at most ONE symbol per read (len x 4, ne x 2) as sparse (value << 24 | excess) lists of 64 words each --
- * a block holds at most 64 reads, so such a list cannot overflow and its model cannot reach the rescale point
- * (n <= 256 + 10 * 64) --, the contig-name pairs.  Then per direction: encode = output bit ring + the hand-off ring of the
- * two wavefronts and its counters; decode = the four pos_alpha histograms.  Then pos value / count.
- * 16.5 KB per block at cap_pos 128 (round 2: 20 KB with sixteen dense tables): nine blocks per CU. */
-#define CBC_LLDS_GAP    0u         /* 8 x 256 */
-#define CBC_LLDS_GX     2048u      /* 2 x 256 */
-#define CBC_LLDS_SP     2560u      /* 6 x 64: len[0..3], ne[0..1] */
-#define CBC_LLDS_RNKEY  2944u      /* CBC_CAP_NAME */
-#define CBC_LLDS_RNEXC  (2944u + CBC_CAP_NAME)
-#define CBC_LLDS_ROLE   (2944u + 2u * CBC_CAP_NAME)
+/* LDS words.  Both directions: of each of the eight gap tables only the symbols 0..63 (where a 5 % edit rate puts 96 %
+ * of the gaps), the six tables that see at most ONE symbol per read (len x 4, ne x 2) as sparse (value << 24 | excess) lists
+ * of 64 words each -- a block holds at most 64 reads, so such a list cannot overflow and its model cannot reach the rescale
+ * point (n <= 256 + 10 * 64) --, the contig-name pairs.  Then per direction: encode = output bit ring + the hand-off ring of
+ * the two wavefronts and its counters; decode = the four pos_alpha histograms.  Then pos value / count.
+ * The gap symbols 64..255 and the two gx tables live in GLOBAL memory, CBC_LONG_SCRATCH_WORDS per block (the kernel zeroes
+ * them): these kernels are bound by how many blocks a CU holds -- 20 KB of LDS per block in round 2 (2 wavefronts per SIMD),
+ * 16.5 KB with the sparse lists, 7.5 KB now: the register file, not LDS, sets the residency. */
+#define CBC_LLDS_GAPLO  0u         /* 8 x 64: excess of gap symbols 0..63 */
+#define CBC_LLDS_SP     512u       /* 6 x 64: len[0..3], ne[0..1] */
+#define CBC_LLDS_RNKEY  896u       /* CBC_CAP_NAME */
+#define CBC_LLDS_RNEXC  (896u + CBC_CAP_NAME)
+#define CBC_LLDS_ROLE   (896u + 2u * CBC_CAP_NAME)
 #define CBC_LLDS_RING   CBC_LLDS_ROLE                               /* encode: CBC_RING_WORDS */
 #define CBC_LLDS_BATCH  (CBC_LLDS_ROLE + CBC_RING_WORDS)            /* encode: CBC_BATCH_SLOTS x CBC_BATCH_WORDS */
 #define CBC_LLDS_CTL    (CBC_LLDS_BATCH + CBC_BATCH_SLOTS * CBC_BATCH_WORDS)   /* encode: 8 */
 #define CBC_LLDS_HIST   CBC_LLDS_ROLE                               /* decode: 512 */
 #define CBC_LLDS_FIXED  (CBC_LLDS_CTL + 8u)
 static inline uint32_t cbc_long_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_LLDS_FIXED + 2u * cap_pos); }
+/* global scratch of a block, in words: [8 x 192 gap symbols 64..255][2 x 256 gx] */
+#define CBC_LSCR_GAPHI  0u
+#define CBC_LSCR_GX     1536u
+#define CBC_LONG_SCRATCH_WORDS 2048u
 
-/* dense tables: index 0..7 gap (2 * prev_kind + strand), 8..9 gx; sparse lists: 0..3 len, 4..5 ne */
-#define CBC_LT_GAP 0u
-#define CBC_LT_GX  8u
+/* gap tables: index 0..7 = 2 * prev_kind + strand; gx: 0..1; sparse lists: 0..3 len, 4..5 ne */
 #define CBC_LS_LEN 0u
 #define CBC_LS_NE  4u
 /* kind model (4 contexts x 3, init 1, step 8) in the free lanes of the small lane table: 0-2, 3-5, 10-12, 13-15 */
@@ -64,6 +67,7 @@ struct cbc_long_args {
     cbc_block_result     *results;
     uint64_t ref_bytes, out_bytes, seq_bytes, n_tok, n_recs;
     uint32_t n_blocks, cap_pos, names_bytes;
+    uint32_t *scratch;                  /* n_blocks x CBC_LONG_SCRATCH_WORDS (no initial content needed) */
 };
 
 /* One block = one stream, coded by TWO wavefronts (round 3; ROLE = CBC_ROLE_MODEL / CBC_ROLE_CODER, as in the block encoder;
@@ -99,7 +103,8 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     E.out32 = (uint32_t *)(A.out + out_off);
     E.cap_words = out_cap >> 2;
     bool args_ok = cbc_fits64(out_off, out_cap, A.out_bytes) && ((out_off & 3u) == 0u) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
-                   cbc_fits64(tok_base, n_tok_blk, A.n_tok) && (name_off < A.names_bytes) && A.cap_pos >= 2u && n_reads <= 64u;
+                   cbc_fits64(tok_base, n_tok_blk, A.n_tok) && (name_off < A.names_bytes) && A.cap_pos >= 2u && n_reads <= 64u &&
+                   A.scratch != nullptr;
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
 
     /* ================================ coder wavefront ======================================= */
@@ -124,7 +129,9 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     E.fsp_key = E.fsp_exc = nullptr; E.fsp_count = 0; E.pos_ov_val = E.pos_ov_occ = nullptr; E.pos_lds_cap = 0xffffffc0u; E.palpha = nullptr;
     E.bloom = nullptr; E.var_ev = nullptr; E.nev = E.nev1 = 0; E.cap_var = 0; E.vtab = nullptr; E.p0ev = nullptr;
     E.p0cnt = W::splat(0u); E.p0over = 0;
-    for (uint32_t b = 0; b < CBC_LLDS_SP; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());        /* the dense tables */
+    uint32_t *scr = A.scratch + (uint64_t)blk * CBC_LONG_SCRATCH_WORDS;
+    for (uint32_t b = 0; b < CBC_LLDS_SP; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());        /* gap symbols 0..63 */
+    if (E.status == CBC_ST_OK) for (uint32_t b = 0; b < CBC_LONG_SCRATCH_WORDS; b += 64u) W::store32_list(scr, ln + b, W::splat(0u), W::all());   /* the rest, gx */
     if (ROLE == CBC_ROLE_FUSED) for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
     W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);
     E.snps_n = 0; E.indels_n = 0; E.pos_card = 1u;
@@ -142,14 +149,65 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         E.small = W::select(inch, cv, sm);
     }
     E.prevPos = 0; E.prevM = 0; E.prevChar = 0; E.win_pos = 0; E.win_clear();
-    V32 ntab = W::splat(256u);                                /* totals of the 10 dense tables, lane = table */
+    V32 ntab = W::splat(256u), lsum = W::splat(0u);            /* lane t < 8: total of gap table t, excess held by its symbols 0..63; lanes 8, 9: totals of gx */
     uint32_t flag_n = 65536u, pos_n = 1u;
     V32 spc = W::splat(0u);                                    /* entries of the six sparse lists, lane = list */
 
-    auto tab_code = [&](uint32_t table, uint32_t x) {          /* dense: 0-7 gap, 8-9 gx */
-        uint32_t n = W::readlane(ntab, table);
-        E.dense_code(lds + 256u * table, 256u, 10u, x, n);
-        ntab = W::select(ln == table, W::splat(n), ntab);
+    /* a 256-symbol dense table in global memory (the list accessors: this wavefront alone writes and re-reads it) */
+    auto gsum_below = [&](const uint32_t *row, uint32_t k) -> uint32_t {     /* excess of the row's entries [0, k), k <= 256 */
+        V32 a = W::splat(0u);
+        const uint32_t kb = W::uni(k);
+        for (uint32_t b = 0; b < kb; b += 64u) a = a + W::load32_list(row, ln + b, (ln + b) < k, 0u);
+        return W::reduce_add(a);
+    };
+    auto grescale = [&](uint32_t *row, uint32_t card) -> uint32_t {          /* stream_model.c:41-48 on e = count - 1; returns the new sum */
+        V32 a = W::splat(0u);
+        for (uint32_t b = 0; b < card; b += 64u) {
+            const Mask m = (ln + b) < card;
+            const V32 e = (W::load32_list(row, ln + b, m, 0u) + 1u) >> 1;
+            W::store32_list(row, ln + b, e, m);
+            a = a + W::select(m, e, W::splat(0u));
+        }
+        return W::reduce_add(a);
+    };
+    /* gap in context t (0..7): symbols 0..63 from LDS, the others from the block's global scratch */
+    auto gap_code = [&](uint32_t t, uint32_t x) {
+        uint32_t n = W::readlane(ntab, t), low = W::readlane(lsum, t);
+        uint32_t *lo_tab = lds + CBC_LLDS_GAPLO + 64u * t, *hi_row = scr + CBC_LSCR_GAPHI + 192u * t;
+        if (x < 64u) {
+            uint32_t lo, cnt;
+            E.dense_lookup(lo_tab, x, lo, cnt);
+            E.encode(lo, cnt, n);
+            W::write_uni(lo_tab, x, cnt - 1u + 10u);
+            low += 10u;
+        } else {
+            W::list_fence();
+            const uint32_t k = x - 64u;
+            const uint32_t cnt = 1u + W::readlane(W::load32_list(hi_row, W::splat(k), W::all(), 0u), 0u);
+            E.encode(x + low + gsum_below(hi_row, k), cnt, n);
+            W::append_list(hi_row, k, cnt - 1u + 10u);
+        }
+        n += 10u;
+        if (n >= CBC_RESCALE) {
+            uint32_t dummy = 0;
+            E.dense_rescale(lo_tab, 64u, dummy);                                  /* dummy = 64 + the new low sum */
+            low = dummy - 64u;
+            W::list_fence();
+            n = 256u + low + grescale(hi_row, 192u);
+        }
+        ntab = W::select(ln == t, W::splat(n), ntab);
+        lsum = W::select(ln == t, W::splat(low), lsum);
+    };
+    auto gx_code = [&](uint32_t which, uint32_t x) {            /* the two bytes of a long gap: rare, all of it in global memory */
+        uint32_t n = W::readlane(ntab, 8u + which);
+        uint32_t *row = scr + CBC_LSCR_GX + 256u * which;
+        W::list_fence();
+        const uint32_t cnt = 1u + W::readlane(W::load32_list(row, W::splat(x), W::all(), 0u), 0u);
+        E.encode(x + gsum_below(row, x), cnt, n);
+        W::append_list(row, x, cnt - 1u + 10u);
+        n += 10u;
+        if (n >= CBC_RESCALE) { W::list_fence(); n = 256u + grescale(row, 256u); }
+        ntab = W::select(ln == 8u + which, W::splat(n), ntab);
     };
     /* the six models that see one symbol per read: all six have coded r symbols when record r comes, n = 256 + 10 r */
     auto sp_code = [&](uint32_t list, uint32_t x, uint32_t r) {
@@ -269,8 +327,8 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         auto edit = [&](uint32_t kind, uint32_t row, uint32_t base) {
             if (E.q_len >= 56u) E.drain();
             const uint32_t g = since;
-            tab_code(CBC_LT_GAP + 2u * pk + strand, g < 255u ? g : 255u);
-            if (g >= 255u) { tab_code(CBC_LT_GX, ((g - 255u) >> 8) & 0xffu); tab_code(CBC_LT_GX + 1u, (g - 255u) & 0xffu); }
+            gap_code(2u * pk + strand, g < 255u ? g : 255u);
+            if (g >= 255u) { gx_code(0u, ((g - 255u) >> 8) & 0xffu); gx_code(1u, (g - 255u) & 0xffu); }
             E.small_code(cbc_long_kind_base(pk), 3u, 8u, kind);
             if (kind != 2u) E.small_code(CBC_LT_CHARS + row * 8u, 5u, 8u, base);
             pk = kind;
@@ -361,11 +419,13 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.fsp_key = D.fsp_exc = nullptr; D.fsp_count = 0; D.pos_ov_valp = D.pos_ov_cntp = nullptr; D.pos_lds_cap = 0xffffffc0u; D.palpha = nullptr;
     bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
                    cbc_fits64(seq_base, (uint64_t)blk_bases + 8u, A.seq_bytes) && cbc_le64(ref_off, A.ref_bytes) && A.cap_pos >= 2u &&
-                   n_reads <= 64u;
+                   n_reads <= 64u && A.var_scratch != nullptr && cbc_le64(((uint64_t)blk + 1u) * CBC_LONG_SCRATCH_WORDS, A.var_scratch_words);
     D.nwords_in = (in_bytes + 3u) >> 2;
     D.tail_valid = in_bytes & 3u;
     if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
     for (uint32_t b = 0; b < CBC_LLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_LLDS_FIXED);
+    if (args_ok) for (uint32_t b = 0; b < CBC_LONG_SCRATCH_WORDS; b += 64u)
+        W::store32_list(A.var_scratch + (uint64_t)blk * CBC_LONG_SCRATCH_WORDS, ln + b, W::splat(0u), W::all());
     D.rlen_n = 0; D.rl123_c0 = 0; D.rl123_n = 0; D.snps_n = 0; D.indels_n = 0; D.rn_count = 0;
     D.pos_card = 1u; D.pos_n = 1u; D.nev = 0; D.nev1 = 0;
     D.pval = W::splat(0xffffffffu); D.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
@@ -385,11 +445,80 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.prevPos = 0; D.prevM = 0; D.prevChar = 0; D.win_clear();
     D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
     D.p0cnt = W::splat(0u); D.p0over = 0;
-    V32 ntab = W::splat(256u), spc = W::splat(0u);
-    auto tab_dec = [&](uint32_t table) -> uint32_t {          /* dense: 0-7 gap, 8-9 gx */
-        uint32_t n = W::readlane(ntab, table);
-        uint32_t x = D.dense_dec(lds + 256u * table, 256u, 10u, n);
-        ntab = W::select(ln == table, W::splat(n), ntab);
+    V32 ntab = W::splat(256u), lsum = W::splat(0u), spc = W::splat(0u);
+    uint32_t *scr = A.var_scratch + (uint64_t)blk * CBC_LONG_SCRATCH_WORDS;
+    /* the symbol of a dense table row in global memory whose cumulative interval holds tg; `first` = cum of the row's entry 0 */
+    auto gsearch = [&](const uint32_t *row, uint32_t card, uint32_t first, uint32_t tg, uint32_t &lo, uint32_t &cnt) -> uint32_t {
+        uint32_t run = first, found = CBC_NOMEMO;
+        for (uint32_t b = 0; b < card && found == CBC_NOMEMO; b += 64u) {
+            const Mask m = (ln + b) < card;
+            const V32 c = W::select(m, W::load32_list(row, ln + b, m, 0u) + 1u, W::splat(0u));     /* counts */
+            const V32 inc = W::scan_incl_add(c) + run;
+            const uint64_t h = W::ballot(m & ((inc - c) <= tg) & (tg < inc));
+            if (h) { const uint32_t hl = W::ctz64(h); found = b + hl; cnt = W::readlane(c, hl); lo = W::readlane(inc, hl) - cnt; }
+            run = W::readlane(inc, 63u);
+        }
+        if (found == CBC_NOMEMO) D.fail(CBC_ST_ASSERT);
+        return found;
+    };
+    auto grescale = [&](uint32_t *row, uint32_t card) -> uint32_t {
+        V32 a = W::splat(0u);
+        for (uint32_t b = 0; b < card; b += 64u) {
+            const Mask m = (ln + b) < card;
+            const V32 e = (W::load32_list(row, ln + b, m, 0u) + 1u) >> 1;
+            W::store32_list(row, ln + b, e, m);
+            a = a + W::select(m, e, W::splat(0u));
+        }
+        return W::reduce_add(a);
+    };
+    auto gap_dec = [&](uint32_t t) -> uint32_t {              /* cbc_long_encode: gap_code */
+        uint32_t n = W::readlane(ntab, t), low = W::readlane(lsum, t), x = 0;
+        uint32_t *lo_tab = lds + CBC_LLDS_GAPLO + 64u * t, *hi_row = scr + CBC_LSCR_GAPHI + 192u * t;
+        if (!D.tag_ok(n)) return 0u;
+        const V32 e = W::load32(lo_tab, ln, W::all(), 0u);
+        const V32 cum = W::scan_incl_add(e) + ln + 1u;        /* lane s: cum of symbol s + 1 */
+        uint32_t ql, qh;
+        if (D.prefix_find(cum, W::all(), 0u, n, x, ql, qh)) {  /* symbols 0..63: one per lane, the search by scaled bounds */
+            D.step_q(ql, qh);
+            W::write_uni(lo_tab, x, W::readlane(e, x) + 10u);
+            low += 10u;
+        } else {
+            const uint32_t tg = D.target(n);
+            if (D.status != CBC_ST_OK) return 0u;
+            W::list_fence();
+            uint32_t lo = 0, cnt = 0;
+            const uint32_t k = gsearch(hi_row, 192u, 64u + low, tg, lo, cnt);
+            if (D.status != CBC_ST_OK) return 0u;
+            D.step(lo, cnt, n);
+            W::append_list(hi_row, k, cnt - 1u + 10u);
+            x = 64u + k;
+        }
+        n += 10u;
+        if (n >= CBC_RESCALE) {
+            uint32_t dummy = 0;
+            D.dense_rescale(lo_tab, 64u, dummy);
+            low = dummy - 64u;
+            W::list_fence();
+            n = 256u + low + grescale(hi_row, 192u);
+        }
+        ntab = W::select(ln == t, W::splat(n), ntab);
+        lsum = W::select(ln == t, W::splat(low), lsum);
+        return x;
+    };
+    auto gx_dec = [&](uint32_t which) -> uint32_t {
+        uint32_t n = W::readlane(ntab, 8u + which);
+        uint32_t *row = scr + CBC_LSCR_GX + 256u * which;
+        const uint32_t tg = D.target(n);
+        if (D.status != CBC_ST_OK) return 0u;
+        W::list_fence();
+        uint32_t lo = 0, cnt = 0;
+        const uint32_t x = gsearch(row, 256u, 0u, tg, lo, cnt);
+        if (D.status != CBC_ST_OK) return 0u;
+        D.step(lo, cnt, n);
+        W::append_list(row, x, cnt - 1u + 10u);
+        n += 10u;
+        if (n >= CBC_RESCALE) { W::list_fence(); n = 256u + grescale(row, 256u); }
+        ntab = W::select(ln == 8u + which, W::splat(n), ntab);
         return x;
     };
     /* the six models that see one symbol per read (cbc_long_encode: sp_code): sparse (value << 24 | excess) lists */
@@ -463,8 +592,8 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
         if (D.status != CBC_ST_OK) break;
         uint32_t i = 0, jr = pos - 1u, pk = 3u;
         for (uint32_t k = 0; k < ne && D.status == CBC_ST_OK; k++) {
-            uint32_t g = tab_dec(CBC_LT_GAP + 2u * pk + strand);
-            if (g == 255u) { uint32_t hi = tab_dec(CBC_LT_GX); g = 255u + ((hi << 8) | tab_dec(CBC_LT_GX + 1u)); }
+            uint32_t g = gap_dec(2u * pk + strand);
+            if (g == 255u) { uint32_t hi = gx_dec(0u); g = 255u + ((hi << 8) | gx_dec(1u)); }
             uint32_t kind = D.small_dec(cbc_long_kind_base(pk), 3u, 8u);
             if (D.status != CBC_ST_OK) break;
             if (g > rl - i || jr > ref_lim || g > ref_lim - jr) { D.fail(CBC_ST_ASSERT); break; }

@@ -137,6 +137,9 @@ def lib():
         L.cbc_gpu_decode_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.POINTER(StreamResult)]
+        L.cbc_gpu_decode_stream_blocks.restype = ctypes.c_int
+        L.cbc_gpu_decode_stream_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32,
+                                                   ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         L.cbc_stream_read_length.restype = ctypes.c_uint32
         L.cbc_stream_read_length.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         L.cbc_gpu_tokenise_sam.restype = ctypes.c_int
@@ -198,7 +201,8 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_long_plan_output", "cbc_gpu_long_lds_bytes", "cbc_gpu_long_encode_blocks_device",
            "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks",
            "cbc_gpu_checksum_device", "cbc_gpu_upload_reference_parts", "cbc_gpu_last_e2e", "cbc_gpu_host_register",
-           "cbc_gpu_host_unregister", "cbc_gpu_plan_output_caps", "cbc_gpu_reserve_encode"]
+           "cbc_gpu_host_unregister", "cbc_gpu_plan_output_caps", "cbc_gpu_reserve_encode",
+           "cbc_gpu_decode_stream_blocks"]
 
 
 class Encoder:
@@ -390,6 +394,28 @@ class Encoder:
         if rc != 0 and rc != -4:
             self._check(rc, "cbc_gpu_encode_stream_blocks")
         return [out[int(offs[b]):int(offs[b + 1])].tobytes() for b in range(nb)], res
+
+    def decode_stream_blocks(self, payloads, pb: "host.PackedBatch", stride=None):
+        """cbc_gpu_decode_stream_blocks over the payloads of encode_stream_blocks(pb): general-form streams, one per block
+        (the fallback for blocks of more than CBC_MAX_BLOCK_READS records).  Returns (recs, bases[n, stride], results)."""
+        nb = pb.n_blocks
+        stride = stride or (pb.read_length + 3) // 4 * 4
+        flat = np.frombuffer(b"".join(payloads) + b"\0" * 16, dtype=np.uint8)
+        offs = np.concatenate([[0], np.cumsum([len(p) for p in payloads])]).astype(np.uint64)
+        blocks = np.zeros(nb, dtype=host.DEC_BLOCK_DTYPE)
+        rb = np.concatenate([[0], np.cumsum(pb.blocks["n_reads"].astype(np.uint64))])
+        blocks["in_off"] = offs[:-1]; blocks["in_bytes"] = np.diff(offs).astype(np.uint32)
+        blocks["ref_off"] = pb.blocks["ref_off"]; blocks["rec_base"] = rb[:-1]; blocks["seq_base"] = rb[:-1] * stride
+        blocks["n_reads"] = pb.blocks["n_reads"]; blocks["read_length"] = pb.read_length; blocks["seq_stride"] = stride
+        n = int(rb[-1])
+        recs = np.zeros(n, dtype=host.REC_DTYPE)
+        seq = np.zeros(n * stride + 16, dtype=np.uint8)
+        res = np.zeros(nb, dtype=host.RESULT_DTYPE)
+        rc = lib().cbc_gpu_decode_stream_blocks(self._ctx, flat.ctypes.data, flat.size - 16, blocks.ctypes.data, nb, recs.ctypes.data, n,
+                                                seq.ctypes.data, seq.size, res.ctypes.data)
+        if rc != 0 and rc != -4:
+            self._check(rc, "cbc_gpu_decode_stream_blocks")
+        return recs, seq[:n * stride].reshape(n, stride), res
 
     def decode_stream(self, stream: bytes, contigs, rec_cap=None):
         """Decode a whole-file stream against the uploaded reference; contigs = the packer's contig table

@@ -283,6 +283,13 @@ int  cbc_gpu_encode_stream(cbc_gpu_ctx *ctx, const cbc_host_batch *batch, uint8_
 int  cbc_gpu_encode_stream_blocks(cbc_gpu_ctx *ctx, const cbc_host_batch *batch, uint8_t *out, uint64_t out_cap,
                                   uint64_t *out_offsets /* n_blocks+1 */, cbc_block_result *results /* or NULL */);
 
+/* The decode twin of cbc_gpu_encode_stream_blocks: block b's payload (in[in_off .. + in_bytes)) is decoded as a one-contig
+ * stream whose contig is the block's reference window; records and bases go where cbc_gpu_decode_blocks would put them
+ * (recs[rec_base ..], seq[seq_base + r * seq_stride]; cbc_read_rec.seq_off = r * seq_stride, .tok_off = 0). */
+int  cbc_gpu_decode_stream_blocks(cbc_gpu_ctx *ctx, const uint8_t *in, uint64_t in_bytes, const cbc_dec_block_desc *blocks,
+                                  uint32_t n_blocks, cbc_read_rec *recs, uint64_t n_recs, uint8_t *seq, uint64_t seq_bytes,
+                                  cbc_block_result *results /* n_blocks or NULL */);
+
 /* Decode a whole-file stream.  contig_off[c] / contig_len[c]: where contig c (FASTA order) starts in the uploaded
  * reference and its length; the stream names contigs only by "next one" (decompress_line, compression.c:71-108).
  * recs[r] = { POS (1-based in its contig), FLAG, length, r * seq_stride (mod 2^32), contig index }, bases of record

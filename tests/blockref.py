@@ -250,7 +250,8 @@ class LongArgs(ctypes.Structure):
                 ("blocks", ctypes.c_void_p), ("ref", ctypes.c_void_p), ("out", ctypes.c_void_p), ("results", ctypes.c_void_p),
                 ("ref_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64), ("seq_bytes", ctypes.c_uint64),
                 ("n_tok", ctypes.c_uint64), ("n_recs", ctypes.c_uint64),
-                ("n_blocks", ctypes.c_uint32), ("cap_pos", ctypes.c_uint32), ("names_bytes", ctypes.c_uint32)]
+                ("n_blocks", ctypes.c_uint32), ("cap_pos", ctypes.c_uint32), ("names_bytes", ctypes.c_uint32),
+                ("scratch", ctypes.c_void_p)]                      # set by the emulation driver
 
 
 def emu_long_encode(pb, out_cap_per_base=2.0):
@@ -268,7 +269,7 @@ def emu_long_encode(pb, out_cap_per_base=2.0):
     res = np.zeros(pb.n_blocks, dtype=host.RESULT_DTYPE)
     a = LongArgs(pb.recs.ctypes.data, pb.seq.ctypes.data, pb.tok.ctypes.data, pb.names.ctypes.data, blocks.ctypes.data,
                  pb.ref.ctypes.data, out.ctypes.data, res.ctypes.data, len(pb.ref), off, len(pb.seq), pb.n_tok, pb.n_recs,
-                 pb.n_blocks, pb.cap_pos, len(pb.names))
+                 pb.n_blocks, pb.cap_pos, len(pb.names), None)
     if L.emu_long_encode_blocks(ctypes.byref(a)) != 0:
         raise RuntimeError("emulation reported an invariant violation")
     return [out[int(blocks[b]["out_off"]):int(blocks[b]["out_off"]) + int(res[b]["nbytes"])].tobytes() for b in range(pb.n_blocks)], res

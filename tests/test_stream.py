@@ -211,6 +211,22 @@ def test_gpu_stream_contigs_and_fallback(enc, built):
     assert int(r_blk[0]["status"]) == 7
     p_gen, r_gen = enc.encode_stream_blocks(big)
     assert int(r_gen[0]["status"]) == 0 and p_gen[0] == oracle.encode(sam, fa)
+    # ... and the decode twin of the general form: such a block back to its reads (the block decoder refuses it), and the
+    # ordinary blocks' general-form payloads too
+    recs, bases, dres = enc.decode_stream_blocks(p_gen, big)
+    want = _seq_column(sam)
+    assert int(dres[0]["status"]) == 0 and int(dres[0]["nbytes"]) == 40_000 and int(dres[0]["n_symbols"]) == int(r_gen[0]["n_symbols"])
+    assert all(bases[i, :len(w)].tobytes() == w for i, w in enumerate(want)) and (recs["pos"] == big.recs["pos"]).all()
+    text, nr = oracle.decode(p_gen[0], fa)
+    assert nr == 40_000 and text == b"".join(w + b"\n" for w in want)
+    fa5, sam5, _, _ = synth.dataset(5, [300000, 120000, 50000], [4000, 1500, 700], 100, sub_rate=0.02, indel_frac=0.5,
+                                    trailing_s_frac=0.2, dup_pos_frac=0.1)
+    enc.upload_reference(blk.ref)
+    p5, r5 = enc.encode_stream_blocks(blk)
+    recs, bases, dres = enc.decode_stream_blocks(p5, blk)
+    assert (dres["status"] == 0).all() and (recs["flag"] == blk.recs["flag"]).all() and (recs["pos"] == blk.recs["pos"]).all()
+    want5 = _seq_column(sam5)
+    assert len(want5) == blk.n_recs and all(bases[i, :len(w)].tobytes() == w for i, w in enumerate(want5))
 
 
 @pytest.mark.gpu
