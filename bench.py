@@ -82,6 +82,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="encode", choices=["encode", "decode"],
                     help="encode = BASELINE.json's metric (default); decode = the mirror kernel on the same workload "
                          "(the payloads are produced by one untimed encode launch and checked to decode to the packed bases)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: build the one-rank process group anyway and go through every collective of the N > 1 path "
+                         "(gather of the bitstreams, checksum exchange, cfg4 pass) -- how the RCCL call sites are rehearsed on a one-GPU box")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real path); gloo = rehearsal of the N>1 host logic when "
                          "several ranks must share one GPU (payloads take a detour through host memory)")
@@ -223,8 +226,11 @@ class Rank:
         self.backend = args.backend
         self.cdev = self.dev if args.backend == "nccl" else torch.device("cpu")     # where collectives run
         self.dist = dist
-        if self.world > 1:
+        self.multi = self.world > 1 or args.force_dist       # the exchange path runs (one rank: a self-gather)
+        if self.multi:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
             if args.backend == "nccl":
                 dist.init_process_group(backend="nccl", device_id=self.dev)
             else:
@@ -281,7 +287,7 @@ class Rank:
         me = {"rank": self.rank, "device_index": self.dev_index, "device": torch.cuda.get_device_name(self.dev),
               "arch": getattr(p, "gcnArchName", None), "pci_bus_id": getattr(p, "pci_bus_id", None),
               "compute_units": p.multi_processor_count}
-        if self.world == 1:
+        if not self.multi:
             return [me]
         out = [None] * self.world
         self.dist.all_gather_object(out, me)
@@ -293,6 +299,7 @@ def run_rank(args, R):
     import torch
     from cbc_amd import gpu, host, shard
     dist, rank, world, dev, cdev, enc, stream = R.dist, R.rank, R.world, R.dev, R.cdev, R.enc, R.stream
+    multi = R.multi
     strong = args.scaling == "strong" and world > 1
 
     # ---- workload (cfg2 shape), packed on the host, then made resident ----
@@ -365,7 +372,7 @@ def run_rank(args, R):
                 ev[1].record()
             return
         encode_once(ev=ev)
-        if world > 1:
+        if multi:
             dist.gather(d_packed[:gather_cap].to(cdev), gather_list, dst=0)
 
     # first launch: check every block finished and size the gather
@@ -379,9 +386,9 @@ def run_rank(args, R):
     payload_bytes = int(offs_first[my_blocks]) if my_blocks else 0
     n_symbols = int(res["n_symbols"].sum())
     first_payload = d_packed[:payload_bytes].clone()       # every later step must reproduce these bytes
-    first_sum = R.device_checksum(d_packed, payload_bytes) if world > 1 else None
+    first_sum = R.device_checksum(d_packed, payload_bytes) if multi else None
     strong_check = None
-    if world > 1:
+    if multi:
         m = torch.tensor([payload_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         gather_cap = min(packed_cap, (int(m.item()) + 4095) // 4096 * 4096)
@@ -457,7 +464,7 @@ def run_rank(args, R):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -465,11 +472,11 @@ def run_rank(args, R):
         step(kev[i])
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t_start
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -489,7 +496,7 @@ def run_rank(args, R):
             raise SystemExit("bench.py: the timed launches did not reproduce the first launch's bitstreams")
 
     rccl = None
-    if world > 1:
+    if multi:
         # the exchange proves itself: checksum of this rank's payload taken on its device vs what rank 0 holds after the
         # LAST timed gather (decode mode makes no gather inside the steps: one is made here)
         if args.mode == "decode":
@@ -523,7 +530,7 @@ def run_rank(args, R):
     cpu = None
     whole_file_bits = None
     verified = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not multi and not args.no_cpu_baseline:
         from oracle import oracle                            # the checker, also timed as the reported baseline
         # parse excluded + verification: the CPU port codes the VERY blocks the GPU coded (same packed batch), bounded by
         # --cpu-sample-reads; its bytes must equal the GPU's compacted payload over those blocks
@@ -567,11 +574,11 @@ def run_rank(args, R):
             spb.close()
 
     e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e and not long_fmt and args.mode == "encode":
+    if rank == 0 and world == 1 and not multi and not args.no_e2e and not long_fmt and args.mode == "encode":
         e2e = e2e_legs(args, enc, pb, first_payload, offs_first)
 
     cfg4 = None
-    if world > 1 and not args.no_cfg4 and not long_fmt and args.mode == "encode":
+    if multi and not args.no_cfg4 and not long_fmt and args.mode == "encode":
         del d_recs, d_seq, d_tok, d_out, d_packed, first_payload
         torch.cuda.empty_cache()
         cfg4 = cfg4_pass(args, R, args.scale if args.scale is not None else 0.1)
@@ -596,8 +603,8 @@ def run_rank(args, R):
                        "bits_per_read": round(payload_bytes * 8.0 / max(n_recs, 1), 3),
                        "whole_file_bits_per_read": whole_file_bits,
                        "symbols_per_read": round(n_symbols / max(n_recs, 1), 3),
-                       "parallelism": "one GPU, no collective" if world == 1 else
-                                      "blocks sharded over %d GPUs (one process each), gather of bitstreams to rank 0 (%s)" % (
+                       "parallelism": "one GPU, no collective" if not multi else
+                                      "blocks sharded over %d GPU(s) (one process each), gather of bitstreams to rank 0 (%s)" % (
                                           world, "RCCL" if args.backend == "nccl" else "gloo rehearsal"),
                        "gathered_equals_single_gpu": strong_check,
                        "host_pack_seconds": round(t_gen, 1),
@@ -737,6 +744,7 @@ def cfg4_pass(args, R, scale):
     import torch
     from cbc_amd import gpu, host
     dist, rank, world, dev, cdev, enc, stream = R.dist, R.rank, R.world, R.dev, R.cdev, R.enc, R.stream
+    multi = R.multi
     lens, reads = cfg4_workload(scale, args.read_len)
     part = assign_largest_first(reads, world)
     mine = [c for c in range(24) if part[c] == rank]
@@ -781,7 +789,7 @@ def cfg4_pass(args, R, scale):
         payload += C["bytes"]
     # this rank's bitstreams (all its contigs, contig order) as ONE buffer: what the exchange step sends
     gather_cap, gather_list = max(payload, 1), None
-    if world > 1:
+    if multi:
         m = torch.tensor([payload], dtype=torch.int64, device=cdev)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         gather_cap = max(int(m.item()), 1)
@@ -806,13 +814,13 @@ def cfg4_pass(args, R, scale):
         for x in side:
             x.synchronize()
         flatten()                                             # the per-step concatenation a real exchange needs
-        if world > 1:
+        if multi:
             dist.gather(flat.to(cdev), gather_list, dst=0)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -820,7 +828,7 @@ def cfg4_pass(args, R, scale):
         step()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t_start
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
@@ -828,7 +836,7 @@ def cfg4_pass(args, R, scale):
         raise SystemExit("bench.py (cfg4): the timed launches did not reproduce the first launch's bitstreams")
     tot = torch.tensor([float(n_bases), float(n_recs), float(n_blocks), float(payload), elapsed], dtype=torch.float64, device=cdev)
     table = None
-    if world > 1:
+    if multi:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         elapsed = float(mx[4].item())
         table = R.verify_exchange(gather_list, payload, first_sum, [int(t_local * 1e6 / args.steps), n_recs, len(mine)])
@@ -846,8 +854,8 @@ def cfg4_pass(args, R, scale):
                    "bits_per_read": round(total_payload * 8.0 / max(total_recs, 1), 3), "contigs_rank0": [GRCH38_NAMES[c] for c in mine],
                    "contig_to_rank": {GRCH38_NAMES[c]: part[c] for c in range(24)},
                    "reads_rank0": n_recs, "host_pack_seconds_rank0": round(t_gen, 1),
-                   "parallelism": "one GPU, no collective" if world == 1 else
-                                  "contigs sharded over %d GPUs (one process each), gather of bitstreams to rank 0 (%s)" % (
+                   "parallelism": "one GPU, no collective" if not multi else
+                                  "contigs sharded over %d GPU(s) (one process each), gather of bitstreams to rank 0 (%s)" % (
                                       world, "RCCL" if args.backend == "nccl" else "gloo rehearsal")},
         "roofline": {"bound": "hbm", "achieved": round(alg, 3), "peak": HBM_PEAK_GBS * world,
                      "unit": "GB/s", "frac": round(alg / (HBM_PEAK_GBS * world), 6),
@@ -874,7 +882,7 @@ def main():
             print(json.dumps(out), flush=True)
     else:
         run_rank(args, R)
-    if R.world > 1:
+    if R.multi:
         R.dist.destroy_process_group()
 
 

@@ -43,7 +43,8 @@
 #define CBC_LLDS_BATCH  (CBC_LLDS_ROLE + CBC_RING_WORDS)            /* encode: CBC_BATCH_SLOTS x CBC_BATCH_WORDS */
 #define CBC_LLDS_CTL    (CBC_LLDS_BATCH + CBC_BATCH_SLOTS * CBC_BATCH_WORDS)   /* encode: 8 */
 #define CBC_LLDS_HIST   CBC_LLDS_ROLE                               /* decode: 512 */
-#define CBC_LLDS_FIXED  (CBC_LLDS_CTL + 8u)
+#define CBC_LLDS_TRIP   (CBC_LLDS_CTL + 8u)                         /* encode: 3 x 192: the (cum, count, total) triples of a batch of 64 edits */
+#define CBC_LLDS_FIXED  (CBC_LLDS_TRIP + 576u)
 static inline uint32_t cbc_long_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_LLDS_FIXED + 2u * cap_pos); }
 /* global scratch of a block, in words: [8 x 192 gap symbols 64..255][2 x 256 gx] */
 #define CBC_LSCR_GAPHI  0u
@@ -231,6 +232,140 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         E.regsparse_code(E.hkey, E.hexc, 16u, 8u, E.hc2, E.hn2, 256u, 1u, (v >> 8) & 0xffu, CBC_ST_ASSERT);
         E.regsparse_code(E.hkey, E.hexc, 24u, 8u, E.hc3, E.hn3, 256u, 1u, v & 0xffu, CBC_ST_ASSERT);
     };
+    /* ---- the edits of a read reach the models in batches of up to 64, one lane per edit.  Within a batch every model is a
+     * COUNTING model (no total can reach the rescale point inside it -- checked, else the batch goes the serial way): the
+     * (cum, count, total) a symbol sees = the tables before the batch + what the lower lanes of the batch add, which
+     * gathers, ballots and one 64-step compare loop give to all lanes at once.  The serial form of this -- three model
+     * calls per edit on wave-uniform values -- kept the CU's one scalar unit 55 % busy (profiles/r03_e_long_encode_pmc.json:
+     * 106 scalar + 80 vector instructions per coded symbol).  An edit word: M coordinate | kind << 16 | read base << 18 |
+     * chars row << 21; carry_end / carry_pk: M coordinate after, and kind of, the previous edit of the read. ---- */
+    V32 eb = W::splat(0u); uint32_t ecount = 0, carry_end = 0, carry_pk = 3u;
+    uint32_t *trip = lds + CBC_LLDS_TRIP;
+    auto serial_edit = [&](uint32_t g, uint32_t pk, uint32_t strand, uint32_t kind, uint32_t row, uint32_t base) {
+        if (E.q_len >= 56u) E.drain();
+        gap_code(2u * pk + strand, g < 255u ? g : 255u);
+        if (g >= 255u) { gx_code(0u, ((g - 255u) >> 8) & 0xffu); gx_code(1u, (g - 255u) & 0xffu); }
+        E.small_code(cbc_long_kind_base(pk), 3u, 8u, kind);
+        if (kind != 2u) E.small_code(CBC_LT_CHARS + row * 8u, 5u, 8u, base);
+    };
+    auto flush_edits = [&](uint32_t strand) {
+        const uint32_t m = ecount;
+        ecount = 0;
+        if (m == 0u || E.status != CBC_ST_OK) return;
+        const Mask live = ln < m;
+        const V32 mc = eb & 0xffffu, kind = (eb >> 16) & 3u, base = (eb >> 18) & 7u, row = (eb >> 21) & 7u;
+        const V32 mend = mc + W::select(kind == 0u, W::splat(1u), W::splat(0u));
+        const V32 pk = W::shift_up1(kind, carry_pk);
+        const V32 g = mc - W::shift_up1(mend, carry_end);
+        const V32 t = pk * 2u + strand;
+        const uint32_t next_end = W::readlane(mend, m - 1u), next_pk = W::readlane(kind, m - 1u);
+        /* lane-table models: prefix sums over the lanes of `small` give every context's (cum, total) by three gathers */
+        const V32 P = W::scan_incl_add(E.small);
+        const V32 kb = W::select(pk < 2u, pk * 3u, (pk - 2u) * 3u + 10u);             /* cbc_long_kind_base per lane */
+        const V32 cb = row * 8u + CBC_LT_CHARS;
+        auto below = [&](const V32 &first) -> V32 { return W::select(first == 0u, W::splat(0u), W::lane_gather(P, first - 1u)); };
+        const V32 k_lo0 = W::select(kind == 0u, W::splat(0u), W::lane_gather(P, kb + kind - 1u) - below(kb)), k_n0 = W::lane_gather(P, kb + 2u) - below(kb);
+        const V32 k_c0 = W::lane_gather(E.small, kb + kind);
+        const V32 c_lo0 = W::select(base == 0u, W::splat(0u), W::lane_gather(P, cb + base - 1u) - below(cb)), c_n0 = W::lane_gather(P, cb + 4u) - below(cb);
+        const V32 c_c0 = W::lane_gather(E.small, cb + base);
+        const Mask has_base = live & (kind != 2u);
+        const V32 g_n0 = W::lane_gather(ntab, t);
+        /* the serial way: a gap that needs its two gx bytes, or a total within a batch of its rescale point (once in ~10^5 uses) */
+        const uint64_t odd = W::ballot(live & ((g >= 255u) | (g_n0 + 640u >= CBC_RESCALE) | (k_n0 + 512u >= CBC_RESCALE))) |
+                             W::ballot(has_base & (c_n0 + 512u >= CBC_RESCALE));
+        if (odd) {
+            for (uint32_t j = 0; j < m && E.status == CBC_ST_OK; j++)
+                serial_edit(W::readlane(g, j), W::readlane(pk, j), strand, W::readlane(kind, j), W::readlane(row, j), W::readlane(base, j));
+            carry_end = next_end; carry_pk = next_pk;
+            return;
+        }
+        /* -- gap: the table rows before the batch -- */
+        const Mask glo = live & (g < 64u), ghi = live & (g >= 64u);
+        const V32 gk = g - 64u;                                   /* index in the global row (ghi lanes) */
+        V32 g_e0 = W::load32(lds + CBC_LLDS_GAPLO, t * 64u + g, glo, 0u), g_pre = W::splat(0u);
+        if (W::ballot(ghi)) {
+            W::list_fence();
+            g_e0 = W::select(ghi, W::load32_list(scr + CBC_LSCR_GAPHI, t * 192u + gk, ghi, 0u), g_e0);
+            g_pre = W::select(ghi, W::lane_gather(lsum, t), g_pre);      /* everything the row holds below symbol 64 */
+        }
+        for (uint32_t tt = 0; tt < 8u; tt++) {
+            const Mask mine = live & (t == tt);
+            if (!W::ballot(mine)) continue;
+            const V32 Pl = W::scan_incl_add(W::load32(lds + CBC_LLDS_GAPLO + 64u * tt, ln, W::all(), 0u));
+            g_pre = W::select(mine & glo & (g != 0u), W::lane_gather(Pl, g - 1u), g_pre);
+            if (W::ballot(mine & ghi)) {
+                uint32_t run = 0;
+                for (uint32_t c = 0; c < 3u; c++) {
+                    const V32 Pc = W::scan_incl_add(W::load32_list(scr + CBC_LSCR_GAPHI + 192u * tt, ln + 64u * c, W::all(), 0u)) + run;
+                    g_pre = g_pre + W::select(mine & ghi & (gk != 0u) & (((gk - 1u) >> 6) == c), W::lane_gather(Pc, (gk - 1u) & 63u), W::splat(0u));
+                    run = W::readlane(Pc, 63u);
+                }
+            }
+        }
+        /* -- what the lower lanes of the batch add: same table and a smaller / the same gap; same table at all -- */
+        V32 ga = W::splat(0u), gb = W::splat(0u), gc = W::splat(0u);
+        for (uint32_t j = 0; j + 1u < m; j++) {
+            const uint32_t tj = W::readlane(t, j), gj = W::readlane(g, j);
+            const Mask same = (t == tj) & (ln > j);
+            gc = gc + W::select(same, W::splat(10u), W::splat(0u));
+            ga = ga + W::select(same & (g > gj), W::splat(10u), W::splat(0u));
+            gb = gb + W::select(same & (g == gj), W::splat(10u), W::splat(0u));
+        }
+        const V32 g_lo = g + g_pre + ga, g_cnt = g_e0 + 1u + gb, g_n = g_n0 + gc;
+        /* -- kind (4 contexts x 3) and chars (6 rows x 5): the batch's uses per (context, symbol), lower lanes by v_mbcnt -- */
+        V32 ka = W::splat(0u), kbq = W::splat(0u), kc = W::splat(0u), ca = W::splat(0u), cbq = W::splat(0u), cc = W::splat(0u), upd = W::splat(0u);
+        for (uint32_t ctx = 0; ctx < 4u; ctx++) for (uint32_t sy = 0; sy < 3u; sy++) {
+            const uint64_t um = W::ballot(live & (pk == ctx) & (kind == sy));
+            if (!um) continue;
+            const V32 pp = W::prefix_popc(um) * 8u;
+            const Mask in = live & (pk == ctx);
+            kc = kc + W::select(in, pp, W::splat(0u));
+            ka = ka + W::select(in & (kind > sy), pp, W::splat(0u));
+            kbq = kbq + W::select(in & (kind == sy), pp, W::splat(0u));
+            upd = upd + W::select(ln == cbc_long_kind_base(ctx) + sy, W::splat(8u * W::popc64(um)), W::splat(0u));
+        }
+        for (uint32_t rw = 0; rw < 6u; rw++) {
+            if (!W::ballot(has_base & (row == rw))) continue;
+            for (uint32_t sy = 0; sy < 5u; sy++) {
+                const uint64_t um = W::ballot(has_base & (row == rw) & (base == sy));
+                if (!um) continue;
+                const V32 pp = W::prefix_popc(um) * 8u;
+                const Mask in = has_base & (row == rw);
+                cc = cc + W::select(in, pp, W::splat(0u));
+                ca = ca + W::select(in & (base > sy), pp, W::splat(0u));
+                cbq = cbq + W::select(in & (base == sy), pp, W::splat(0u));
+                upd = upd + W::select(ln == CBC_LT_CHARS + rw * 8u + sy, W::splat(8u * W::popc64(um)), W::splat(0u));
+            }
+        }
+        /* -- the tables after the batch -- */
+        E.small = E.small + upd;
+        W::lds_add(lds + CBC_LLDS_GAPLO, t * 64u + g, W::splat(10u), glo);
+        W::list_add(scr + CBC_LSCR_GAPHI, t * 192u + gk, W::splat(10u), ghi);
+        for (uint32_t tt = 0; tt < 8u; tt++) {
+            const uint64_t um = W::ballot(live & (t == tt));
+            if (!um) continue;
+            const uint32_t nlo = W::popc64(W::ballot(glo & (t == tt)));
+            ntab = ntab + W::select(ln == tt, W::splat(10u * W::popc64(um)), W::splat(0u));
+            lsum = lsum + W::select(ln == tt, W::splat(10u * nlo), W::splat(0u));
+        }
+        /* -- the triples, in stream order: gap, kind, [base] per edit -- */
+        const uint64_t delm = W::ballot(live & (kind == 2u));
+        const V32 o = ln * 3u - W::prefix_popc(delm);
+        const uint32_t total = 3u * m - W::popc64(delm);
+        W::store32(trip, o, g_lo, live); W::store32(trip + 192u, o, g_cnt, live); W::store32(trip + 384u, o, g_n, live);
+        W::store32(trip, o + 1u, k_lo0 + ka, live); W::store32(trip + 192u, o + 1u, k_c0 + kbq, live); W::store32(trip + 384u, o + 1u, k_n0 + kc, live);
+        W::store32(trip, o + 2u, c_lo0 + ca, has_base); W::store32(trip + 192u, o + 2u, c_c0 + cbq, has_base); W::store32(trip + 384u, o + 2u, c_n0 + cc, has_base);
+        if (E.q_len) E.drain();                                   /* what the record's header left queued goes first */
+        for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+            const uint32_t cnt = total - c0 < 64u ? total - c0 : 64u;
+            E.q_lo = W::load32(trip, ln + c0, ln < cnt, 0u); E.q_cnt = W::load32(trip + 192u, ln + c0, ln < cnt, 1u);
+            E.q_n = W::load32(trip + 384u, ln + c0, ln < cnt, 1u);
+            E.q_len = cnt;
+            E.drain();
+        }
+        carry_end = next_end; carry_pk = next_pk;
+    };
+
     if (E.status == CBC_ST_OK) { code_int(CBC_LONG_MAGIC); code_int(8u); E.drain(); }
 
     const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
@@ -322,17 +457,13 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         if (E.status != CBC_ST_OK) break;
         sp_code(CBC_LS_NE, ne >> 8, r); sp_code(CBC_LS_NE + 1u, ne & 0xffu, r);
 
-        /* -- pass 1: the edits, in read order -- */
-        uint32_t i = 0, since = 0, pk = 3u; uint32_t jr = pos - 1u;           /* read index, matched run, previous kind, reference index */
-        auto edit = [&](uint32_t kind, uint32_t row, uint32_t base) {
-            if (E.q_len >= 56u) E.drain();
-            const uint32_t g = since;
-            gap_code(2u * pk + strand, g < 255u ? g : 255u);
-            if (g >= 255u) { gx_code(0u, ((g - 255u) >> 8) & 0xffu); gx_code(1u, (g - 255u) & 0xffu); }
-            E.small_code(cbc_long_kind_base(pk), 3u, 8u, kind);
-            if (kind != 2u) E.small_code(CBC_LT_CHARS + row * 8u, 5u, 8u, base);
-            pk = kind;
-            since = 0;
+        /* -- pass 1: the edits, in read order.  The walk only COLLECTS them, one lane each (M coordinate, kind, bases); every
+         *    64 -- and at the end of the read -- flush_edits() turns the batch into model triples, all lanes at once -- */
+        uint32_t i = 0, mcoord = 0; uint32_t jr = pos - 1u;                 /* read index, M bases consumed, reference index */
+        carry_end = 0; carry_pk = 3u;
+        auto push = [&](uint32_t mc, uint32_t kind, uint32_t row, uint32_t base) {
+            eb = W::select(ln == ecount, W::splat(mc | (kind << 16) | (base << 18) | (row << 21)), eb);
+            if (++ecount == 64u) flush_edits(strand);
         };
         V32 tokv = W::splat(0u);
         for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
@@ -342,7 +473,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                 const uint32_t lb = W::uni(len);
                 uint32_t cn = len < 256u ? len : 256u;
                 V32 rd_n = W::load32_bytes(rdb + i, bo, bo < cn), rf_n = W::load32_bytes(refb + jr, bo, bo < cn);
-                for (uint32_t b = 0; b < lb; b += 256u) {
+                for (uint32_t b = 0; b < lb && E.status == CBC_ST_OK; b += 256u) {
                     const uint32_t c = cn;
                     const V32 rd = rd_n, rf = rf_n;
                     if (b + 256u < len) {                                  /* the next chunk's loads go out before this one is walked */
@@ -351,32 +482,28 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                     }
                     const V32 x = (rd ^ rf) & chunk_mask(c);
                     uint64_t mm = W::ballot(x != 0u);
-                    uint32_t next = 0;                                     /* first base of the chunk not yet accounted for */
                     while (mm && E.status == CBC_ST_OK) {
                         const uint32_t k = W::ctz64(mm); mm &= mm - 1ull;
                         const uint32_t xk = W::readlane(x, k), rdk = W::readlane(rd, k), rfk = W::readlane(rf, k);
-                        for (uint32_t q = 0; q < 4u; q++) if ((xk >> (8u * q)) & 0xffu) {
-                            const uint32_t p = 4u * k + q;
-                            since += p - next; next = p + 1u;
-                            edit(0u, cbc_basepair((rfk >> (8u * q)) & 0xffu), cbc_basepair((rdk >> (8u * q)) & 0xffu));
-                        }
+                        for (uint32_t q = 0; q < 4u; q++) if ((xk >> (8u * q)) & 0xffu)
+                            push(mcoord + b + 4u * k + q, 0u, cbc_basepair((rfk >> (8u * q)) & 0xffu), cbc_basepair((rdk >> (8u * q)) & 0xffu));
                     }
-                    since += c - next;
                 }
-                i += len; jr += len;
+                i += len; jr += len; mcoord += len;
             } else if (op == CBC_OP_I || op == CBC_OP_S) {
                 const uint32_t lb = W::uni(len);
                 for (uint32_t b = 0; b < lb && E.status == CBC_ST_OK; b += 64u) {        /* the inserted bases, 64 per load */
                     const uint32_t c = len - b < 64u ? len - b : 64u;
                     const V32 ib = W::load8(rdb, ln + (i + b), ln < c);
-                    for (uint32_t q = 0; q < c && E.status == CBC_ST_OK; q++) edit(1u, 5u, cbc_basepair(W::readlane(ib, q)));
+                    for (uint32_t q = 0; q < c && E.status == CBC_ST_OK; q++) push(mcoord, 1u, 5u, cbc_basepair(W::readlane(ib, q)));
                 }
                 i += len;
             } else {                                                       /* D (pass 0 refused everything else) */
-                for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) edit(2u, 0u, 0u);
+                for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) push(mcoord, 2u, 0u, 0u);
                 jr += len;
             }
         }
+        flush_edits(strand);
     }
     if (E.status == CBC_ST_OK) {
         E.cur_read = n_reads;

@@ -192,6 +192,11 @@ struct WaveGPU {
     {
         if (m) __hip_atomic_store(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    /* += into such a list, lanes may name the same word */
+    static CBC_FN void list_add(uint32_t *p, V32 idx, V32 val, Mask m)
+    {
+        if (m) __hip_atomic_fetch_add(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     static CBC_FN void append_list(uint32_t *p, uint32_t idx, uint32_t val)
     {
         if (lane() == 0) __hip_atomic_store(p + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

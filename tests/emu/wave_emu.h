@@ -148,6 +148,7 @@ struct WaveEmu {
     }
     static V32 load32_list(const uint32_t *p, const V32 &idx, const Mask &m, uint32_t other) { return load32(p, idx, m, other); }
     static void append_list(uint32_t *p, uint32_t idx, uint32_t val) { p[idx] = val; }
+    static void list_add(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m) { for (int i = 0; i < 64; i++) if (m.b[i]) p[idx.v[i]] += val.v[i]; }
     static void store32_list(uint32_t *p, const V32 &idx, const V32 &val, const Mask &m) { store32(p, idx, val, m); }
     static void list_fence() {}
     static uint32_t read_uni(const uint32_t *p, uint32_t idx) { return p[idx]; }
