@@ -85,7 +85,10 @@ __global__ void __launch_bounds__(64)
 cbc_decode_whole_kernel(cbc_dstream_args A) { cbc_decode_whole<WaveGPU>(A, cbc_lds); }
 
 /* long-read format (cbc_long_body.h): one wavefront per block */
-__global__ void __launch_bounds__(128)
+#ifndef CBC_LONG_ENC_WAVES
+#define CBC_LONG_ENC_WAVES 3           /* wavefronts per SIMD the register budget is cut for (A/B: profiles/r03_ab_kernels.log) */
+#endif
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CBC_LONG_ENC_WAVES)))
 cbc_long_encode_kernel(cbc_long_args A)
 {
     if (blockIdx.x >= A.n_blocks) return;
@@ -1203,8 +1206,8 @@ API int cbc_gpu_long_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device
     A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
     A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = 0;
     /* the blocks' global-memory table parts (cbc_long_body.h): the context's own buffer -- batch->d_var_scratch is not used */
-    { int rc_ = arena_need(ctx, A_LSCR, (uint64_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS * 4 + 256, "hipMalloc long-read table scratch"); if (rc_) return rc_; }
-    A.var_scratch = (uint32_t *)ctx->arena[A_LSCR].p; A.var_scratch_words = (uint64_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS;
+    { int rc_ = arena_need(ctx, A_LSCR, (uint64_t)b->n_blocks * CBC_LONG_TABLE_WORDS * 4 + 256, "hipMalloc long-read table scratch"); if (rc_) return rc_; }
+    A.var_scratch = (uint32_t *)ctx->arena[A_LSCR].p; A.var_scratch_words = (uint64_t)b->n_blocks * CBC_LONG_TABLE_WORDS;
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
     hipLaunchKernelGGL(cbc_long_decode_kernel, dim3(b->n_blocks), dim3(64), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_long_decode_kernel");

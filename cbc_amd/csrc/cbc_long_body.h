@@ -49,7 +49,12 @@ static inline uint32_t cbc_long_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_L
 /* global scratch of a block, in words: [8 x 192 gap symbols 64..255][2 x 256 gx] */
 #define CBC_LSCR_GAPHI  0u
 #define CBC_LSCR_GX     1536u
-#define CBC_LONG_SCRATCH_WORDS 2048u
+#define CBC_LSCR_EDITS  2048u      /* encode: the edits of the read being coded (their count precedes them in the stream) */
+#ifndef CBC_LONG_EDIT_CAP
+#define CBC_LONG_EDIT_CAP 8192u    /* a read with more edits than this is walked twice (count, then code) */
+#endif
+#define CBC_LONG_TABLE_WORDS 2048u                                   /* what the decoder needs per block */
+#define CBC_LONG_SCRATCH_WORDS (2048u + CBC_LONG_EDIT_CAP)           /* ... and the encoder */
 
 /* gap tables: index 0..7 = 2 * prev_kind + strand; gx: 0..1; sparse lists: 0..3 len, 4..5 ne */
 #define CBC_LS_LEN 0u
@@ -69,6 +74,42 @@ struct cbc_long_args {
     uint64_t ref_bytes, out_bytes, seq_bytes, n_tok, n_recs;
     uint32_t n_blocks, cap_pos, names_bytes;
     uint32_t *scratch;                  /* n_blocks x CBC_LONG_SCRATCH_WORDS (no initial content needed) */
+};
+
+/* 512 consecutive bytes of a byte array in two vector registers (4 bytes per lane: [base, base + 256) and the 256 after
+ * them) with a third register loaded one window further ahead; unaligned dwords per lane come out of the two by lane
+ * gathers and a funnel shift -- no memory access.  The encoder walks a read and its reference through such windows: a 10 kb
+ * read with 5 % edits has ~340 CIGAR runs of ~30 bases, and a global-memory round trip per run was nine tenths of the model
+ * wavefront's time once the models themselves ran a batch at a time (profiles/r03_i_ab_long.log: 2800 cycles per run). */
+template <class W>
+struct CbcLWin {
+    typedef typename W::V32 V32;
+    V32 cur, nx1, nx2; uint32_t base, lim; const uint8_t *p;
+    CBC_MFN V32 ld(uint32_t b)
+    {
+        const V32 bo = W::lane() * 4u;
+        return W::load32_bytes(p + b, bo, (bo + b < lim) & ((lim - b - bo) >= 4u));      /* bytes past `lim` read as 0 */
+    }
+    CBC_MFN void reset(const uint8_t *p_, uint32_t lim_, uint32_t pos)
+    {
+        p = p_; lim = lim_; base = pos & ~3u; cur = ld(base); nx1 = ld(base + 256u); nx2 = ld(base + 512u);
+    }
+    CBC_MFN void to(uint32_t pos)                              /* afterwards base <= pos < base + 256 */
+    {
+        while (pos - base >= 256u) {
+            if (pos - base < 768u) { cur = nx1; nx1 = nx2; base += 256u; nx2 = ld(base + 512u); }
+            else { reset(p, lim, pos); }
+        }
+    }
+    /* lane l: bytes [pos + 4l, pos + 4l + 4); wants base <= pos < base + 256; bytes from base + 512 on are garbage */
+    CBC_MFN V32 dwords(uint32_t pos)
+    {
+        const uint32_t off = pos - base;
+        const V32 wi = W::lane() + (off >> 2);
+        const V32 lo = W::select(wi < 64u, W::lane_gather(cur, wi), W::lane_gather(nx1, wi));
+        const V32 hi = W::select(wi + 1u < 64u, W::lane_gather(cur, wi + 1u), W::lane_gather(nx1, wi + 1u));
+        return W::funnel_shr(hi, lo, (off & 3u) * 8u);
+    }
 };
 
 /* One block = one stream, coded by TWO wavefronts (round 3; ROLE = CBC_ROLE_MODEL / CBC_ROLE_CODER, as in the block encoder;
@@ -107,6 +148,10 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                    cbc_fits64(tok_base, n_tok_blk, A.n_tok) && (name_off < A.names_bytes) && A.cap_pos >= 2u && n_reads <= 64u &&
                    A.scratch != nullptr;
     if (!args_ok) { E.cap_words = 0; E.fail(CBC_ST_ASSERT); }
+#ifdef CBC_STAMP
+    for (int i = 0; i < 16; i++) E.t_sum[i] = 0;
+    CBC_T0();
+#endif
 
     /* ================================ coder wavefront ======================================= */
     if (ROLE == CBC_ROLE_CODER) {
@@ -116,6 +161,11 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         uint32_t nbytes = 0;
         if (E.status == CBC_ST_OK) { E.flush_recs(); nbytes = E.finish(); }
         if (E.status != CBC_ST_OK) nbytes = 0;
+#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+        CBC_TS(9);
+        if (out_cap >= 512u) for (int i = 0; i < 16; i++) {      /* diagnostic build: over the payload start */
+            W::write_uni(E.out32, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.out32, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); }
+#endif
         V32 resv = W::select(ln == 0u, W::splat(nbytes), W::select(ln == 1u, W::splat(E.status),
                    W::select(ln == 2u, W::splat(E.nsym), W::splat(E.fail_read))));
         W::store32((uint32_t *)(A.results + blk), ln, resv, ln < 4u);
@@ -132,7 +182,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     E.p0cnt = W::splat(0u); E.p0over = 0;
     uint32_t *scr = A.scratch + (uint64_t)blk * CBC_LONG_SCRATCH_WORDS;
     for (uint32_t b = 0; b < CBC_LLDS_SP; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());        /* gap symbols 0..63 */
-    if (E.status == CBC_ST_OK) for (uint32_t b = 0; b < CBC_LONG_SCRATCH_WORDS; b += 64u) W::store32_list(scr, ln + b, W::splat(0u), W::all());   /* the rest, gx */
+    if (E.status == CBC_ST_OK) for (uint32_t b = 0; b < CBC_LONG_TABLE_WORDS; b += 64u) W::store32_list(scr, ln + b, W::splat(0u), W::all());   /* the rest, gx */
     if (ROLE == CBC_ROLE_FUSED) for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
     W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);
     E.snps_n = 0; E.indels_n = 0; E.pos_card = 1u;
@@ -252,6 +302,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         const uint32_t m = ecount;
         ecount = 0;
         if (m == 0u || E.status != CBC_ST_OK) return;
+        CBC_TS(0);                                                /* the walk that collected the batch */
         const Mask live = ln < m;
         const V32 mc = eb & 0xffffu, kind = (eb >> 16) & 3u, base = (eb >> 18) & 7u, row = (eb >> 21) & 7u;
         const V32 mend = mc + W::select(kind == 0u, W::splat(1u), W::splat(0u));
@@ -355,6 +406,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         W::store32(trip, o, g_lo, live); W::store32(trip + 192u, o, g_cnt, live); W::store32(trip + 384u, o, g_n, live);
         W::store32(trip, o + 1u, k_lo0 + ka, live); W::store32(trip + 192u, o + 1u, k_c0 + kbq, live); W::store32(trip + 384u, o + 1u, k_n0 + kc, live);
         W::store32(trip, o + 2u, c_lo0 + ca, has_base); W::store32(trip + 192u, o + 2u, c_c0 + cbq, has_base); W::store32(trip + 384u, o + 2u, c_n0 + cc, has_base);
+        CBC_TS(1);                                                /* the batch's model arithmetic */
         if (E.q_len) E.drain();                                   /* what the record's header left queued goes first */
         for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
             const uint32_t cnt = total - c0 < 64u ? total - c0 : 64u;
@@ -363,6 +415,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
             E.q_len = cnt;
             E.drain();
         }
+        CBC_TS(7);                                                /* hand-over of the triples (waiting for a slot: 6) */
         carry_end = next_end; carry_pk = next_pk;
     };
 
@@ -419,91 +472,92 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         const uint32_t hdr = W::read_uni(tokb, to), n_cig = hdr & 0xffffu;
         if (to + 2u + n_cig > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
 
-        /* -- pass 0: the number of edits, which the stream carries before them.  Nothing serial: mismatches are counted by
-         *    four ballots per 256 bases, I / S / D runs by their length -- */
-        uint32_t ne = 0;
-        {
-            uint32_t i = 0, jr = pos - 1u;
+        /* -- the edits, in read order.  ONE walk along the CIGAR collects them (read and reference come through register
+         *    windows: no memory access per CIGAR run), 64 at a time into the block's edit buffer in global memory; their
+         *    number, which the stream carries first, is then known, and the buffer is read back a batch at a time into
+         *    flush_edits().  A read with more edits than the buffer holds is walked a second time instead. -- */
+        uint32_t *ebuf = scr + CBC_LSCR_EDITS;
+        CbcLWin<W> rw, fw;
+        uint32_t over = 0;                                        /* first walk: the buffer is full, it only counts from there */
+        auto walk = [&](const bool second) -> uint32_t {
+            uint32_t i = 0, mcoord = 0, n = 0, stored = 0; uint32_t jr = pos - 1u;    /* read index, M bases consumed, edits, reference index */
+            over = 0; ecount = 0;
+            rw.reset(rdb, rl + 3u, 0u); fw.reset(refb, ref_lim, jr);
+            auto emit = [&](uint32_t mc, uint32_t kind, uint32_t row, uint32_t base) {
+                n++;
+                if (over) return;
+                eb = W::select(ln == ecount, W::splat(mc | (kind << 16) | (base << 18) | (row << 21)), eb);
+                if (++ecount < 64u) return;
+                if (second) flush_edits(strand);
+                else if (stored + 64u <= CBC_LONG_EDIT_CAP) { W::store32_list(ebuf, ln + stored, eb, W::all()); stored += 64u; ecount = 0; }
+                else { over = 1u; ecount = 0; }
+            };
             V32 tokv = W::splat(0u);
             for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
                 if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
                 const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
                 if (op == CBC_OP_M) {
                     if (len > rl - i || jr > ref_lim || len > ref_lim - jr || ref_lim - jr - len < 3u) { E.fail(CBC_ST_ASSERT); break; }
-                    const uint32_t lb = W::uni(len);
-                    uint32_t nm = 0;
-                    for (uint32_t b = 0; b < lb; b += 512u) {           /* two chunks per trip: four loads in flight */
-                        const uint32_t c0 = len - b < 256u ? len - b : 256u, c1 = len - b > 256u ? (len - b - 256u < 256u ? len - b - 256u : 256u) : 0u;
-                        const V32 rd0 = W::load32_bytes(rdb + (i + b), bo, bo < c0), rf0 = W::load32_bytes(refb + (jr + b), bo, bo < c0);
-                        const V32 rd1 = W::load32_bytes(rdb + (i + b + 256u), bo, bo < c1), rf1 = W::load32_bytes(refb + (jr + b + 256u), bo, bo < c1);
-                        const V32 x0 = (rd0 ^ rf0) & chunk_mask(c0), x1 = (rd1 ^ rf1) & chunk_mask(c1);
-                        nm += W::popc64(W::ballot((x0 & 0xffu) != 0u)) + W::popc64(W::ballot((x0 & 0xff00u) != 0u)) +
-                              W::popc64(W::ballot((x0 & 0xff0000u) != 0u)) + W::popc64(W::ballot((x0 >> 24) != 0u));
-                        nm += W::popc64(W::ballot((x1 & 0xffu) != 0u)) + W::popc64(W::ballot((x1 & 0xff00u) != 0u)) +
-                              W::popc64(W::ballot((x1 & 0xff0000u) != 0u)) + W::popc64(W::ballot((x1 >> 24) != 0u));
+                    for (uint32_t b = 0; b < len && E.status == CBC_ST_OK; ) {
+                        /* a piece of the run: at most 256 bases, all inside both 512-byte windows (+ 3 bytes of dword slack) */
+                        rw.to(i + b); fw.to(jr + b);
+                        uint32_t c = len - b < 256u ? len - b : 256u;
+                        const uint32_t room_r = 509u - (i + b - rw.base), room_f = 509u - (jr + b - fw.base);
+                        if (c > room_r) c = room_r;
+                        if (c > room_f) c = room_f;
+                        const V32 rd = rw.dwords(i + b), rf = fw.dwords(jr + b);
+                        const V32 x = (rd ^ rf) & chunk_mask(c);
+                        uint64_t mm = W::ballot(x != 0u);
+                        while (mm && E.status == CBC_ST_OK) {
+                            const uint32_t k = W::ctz64(mm); mm &= mm - 1ull;
+                            const uint32_t xk = W::readlane(x, k), rdk = W::readlane(rd, k), rfk = W::readlane(rf, k);
+                            for (uint32_t q = 0; q < 4u; q++) if ((xk >> (8u * q)) & 0xffu)
+                                emit(mcoord + b + 4u * k + q, 0u, cbc_basepair((rfk >> (8u * q)) & 0xffu), cbc_basepair((rdk >> (8u * q)) & 0xffu));
+                        }
+                        b += c;
                     }
-                    ne += nm; i += len; jr += len;
+                    i += len; jr += len; mcoord += len;
                 } else if (op == CBC_OP_I || op == CBC_OP_S) {
                     if (len > rl - i) { E.fail(CBC_ST_ASSERT); break; }
-                    ne += len; i += len;
+                    for (uint32_t b = 0; b < len && E.status == CBC_ST_OK; ) {          /* the inserted bases, through the read window */
+                        rw.to(i + b);
+                        uint32_t c = len - b < 256u ? len - b : 256u;
+                        const uint32_t room = 509u - (i + b - rw.base);
+                        if (c > room) c = room;
+                        const V32 ib = rw.dwords(i + b);
+                        for (uint32_t q = 0; q < c && E.status == CBC_ST_OK; q++)
+                            emit(mcoord, 1u, 5u, cbc_basepair((W::readlane(ib, q >> 2) >> (8u * (q & 3u))) & 0xffu));
+                        b += c;
+                    }
+                    i += len;
                 } else if (op == CBC_OP_D) {
                     if (jr > ref_lim || len > ref_lim - jr) { E.fail(CBC_ST_ASSERT); break; }
-                    ne += len; jr += len;
+                    for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) emit(mcoord, 2u, 0u, 0u);
+                    jr += len;
                 } else { E.fail(CBC_ST_UNSUPPORTED); break; }
-                if (ne > 0xffffu) { E.fail(CBC_ST_ASSERT); break; }                /* the edit count is a u16 in the stream */
+                if (n > 0xffffu) { E.fail(CBC_ST_ASSERT); break; }                    /* the edit count is a u16 in the stream */
             }
-            if (E.status == CBC_ST_OK && i != rl) E.fail(CBC_ST_ASSERT);          /* the CIGAR must consume the read exactly */
-        }
-        if (E.status != CBC_ST_OK) break;
-        sp_code(CBC_LS_NE, ne >> 8, r); sp_code(CBC_LS_NE + 1u, ne & 0xffu, r);
-
-        /* -- pass 1: the edits, in read order.  The walk only COLLECTS them, one lane each (M coordinate, kind, bases); every
-         *    64 -- and at the end of the read -- flush_edits() turns the batch into model triples, all lanes at once -- */
-        uint32_t i = 0, mcoord = 0; uint32_t jr = pos - 1u;                 /* read index, M bases consumed, reference index */
-        carry_end = 0; carry_pk = 3u;
-        auto push = [&](uint32_t mc, uint32_t kind, uint32_t row, uint32_t base) {
-            eb = W::select(ln == ecount, W::splat(mc | (kind << 16) | (base << 18) | (row << 21)), eb);
-            if (++ecount == 64u) flush_edits(strand);
+            if (E.status == CBC_ST_OK && i != rl) E.fail(CBC_ST_ASSERT);              /* the CIGAR must consume the read exactly */
+            if (second) { flush_edits(strand); return n; }
+            if (!over && ecount) { W::store32_list(ebuf, ln + stored, eb, ln < ecount); stored += ecount; }
+            ecount = 0;
+            return n;
         };
-        V32 tokv = W::splat(0u);
-        for (uint32_t o = 0; o < n_cig && E.status == CBC_ST_OK; o++) {
-            if ((o & 63u) == 0u) tokv = W::load32(tokb + to + 2u + o, ln, (ln + o) < n_cig, 0u);
-            const uint32_t t = W::readlane(tokv, o & 63u), op = t & 15u, len = t >> 4;
-            if (op == CBC_OP_M) {
-                const uint32_t lb = W::uni(len);
-                uint32_t cn = len < 256u ? len : 256u;
-                V32 rd_n = W::load32_bytes(rdb + i, bo, bo < cn), rf_n = W::load32_bytes(refb + jr, bo, bo < cn);
-                for (uint32_t b = 0; b < lb && E.status == CBC_ST_OK; b += 256u) {
-                    const uint32_t c = cn;
-                    const V32 rd = rd_n, rf = rf_n;
-                    if (b + 256u < len) {                                  /* the next chunk's loads go out before this one is walked */
-                        cn = len - b - 256u < 256u ? len - b - 256u : 256u;
-                        rd_n = W::load32_bytes(rdb + (i + b + 256u), bo, bo < cn); rf_n = W::load32_bytes(refb + (jr + b + 256u), bo, bo < cn);
-                    }
-                    const V32 x = (rd ^ rf) & chunk_mask(c);
-                    uint64_t mm = W::ballot(x != 0u);
-                    while (mm && E.status == CBC_ST_OK) {
-                        const uint32_t k = W::ctz64(mm); mm &= mm - 1ull;
-                        const uint32_t xk = W::readlane(x, k), rdk = W::readlane(rd, k), rfk = W::readlane(rf, k);
-                        for (uint32_t q = 0; q < 4u; q++) if ((xk >> (8u * q)) & 0xffu)
-                            push(mcoord + b + 4u * k + q, 0u, cbc_basepair((rfk >> (8u * q)) & 0xffu), cbc_basepair((rdk >> (8u * q)) & 0xffu));
-                    }
-                }
-                i += len; jr += len; mcoord += len;
-            } else if (op == CBC_OP_I || op == CBC_OP_S) {
-                const uint32_t lb = W::uni(len);
-                for (uint32_t b = 0; b < lb && E.status == CBC_ST_OK; b += 64u) {        /* the inserted bases, 64 per load */
-                    const uint32_t c = len - b < 64u ? len - b : 64u;
-                    const V32 ib = W::load8(rdb, ln + (i + b), ln < c);
-                    for (uint32_t q = 0; q < c && E.status == CBC_ST_OK; q++) push(mcoord, 1u, 5u, cbc_basepair(W::readlane(ib, q)));
-                }
-                i += len;
-            } else {                                                       /* D (pass 0 refused everything else) */
-                for (uint32_t c = 0; c < len && E.status == CBC_ST_OK; c++) push(mcoord, 2u, 0u, 0u);
-                jr += len;
+        const uint32_t ne = walk(false);
+        const uint32_t walk_again = over;
+        if (E.status != CBC_ST_OK) break;
+        CBC_TS(2);                                                /* record header + the walk */
+        sp_code(CBC_LS_NE, ne >> 8, r); sp_code(CBC_LS_NE + 1u, ne & 0xffu, r);
+        carry_end = 0; carry_pk = 3u;
+        if (walk_again) (void)walk(true);                         /* more edits than the buffer holds: collect and code in one go */
+        else {
+            W::list_fence();
+            for (uint32_t k = 0; k < ne && E.status == CBC_ST_OK; k += 64u) {
+                eb = W::load32_list(ebuf, ln + k, (ln + k) < ne, 0u);
+                ecount = ne - k < 64u ? ne - k : 64u;
+                flush_edits(strand);
             }
         }
-        flush_edits(strand);
     }
     if (E.status == CBC_ST_OK) {
         E.cur_read = n_reads;
@@ -512,6 +566,10 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         E.rname_code(E.prevChar, (uint32_t)'\n');
         E.rname_code((uint32_t)'\n', 0u);
     }
+#if defined(CBC_STAMP) && defined(__HIP_DEVICE_COMPILE__)
+    if (ROLE == CBC_ROLE_MODEL && out_cap >= 512u) { CBC_TS(3); for (int i = 0; i < 16; i++) {      /* diagnostic build: payload area, second 128 bytes */
+        W::write_uni(E.out32 + 32, 2 * i, (uint32_t)E.t_sum[i]); W::write_uni(E.out32 + 32, 2 * i + 1, (uint32_t)(E.t_sum[i] >> 32)); } }
+#endif
     if (ROLE == CBC_ROLE_MODEL) { E.publish(CBC_BF_LAST, 0ull); return; }   /* with whatever is still queued, and this wavefront's status */
     uint32_t nbytes = 0;
     if (E.status == CBC_ST_OK) E.drain_q();
@@ -546,13 +604,13 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.fsp_key = D.fsp_exc = nullptr; D.fsp_count = 0; D.pos_ov_valp = D.pos_ov_cntp = nullptr; D.pos_lds_cap = 0xffffffc0u; D.palpha = nullptr;
     bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
                    cbc_fits64(seq_base, (uint64_t)blk_bases + 8u, A.seq_bytes) && cbc_le64(ref_off, A.ref_bytes) && A.cap_pos >= 2u &&
-                   n_reads <= 64u && A.var_scratch != nullptr && cbc_le64(((uint64_t)blk + 1u) * CBC_LONG_SCRATCH_WORDS, A.var_scratch_words);
+                   n_reads <= 64u && A.var_scratch != nullptr && cbc_le64(((uint64_t)blk + 1u) * CBC_LONG_TABLE_WORDS, A.var_scratch_words);
     D.nwords_in = (in_bytes + 3u) >> 2;
     D.tail_valid = in_bytes & 3u;
     if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
     for (uint32_t b = 0; b < CBC_LLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_LLDS_FIXED);
-    if (args_ok) for (uint32_t b = 0; b < CBC_LONG_SCRATCH_WORDS; b += 64u)
-        W::store32_list(A.var_scratch + (uint64_t)blk * CBC_LONG_SCRATCH_WORDS, ln + b, W::splat(0u), W::all());
+    if (args_ok) for (uint32_t b = 0; b < CBC_LONG_TABLE_WORDS; b += 64u)
+        W::store32_list(A.var_scratch + (uint64_t)blk * CBC_LONG_TABLE_WORDS, ln + b, W::splat(0u), W::all());
     D.rlen_n = 0; D.rl123_c0 = 0; D.rl123_n = 0; D.snps_n = 0; D.indels_n = 0; D.rn_count = 0;
     D.pos_card = 1u; D.pos_n = 1u; D.nev = 0; D.nev1 = 0;
     D.pval = W::splat(0xffffffffu); D.pcnt = W::select(ln == 0u, W::splat(1u), W::splat(0u));
@@ -573,7 +631,7 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.rl_memo_x = CBC_NOMEMO; D.rl_memo_lo = 0; D.rl_memo_cnt = 0; D.rl_last_x = 0;
     D.p0cnt = W::splat(0u); D.p0over = 0;
     V32 ntab = W::splat(256u), lsum = W::splat(0u), spc = W::splat(0u);
-    uint32_t *scr = A.var_scratch + (uint64_t)blk * CBC_LONG_SCRATCH_WORDS;
+    uint32_t *scr = A.var_scratch + (uint64_t)blk * CBC_LONG_TABLE_WORDS;
     /* the symbol of a dense table row in global memory whose cumulative interval holds tg; `first` = cum of the row's entry 0 */
     auto gsearch = [&](const uint32_t *row, uint32_t card, uint32_t first, uint32_t tg, uint32_t &lo, uint32_t &cnt) -> uint32_t {
         uint32_t run = first, found = CBC_NOMEMO;

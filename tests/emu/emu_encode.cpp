@@ -163,8 +163,8 @@ int emu_long_decode_blocks(const cbc_dec_device_batch *b)
     A.in_bytes = b->in_bytes; A.ref_bytes = b->ref_bytes; A.n_recs = b->n_recs; A.seq_bytes = b->seq_bytes;
     A.n_blocks = b->n_blocks; A.cap_pos = b->caps.cap_pos; A.cap_var = b->caps.cap_var;
     g_emu_errors = 0;
-    std::vector<uint32_t> scratch((size_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS + 64, 0xdeadbeefu);
-    A.var_scratch = scratch.data(); A.var_scratch_words = (uint64_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS;
+    std::vector<uint32_t> scratch((size_t)b->n_blocks * CBC_LONG_TABLE_WORDS + 64, 0xdeadbeefu);
+    A.var_scratch = scratch.data(); A.var_scratch_words = (uint64_t)b->n_blocks * CBC_LONG_TABLE_WORDS;
     for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
         std::vector<uint32_t> lds(cbc_long_lds_bytes(A.cap_pos) / 4, 0xdeadbeefu);
         cbc_long_decode<WaveEmu>(A, blk, lds.data());

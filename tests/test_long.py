@@ -20,6 +20,7 @@ CASES = [
     (7, 500_000, 400, 1_000, 0.02),
     (9, 300_000, 30, 30_000, 0.10),                 # beyond 16 kb; gaps and counts that need the escapes
     (11, 100_000, 150, 200, 0.0),                   # no edits at all
+    (15, 400_000, 12, 30_000, 0.45),                # ~13 k edits per read: more than the encoder's edit buffer holds (the read is walked twice)
     (13, 1_500_000, 300, 4_000, 0.002),             # sparse edits: most gaps beyond the 64 symbols held in LDS, many with the two gx bytes
 ]
 
