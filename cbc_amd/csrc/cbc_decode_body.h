@@ -636,6 +636,28 @@ struct CbcDec {
         uint32_t n = 256u + 10u * (pos_card - 1u);
         if (n + 10u >= CBC_RESCALE) { fail(CBC_ST_ASSERT); return 0u; }
         uint32_t tg = target(n), lo, cnt;
+        if (histp == nullptr) {
+            /* no histograms (the long-read decoder: at most 64 reads, hence at most 64 registered deltas, per block): the
+             * registered values one per lane, count(b) = 1 + 10 * #{values whose byte k is b}, cum(b) = b + 10 * #{... below b};
+             * cum is increasing, so the symbol comes out of eight bisection steps of one ballot each */
+            if (status != CBC_ST_OK) return 0u;
+            if (pos_card > 65u) { fail(CBC_ST_CAP_POS); return 0u; }
+            V32 ln = W::lane();
+            const Mask have = (ln + 1u) < pos_card;                          /* lane i: alphabet entry i + 1 */
+            V32 v = W::lane_gather(pval, ln + 1u);
+            if (pos_card == 65u) v = W::select(ln == 63u, W::splat(W::read_uni(pos_val_p(), 64u)), v);
+            const V32 by = (v >> (8u * (3u - k))) & 0xffu;
+            uint32_t lo_b = 0u, hi_b = 255u;
+            while (lo_b < hi_b) {
+                const uint32_t mid = (lo_b + hi_b + 1u) >> 1;
+                if (mid + 10u * W::popc64(W::ballot(have & (by < mid))) <= tg) lo_b = mid; else hi_b = mid - 1u;
+            }
+            lo = lo_b + 10u * W::popc64(W::ballot(have & (by < lo_b)));
+            cnt = 1u + 10u * W::popc64(W::ballot(have & (by == lo_b)));
+            if (tg < lo || tg - lo >= cnt) { fail(CBC_ST_ASSERT); return 0u; }
+            step(lo, cnt, n);
+            return lo_b;
+        }
         /* symbols 4*lane..4*lane+3 of context k = two words of u16 counts; excess = 10 per registered delta */
         const uint32_t *h = histp + 128u * k;
         V32 ln = W::lane();
@@ -647,7 +669,7 @@ struct CbcDec {
     }
     CBC_MFN void hist_inc(uint32_t k, uint32_t b)
     {
-        if (palpha) return;                                   /* dense tables carry their own counts */
+        if (palpha || histp == nullptr) return;               /* dense tables carry their own counts; the lane form derives them */
         uint32_t *h = histp + 128u * k;
         W::write_uni(h, b >> 1, W::read_uni(h, b >> 1) + (1u << ((b & 1u) * 16u)));
     }

@@ -86,7 +86,7 @@ cbc_decode_whole_kernel(cbc_dstream_args A) { cbc_decode_whole<WaveGPU>(A, cbc_l
 
 /* long-read format (cbc_long_body.h): one wavefront per block */
 #ifndef CBC_LONG_ENC_WAVES
-#define CBC_LONG_ENC_WAVES 3           /* wavefronts per SIMD the register budget is cut for (A/B: profiles/r03_ab_kernels.log) */
+#define CBC_LONG_ENC_WAVES 7           /* wavefronts per SIMD the register budget is cut for (A/B: profiles/r03_ab_kernels.log) */
 #endif
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CBC_LONG_ENC_WAVES)))
 cbc_long_encode_kernel(cbc_long_args A)
@@ -1197,7 +1197,7 @@ API int cbc_gpu_long_decode_blocks_device(cbc_gpu_ctx *ctx, const cbc_dec_device
     if (!b->d_in || !b->d_blocks || !b->d_ref || !b->d_recs || !b->d_seq || !b->d_results)
         return set_err(ctx, CBC_E_ARG, "null device pointer in cbc_dec_device_batch", hipSuccess);
     if (b->caps.cap_pos < 2 || b->caps.cap_pos > 8192) return set_err(ctx, CBC_E_ARG, "lds caps out of range", hipSuccess);
-    const uint32_t lds = cbc_long_lds_bytes(b->caps.cap_pos);
+    const uint32_t lds = cbc_long_dec_lds_bytes(b->caps.cap_pos);
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     hipStream_t s = hip_stream == CBC_CTX_STREAM ? ctx->stream : (hipStream_t)hip_stream;
     cbc_dec_args A;

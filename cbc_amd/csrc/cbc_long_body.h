@@ -29,8 +29,8 @@
 /* LDS words.  Both directions: of each of the eight gap tables only the symbols 0..63 (where a 5 % edit rate puts 96 %
  * of the gaps), the six tables that see at most ONE symbol per read (len x 4, ne x 2) as sparse (value << 24 | excess) lists
  * of 64 words each -- a block holds at most 64 reads, so such a list cannot overflow and its model cannot reach the rescale
- * point (n <= 256 + 10 * 64) --, the contig-name pairs.  Then per direction: encode = output bit ring + the hand-off ring of
- * the two wavefronts and its counters; decode = the four pos_alpha histograms.  Then pos value / count.
+ * point (n <= 256 + 10 * 64) --, the contig-name pairs.  Then, encode only: the output bit ring, the hand-off ring of the
+ * two wavefronts with its counters, the triples of a batch.  Then pos value / count (the decoder derives pos_alpha from them).
  * The gap symbols 64..255 and the two gx tables live in GLOBAL memory, CBC_LONG_SCRATCH_WORDS per block (the kernel zeroes
  * them): these kernels are bound by how many blocks a CU holds -- 20 KB of LDS per block in round 2 (2 wavefronts per SIMD),
  * 16.5 KB with the sparse lists, 7.5 KB now: the register file, not LDS, sets the residency. */
@@ -42,10 +42,11 @@
 #define CBC_LLDS_RING   CBC_LLDS_ROLE                               /* encode: CBC_RING_WORDS */
 #define CBC_LLDS_BATCH  (CBC_LLDS_ROLE + CBC_RING_WORDS)            /* encode: CBC_BATCH_SLOTS x CBC_BATCH_WORDS */
 #define CBC_LLDS_CTL    (CBC_LLDS_BATCH + CBC_BATCH_SLOTS * CBC_BATCH_WORDS)   /* encode: 8 */
-#define CBC_LLDS_HIST   CBC_LLDS_ROLE                               /* decode: 512 */
+
 #define CBC_LLDS_TRIP   (CBC_LLDS_CTL + 8u)                         /* encode: 3 x 192: the (cum, count, total) triples of a batch of 64 edits */
 #define CBC_LLDS_FIXED  (CBC_LLDS_TRIP + 576u)
-static inline uint32_t cbc_long_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_LLDS_FIXED + 2u * cap_pos); }
+static inline uint32_t cbc_long_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_LLDS_FIXED + 2u * cap_pos); }       /* encode */
+static inline uint32_t cbc_long_dec_lds_bytes(uint32_t cap_pos) { return 4u * (CBC_LLDS_ROLE + 2u * cap_pos); }   /* decode: no rings */
 /* global scratch of a block, in words: [8 x 192 gap symbols 64..255][2 x 256 gx] */
 #define CBC_LSCR_GAPHI  0u
 #define CBC_LSCR_GX     1536u
@@ -599,8 +600,8 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.l = W::dv(0u); D.rng = W::dv(CBC_M26 + 1u); D.d = W::dv(0u); D.acc = 0; D.navail = 0; D.widx = 0; D.wordv = W::splat(0u);
     D.inb = A.in + in_off;
     D.lds = lds; D.cap_pos = A.cap_pos; D.cap_var = 0; D.L0 = 256u; D.evp = nullptr; D.vtab = nullptr;
-    D.rname_key = lds + CBC_LLDS_RNKEY; D.rname_exc = lds + CBC_LLDS_RNEXC; D.rn_cap = CBC_CAP_NAME; D.histp = lds + CBC_LLDS_HIST;
-    D.pos_valp = lds + CBC_LLDS_FIXED; D.pos_cntp = D.pos_valp + A.cap_pos;
+    D.rname_key = lds + CBC_LLDS_RNKEY; D.rname_exc = lds + CBC_LLDS_RNEXC; D.rn_cap = CBC_CAP_NAME; D.histp = nullptr;
+    D.pos_valp = lds + CBC_LLDS_ROLE; D.pos_cntp = D.pos_valp + A.cap_pos;
     D.fsp_key = D.fsp_exc = nullptr; D.fsp_count = 0; D.pos_ov_valp = D.pos_ov_cntp = nullptr; D.pos_lds_cap = 0xffffffc0u; D.palpha = nullptr;
     bool args_ok = cbc_fits64(in_off, ((uint64_t)in_bytes + 3u) & ~3ull, A.in_bytes) && cbc_fits64(rec_base, n_reads, A.n_recs) &&
                    cbc_fits64(seq_base, (uint64_t)blk_bases + 8u, A.seq_bytes) && cbc_le64(ref_off, A.ref_bytes) && A.cap_pos >= 2u &&
@@ -608,7 +609,7 @@ CBC_FN void cbc_long_decode(const cbc_dec_args &A, uint32_t blk, uint32_t *lds)
     D.nwords_in = (in_bytes + 3u) >> 2;
     D.tail_valid = in_bytes & 3u;
     if (!args_ok) { D.nwords_in = 0; D.fail(CBC_ST_ASSERT); }
-    for (uint32_t b = 0; b < CBC_LLDS_FIXED; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_LLDS_FIXED);
+    for (uint32_t b = 0; b < CBC_LLDS_ROLE; b += 64u) W::store32(lds, ln + b, W::splat(0u), (ln + b) < CBC_LLDS_ROLE);
     if (args_ok) for (uint32_t b = 0; b < CBC_LONG_TABLE_WORDS; b += 64u)
         W::store32_list(A.var_scratch + (uint64_t)blk * CBC_LONG_TABLE_WORDS, ln + b, W::splat(0u), W::all());
     D.rlen_n = 0; D.rl123_c0 = 0; D.rl123_n = 0; D.snps_n = 0; D.indels_n = 0; D.rn_count = 0;

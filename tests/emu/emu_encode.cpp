@@ -166,7 +166,7 @@ int emu_long_decode_blocks(const cbc_dec_device_batch *b)
     std::vector<uint32_t> scratch((size_t)b->n_blocks * CBC_LONG_TABLE_WORDS + 64, 0xdeadbeefu);
     A.var_scratch = scratch.data(); A.var_scratch_words = (uint64_t)b->n_blocks * CBC_LONG_TABLE_WORDS;
     for (uint32_t blk = 0; blk < b->n_blocks; blk++) {
-        std::vector<uint32_t> lds(cbc_long_lds_bytes(A.cap_pos) / 4, 0xdeadbeefu);
+        std::vector<uint32_t> lds(cbc_long_dec_lds_bytes(A.cap_pos) / 4, 0xdeadbeefu);
         cbc_long_decode<WaveEmu>(A, blk, lds.data());
     }
     return g_emu_errors ? -100 : 0;
