@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <new>
 #include <time.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>              /* types and prototypes only: librccl.so (573 MB) is loaded when a group is created */
 
 #include "../../include/cbc_gpu.h"
 #include "cbc_wave_gpu.h"
@@ -219,7 +221,7 @@ cbc_checksum_kernel(const uint8_t *__restrict__ p, uint64_t n, unsigned long lon
 /* grow-only device buffer owned by the context: the host-buffer entry points keep their device arrays between calls
  * (a hipMalloc / hipFree pair per array and call cost more than the copies they framed: profiles/r02_final_pcie.log) */
 struct cbc_arena { void *p; uint64_t cap; };
-enum { A_RECS, A_SEQ, A_TOK, A_NAMES, A_BLOCKS, A_OUT, A_RES, A_OFF, A_PACKED, A_CODES, A_RUNS, A_VS, A_IN, A_EXC_I, A_EXC_V, A_CNT, A_LSCR, A_COUNT };
+enum { A_RECS, A_SEQ, A_TOK, A_NAMES, A_BLOCKS, A_OUT, A_RES, A_OFF, A_PACKED, A_CODES, A_RUNS, A_VS, A_IN, A_EXC_I, A_EXC_V, A_CNT, A_LSCR, A_STASH, A_GATHER, A_COUNT };
 #define CBC_MAX_CHUNKS 8
 #define CBC_N_KSTREAMS 8           /* every chunk's launch on a stream of its own: launches of different chunks share the chip */
 
@@ -235,6 +237,7 @@ struct cbc_gpu_ctx {
     int n_cus;                     /* compute units of the device (block residency decides the kernel build) */
     uint8_t *d_ref; uint64_t ref_bytes;
     cbc_arena arena[A_COUNT];
+    uint64_t stash_len;            /* bitstreams kept on the device by encode calls with out == NULL (cbc_gpu_group_gather moves them) */
     cbc_e2e_times last_e2e;
     char err[512];
 };
@@ -553,7 +556,7 @@ static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const 
                               uint64_t n_seq_runs, uint8_t *out, uint64_t out_cap, uint64_t *out_offsets, cbc_block_result *results,
                               const uint8_t *d_seq_ext, const uint32_t *d_tok_ext, const cbc_tok_record_summary *sums)
 {
-    if (!ctx || !hb || !out || !out_offsets) return CBC_E_ARG;
+    if (!ctx || !hb || !out_offsets) return CBC_E_ARG;     /* out == NULL: the bitstreams stay on the device (the context's stash) */
     if (!ctx->d_ref) return set_err(ctx, CBC_E_ARG, "cbc_gpu_upload_reference has not been called", hipSuccess);
     const uint32_t nb = hb->n_blocks;
     out_offsets[0] = 0;
@@ -702,10 +705,28 @@ static int encode_blocks_impl(cbc_gpu_ctx *ctx, const cbc_host_batch *hb, const 
             rc = CBC_E_BLOCK;
         }
     }
+    if (!out) {
+        /* keep them: appended to the stash (a grow-with-copy buffer), for cbc_gpu_group_gather / cbc_gpu_stash_fetch */
+        if (total) {
+            const uint64_t need = ctx->stash_len + total + 16;
+            if (ctx->arena[A_STASH].cap < need) {
+                void *np = NULL; const uint64_t want = (need + (need >> 1) + (4ull << 20)) & ~((2ull << 20) - 1);
+                GO(hipMalloc(&np, want), "hipMalloc stash");
+                if (ctx->stash_len) GO(hipMemcpyAsync(np, ctx->arena[A_STASH].p, ctx->stash_len, hipMemcpyDeviceToDevice, ctx->stream), "stash copy");
+                GO(hipStreamSynchronize(ctx->stream), "stash copy");
+                if (ctx->arena[A_STASH].p) (void)hipFree(ctx->arena[A_STASH].p);
+                ctx->arena[A_STASH].p = np; ctx->arena[A_STASH].cap = want;
+            }
+            GO(hipMemcpyAsync((uint8_t *)ctx->arena[A_STASH].p + ctx->stash_len, d_compact, total, hipMemcpyDeviceToDevice, ctx->stream), "D2D stash");
+            GO(hipStreamSynchronize(ctx->stream), "D2D stash");
+            ctx->stash_len += total;
+        }
+    } else {
     if (total > out_cap) { rc = set_err(ctx, CBC_E_ARG, "out_cap too small for the compacted payloads", hipSuccess); goto done; }
     if (total) {
         GO(hipMemcpyAsync(out, d_compact, total, hipMemcpyDeviceToHost, ctx->stream), "D2H payloads");
         GO(hipStreamSynchronize(ctx->stream), "D2H payloads");
+    }
     }
     tm.d2h_bytes = total + (uint64_t)nb * (sizeof(cbc_block_result) + 8) + 8;
 done:
@@ -737,6 +758,136 @@ API int cbc_gpu_host_unregister(cbc_gpu_ctx *ctx, const void *p)
     if (!ctx || !p) return CBC_E_ARG;
     HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
     HIPCHK(hipHostUnregister((void *)p), "hipHostUnregister");
+    return CBC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the exchange step of the multi-device path: every device's bitstreams to device 0 over RCCL
+ * (grouped ncclSend / ncclRecv over xGMI), checksummed on both sides, then one D2H.  One process, one context per device --
+ * the shape of `cbc --devices a,b,...`; bench.py's one-process-per-GPU form makes the same exchange through
+ * torch.distributed's "nccl" backend, which is this library too.  librccl.so is loaded here, not at program start.
+ * ---------------------------------------------------------------------------------------------- */
+struct cbc_rccl_api {
+    void *so;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+struct cbc_gpu_group { int n; cbc_gpu_ctx **ctx; ncclComm_t *comm; cbc_rccl_api api; char err[256]; };
+
+static int rccl_load(cbc_rccl_api *a, char *err, size_t errlen)
+{
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    a->so = NULL;
+    for (unsigned k = 0; k < 3 && !a->so; k++) a->so = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+    if (!a->so) { snprintf(err, errlen, "cannot load librccl: %s", dlerror()); return CBC_E_NODEV; }
+#define SYM(field, name) do { *(void **)&a->field = dlsym(a->so, name); if (!a->field) { snprintf(err, errlen, "librccl has no %s", name); return CBC_E_NODEV; } } while (0)
+    SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+    SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return CBC_OK;
+}
+
+API const char *cbc_gpu_group_last_error(cbc_gpu_group *g) { return g ? g->err : "no group"; }
+
+API void cbc_gpu_group_destroy(cbc_gpu_group *g)
+{
+    if (!g) return;
+    if (g->comm) { for (int k = 0; k < g->n; k++) if (g->comm[k]) { (void)hipSetDevice(g->ctx[k]->device); (void)g->api.CommDestroy(g->comm[k]); } }
+    free(g->comm); free(g->ctx);
+    /* the library stays loaded: unloading RCCL while HIP is alive is not worth the risk */
+    delete g;
+}
+
+API int cbc_gpu_group_create(cbc_gpu_ctx *const *ctxs, int n, cbc_gpu_group **out)
+{
+    if (!ctxs || !out || n < 1 || n > 64) return CBC_E_ARG;
+    *out = NULL;
+    for (int k = 0; k < n; k++) { if (!ctxs[k]) return CBC_E_ARG; for (int j = 0; j < k; j++) if (ctxs[j]->device == ctxs[k]->device) return CBC_E_ARG; }   /* one rank per device */
+    cbc_gpu_group *g = new (std::nothrow) cbc_gpu_group();
+    if (!g) return CBC_E_NOMEM;
+    memset(g, 0, sizeof *g);
+    g->n = n;
+    g->ctx = (cbc_gpu_ctx **)calloc((size_t)n, sizeof(cbc_gpu_ctx *)); g->comm = (ncclComm_t *)calloc((size_t)n, sizeof(ncclComm_t));
+    int *devs = (int *)calloc((size_t)n, sizeof(int));
+    int rc = (g->ctx && g->comm && devs) ? CBC_OK : CBC_E_NOMEM;
+    if (!rc) rc = rccl_load(&g->api, g->err, sizeof g->err);
+    if (!rc) {
+        for (int k = 0; k < n; k++) { g->ctx[k] = ctxs[k]; devs[k] = ctxs[k]->device; }
+        const ncclResult_t r = g->api.CommInitAll(g->comm, n, devs);
+        if (r != ncclSuccess) { snprintf(g->err, sizeof g->err, "ncclCommInitAll: %s", g->api.GetErrorString(r)); rc = CBC_E_NODEV; memset(g->comm, 0, (size_t)n * sizeof(ncclComm_t)); }
+    }
+    free(devs);
+    if (rc) { if (ctxs[0]) snprintf(ctxs[0]->err, sizeof ctxs[0]->err, "%s", g->err); cbc_gpu_group_destroy(g); return rc; }
+    *out = g;
+    return CBC_OK;
+}
+
+API int cbc_gpu_stash_reset(cbc_gpu_ctx *ctx) { if (!ctx) return CBC_E_ARG; ctx->stash_len = 0; return CBC_OK; }
+API uint64_t cbc_gpu_stash_bytes(cbc_gpu_ctx *ctx) { return ctx ? ctx->stash_len : 0; }
+API int cbc_gpu_stash_fetch(cbc_gpu_ctx *ctx, uint8_t *out, uint64_t out_cap)
+{
+    if (!ctx || (ctx->stash_len && !out) || out_cap < ctx->stash_len) return CBC_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device), "hipSetDevice");
+    if (ctx->stash_len) HIPCHK(hipMemcpy(out, ctx->arena[A_STASH].p, ctx->stash_len, hipMemcpyDeviceToHost), "D2H stash");
+    return CBC_OK;
+}
+
+static int device_checksum_now(cbc_gpu_ctx *ctx, const uint8_t *d, uint64_t n, uint64_t *sum)
+{
+    int rc = arena_need(ctx, A_CNT, 8, "hipMalloc checksum"); if (rc) return rc;
+    rc = cbc_gpu_checksum_device(ctx, d, n, (uint64_t *)ctx->arena[A_CNT].p, CBC_CTX_STREAM); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(sum, ctx->arena[A_CNT].p, 8, hipMemcpyDeviceToHost, ctx->stream), "D2H checksum");
+    HIPCHK(hipStreamSynchronize(ctx->stream), "checksum");
+    return CBC_OK;
+}
+
+/* Member k's stash -> out[sum of the earlier members' bytes ...], through member 0's device.  nbytes[k] / sums[k] (may be
+ * NULL): what member k held and the checksum it took of it before the exchange; the call fails with CBC_E_IO when what
+ * member 0 received sums to something else. */
+API int cbc_gpu_group_gather(cbc_gpu_group *g, uint8_t *out, uint64_t out_cap, uint64_t *nbytes, uint64_t *sums)
+{
+    if (!g || !nbytes) return CBC_E_ARG;
+    cbc_gpu_ctx *c0 = g->ctx[0];
+    cbc_gpu_ctx *ctx = c0;                                      /* for HIPCHK / set_err */
+    uint64_t total = 0, sent[64], got = 0;
+    for (int k = 0; k < g->n; k++) { nbytes[k] = g->ctx[k]->stash_len; total += nbytes[k]; }
+    if (total > out_cap || (total && !out)) return set_err(c0, CBC_E_ARG, "out_cap too small for the gathered bitstreams", hipSuccess);
+    for (int k = 0; k < g->n; k++) {                          /* every member sums its own bytes on its own device */
+        cbc_gpu_ctx *ck = g->ctx[k];
+        HIPCHK(hipSetDevice(ck->device), "hipSetDevice");
+        int rc = device_checksum_now(ck, (const uint8_t *)ck->arena[A_STASH].p, nbytes[k], &sent[k]); if (rc) return rc;
+        if (sums) sums[k] = sent[k];
+    }
+    HIPCHK(hipSetDevice(c0->device), "hipSetDevice");
+    { int rc = arena_need(c0, A_GATHER, total + 16, "hipMalloc gather"); if (rc) return rc; }
+    uint8_t *dst = (uint8_t *)c0->arena[A_GATHER].p;
+    /* one group: every send and its receive (a one-member group sends to itself: the self-test of the call sites) */
+    ncclResult_t r = g->api.GroupStart();
+    uint64_t at = 0;
+    for (int k = 0; k < g->n && r == ncclSuccess; k++) {
+        if (nbytes[k]) {
+            (void)hipSetDevice(g->ctx[k]->device);
+            r = g->api.Send(g->ctx[k]->arena[A_STASH].p, (size_t)nbytes[k], ncclUint8, 0, g->comm[k], g->ctx[k]->stream);
+            if (r == ncclSuccess) { (void)hipSetDevice(c0->device); r = g->api.Recv(dst + at, (size_t)nbytes[k], ncclUint8, k, g->comm[0], c0->stream); }
+        }
+        at += nbytes[k];
+    }
+    { const ncclResult_t e = g->api.GroupEnd(); if (r == ncclSuccess) r = e; }
+    if (r != ncclSuccess) { snprintf(g->err, sizeof g->err, "RCCL send/recv: %s", g->api.GetErrorString(r)); return set_err(c0, CBC_E_NODEV, g->err, hipSuccess); }
+    for (int k = 0; k < g->n; k++) { HIPCHK(hipSetDevice(g->ctx[k]->device), "hipSetDevice"); HIPCHK(hipStreamSynchronize(g->ctx[k]->stream), "RCCL exchange"); }
+    HIPCHK(hipSetDevice(c0->device), "hipSetDevice");
+    at = 0;
+    for (int k = 0; k < g->n; k++) {                          /* ... and member 0 sums what arrived */
+        int rc = device_checksum_now(c0, dst + at, nbytes[k], &got); if (rc) return rc;
+        if (got != sent[k]) { snprintf(g->err, sizeof g->err, "member %d: checksum %016llx sent, %016llx received", k, (unsigned long long)sent[k], (unsigned long long)got); return set_err(c0, CBC_E_IO, g->err, hipSuccess); }
+        at += nbytes[k];
+    }
+    if (total) HIPCHK(hipMemcpy(out, dst, total, hipMemcpyDeviceToHost), "D2H gathered bitstreams");
     return CBC_OK;
 }
 

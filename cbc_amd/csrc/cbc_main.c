@@ -42,7 +42,8 @@ static void usage(const char *p)
             "options: -l (header read length = longest read)  --block-reads N (default 4096)  --device N (default 0)\n"
             "         --threads N (SAM parser threads, default one per CPU)  --verbose (stage times)\n"
             "         --compat (write the reference's own single-stream format; slow: one stream = one wavefront)\n"
-            "         --devices 0,1,... (shard the contigs / block ranges over several MI355X, one host thread each)\n"
+            "         --devices 0,1,... (shard the contigs / block ranges over several MI355X, one host thread each; the bitstreams\n"
+            "                           reach device 0 over RCCL / xGMI when every ordinal is a device of its own)   --rccl (RCCL or fail)\n"
             "         --device-parse (tokenise the SAM text on the GPU; falls back to the host parser for leading soft clips / records without MD)\n"
             "         --long (long-read format extension: reads up to 65535 bases, any SAM line length; not a reference format)\n", p, p);
 }
@@ -83,6 +84,8 @@ typedef struct {
     uint8_t **blk_payload; uint32_t *blk_bytes;        /* per block, filled by the owning thread (malloc'ed runs) */
     uint8_t **runs; uint32_t n_runs;
     int rc; char err[512]; double seconds; float kernel_ms; uint64_t n_reads, ref_bytes;
+    int keep_on_device;                /* the bitstreams stay in the context's stash (blk_stash_off) for the RCCL gather */
+    uint64_t *blk_stash_off; cbc_gpu_ctx *ctx;
 } dev_job;
 
 static void *dev_encode(void *arg)
@@ -137,20 +140,26 @@ static void *dev_encode(void *arg)
         hb.tok = p->tok + t0k; hb.n_tok = t1k - t0k; hb.names = p->names; hb.names_bytes = p->names_bytes;
         hb.blocks = bl; hb.n_blocks = nb; hb.caps = p->caps;
         uint64_t cap = cbc_gpu_plan_output_caps(bl, nb, &hb.caps);
-        uint8_t *pay = (uint8_t *)malloc(cap ? cap : 1);
-        if (!pay) { J->rc = CBC_E_NOMEM; free(bl); free(offs); break; }
-        J->rc = cbc_gpu_encode_blocks(ctx, &hb, pay, cap, offs, NULL);
+        uint8_t *pay = J->keep_on_device ? NULL : (uint8_t *)malloc(cap ? cap : 1);
+        if (!pay && !J->keep_on_device) { J->rc = CBC_E_NOMEM; free(bl); free(offs); break; }
+        const uint64_t stash0 = cbc_gpu_stash_bytes(ctx);
+        J->rc = cbc_gpu_encode_blocks(ctx, &hb, pay, cap, offs, NULL);     /* pay == NULL: the bitstreams stay on the device */
         if (J->rc) snprintf(J->err, sizeof J->err, "%s", cbc_gpu_last_error(ctx));
         else {
             float ms = 0; if (!cbc_gpu_last_kernel_ms(ctx, &ms)) J->kernel_ms += ms;
-            for (uint32_t k = 0; k < nb; k++) { J->blk_payload[b0 + k] = pay + offs[k]; J->blk_bytes[b0 + k] = (uint32_t)(offs[k + 1] - offs[k]); }
-            J->runs[J->n_runs++] = pay; pay = NULL;
+            for (uint32_t k = 0; k < nb; k++) {
+                J->blk_bytes[b0 + k] = (uint32_t)(offs[k + 1] - offs[k]);
+                if (J->keep_on_device) J->blk_stash_off[b0 + k] = stash0 + offs[k];
+                else J->blk_payload[b0 + k] = pay + offs[k];
+            }
+            if (pay) { J->runs[J->n_runs++] = pay; pay = NULL; }
         }
         free(pay); free(bl); free(offs);
         b0 = b1;
     }
     free(new_base);
-    cbc_gpu_shutdown(ctx);
+    if (J->keep_on_device && !J->rc) J->ctx = ctx;               /* the gather needs the context; compress_on_devices shuts it down */
+    else cbc_gpu_shutdown(ctx);
     J->seconds = now_s() - t0;
     return NULL;
 }
@@ -168,8 +177,16 @@ static int parse_devices(const char *s, int *devs)
     return n;
 }
 
-static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, const char *out, int verbose)
+static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, const char *out, int verbose, int want_rccl)
 {
+    /* the exchange step: over RCCL (every device's bitstreams to device 0 over xGMI, then one D2H) when every listed ordinal
+     * is a device of its own; two contexts on one device (rehearsals on a one-GPU box) bring theirs back over PCIe */
+    int distinct = 1;
+    for (int a = 0; a < ndev; a++) for (int b = 0; b < a; b++) if (devs[a] == devs[b]) distinct = 0;
+    const int use_rccl = distinct && (ndev > 1 || want_rccl);
+    if (want_rccl && !distinct) { fprintf(stderr, "cbc: --rccl wants every --devices ordinal once\n"); return 1; }
+    uint64_t *blk_stash_off = (uint64_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint64_t));
+    uint8_t *gathered = NULL;
     uint32_t *part = (uint32_t *)calloc(p->n_contigs ? p->n_contigs : 1, sizeof(uint32_t));
     uint8_t **blk_payload = (uint8_t **)calloc((size_t)p->n_blocks + 1, sizeof(uint8_t *));
     uint32_t *blk_bytes = (uint32_t *)calloc((size_t)p->n_blocks + 1, sizeof(uint32_t));
@@ -181,11 +198,34 @@ static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, c
         memset(&jobs[d], 0, sizeof jobs[d]);
         jobs[d].p = p; jobs[d].device = devs[d]; jobs[d].part = (uint32_t)d; jobs[d].part_of_contig = part;
         jobs[d].blk_payload = blk_payload; jobs[d].blk_bytes = blk_bytes;
+        jobs[d].keep_on_device = use_rccl; jobs[d].blk_stash_off = blk_stash_off;
         if (pthread_create(&th[d], NULL, dev_encode, &jobs[d]) != 0) { fprintf(stderr, "cbc: cannot start a device thread\n"); return 1; }
     }
     int bad = 0;
     for (int d = 0; d < ndev; d++) { pthread_join(th[d], NULL); if (jobs[d].rc) { fprintf(stderr, "cbc: device %d: %s\n", devs[d], jobs[d].err); bad = 1; } }
     if (bad) return 1;
+    const char *exchange = "one D2H per device (PCIe)";
+    if (use_rccl) {
+        cbc_gpu_ctx *ctxs[CBC_MAX_DEVICES]; uint64_t nbytes[CBC_MAX_DEVICES], sums[CBC_MAX_DEVICES], base[CBC_MAX_DEVICES], total = 0;
+        for (int d = 0; d < ndev; d++) { ctxs[d] = jobs[d].ctx; nbytes[d] = cbc_gpu_stash_bytes(ctxs[d]); base[d] = total; total += nbytes[d]; }
+        gathered = (uint8_t *)malloc(total ? total : 1);
+        if (!gathered) { fprintf(stderr, "cbc: out of memory\n"); return 1; }
+        cbc_gpu_group *grp = NULL;
+        int rc = cbc_gpu_group_create(ctxs, ndev, &grp);
+        if (!rc) {
+            rc = cbc_gpu_group_gather(grp, gathered, total, nbytes, sums);
+            if (rc) fprintf(stderr, "cbc: RCCL gather failed: %s\n", cbc_gpu_group_last_error(grp));
+            else {
+                exchange = "RCCL: grouped ncclSend / ncclRecv to device 0 over xGMI, checksums verified, one D2H";
+                if (verbose) for (int d = 0; d < ndev; d++) printf("rccl: member %d (device %d) %llu bytes, checksum %016llx sent == received\n", d, devs[d], (unsigned long long)nbytes[d], (unsigned long long)sums[d]);
+            }
+            cbc_gpu_group_destroy(grp);
+        } else fprintf(stderr, "cbc: no RCCL group (%s)%s\n", cbc_gpu_last_error(ctxs[0]), want_rccl ? "" : "; falling back to one D2H per device");
+        if (rc && want_rccl) return 1;
+        if (rc) for (int d = 0; d < ndev; d++) if (cbc_gpu_stash_fetch(ctxs[d], gathered + base[d], nbytes[d])) { fprintf(stderr, "cbc: device %d: %s\n", devs[d], cbc_gpu_last_error(ctxs[d])); return 1; }
+        for (uint32_t b = 0; b < p->n_blocks; b++) blk_payload[b] = gathered + base[part[p->info[b].contig]] + blk_stash_off[b];
+        for (int d = 0; d < ndev; d++) cbc_gpu_shutdown(ctxs[d]);
+    }
     double t1 = now_s();
     for (uint32_t b = 0; b < p->n_blocks; b++) offs[b + 1] = offs[b] + blk_bytes[b];
     uint8_t *flat = (uint8_t *)malloc(offs[p->n_blocks] ? offs[p->n_blocks] : 1);
@@ -201,7 +241,9 @@ static int compress_on_devices(const cbc_packed *p, const int *devs, int ndev, c
     if (verbose) for (int d = 0; d < ndev; d++)
         printf("device %d: %llu reads, %llu reference bytes uploaded (its contigs only), %.3f s (init + reference upload + encode), kernels %.3f ms\n", devs[d],
                (unsigned long long)jobs[d].n_reads, (unsigned long long)jobs[d].ref_bytes, jobs[d].seconds, (double)jobs[d].kernel_ms);
+    if (verbose) printf("exchange: %s\n", exchange);
     if (verbose) printf("time: all devices %.3f s, assemble + write %.3f s\n", t1 - t0, now_s() - t1);
+    free(gathered); free(blk_stash_off);
     for (int d = 0; d < ndev; d++) { for (uint32_t k = 0; k < jobs[d].n_runs; k++) free(jobs[d].runs[k]); free(jobs[d].runs); }
     free(flat); free(blob); free(part); free(blk_payload); free(blk_bytes); free(offs);
     return 0;
@@ -241,7 +283,7 @@ static void estimate_batch(const char *sam, size_t sam_len, uint32_t block_reads
 static double g_main_t0;
 
 static int do_compress(const char *in, const char *out, const char *ref, uint32_t block_reads, int device, int var_length, int threads, int verbose, int compat,
-                       const int *devs, int ndev, int long_reads, int device_parse)
+                       const int *devs, int ndev, int long_reads, int device_parse, int want_rccl)
 {
     size_t sam_len = 0, fa_len = 0;
     double t0 = now_s();
@@ -249,7 +291,7 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     memset(&IJ, 0, sizeof IJ); IJ.device = device;
     const char *sam = map_file(in, &sam_len), *fa = map_file(ref, &fa_len);
     if (!sam || !fa) return 1;
-    if (!(device_parse && !compat && !long_reads && ndev <= 1) && ndev <= 1) {
+    if (!(device_parse && !compat && !long_reads && ndev <= 1) && ndev <= 1 && !want_rccl) {
         if (!compat && !long_reads) estimate_batch(sam, sam_len, block_reads, &IJ);
         init_started = pthread_create(&init_th, NULL, init_thread, &IJ) == 0;
     }
@@ -284,8 +326,8 @@ static int do_compress(const char *in, const char *out, const char *ref, uint32_
     unmap_file(sam, sam_len); unmap_file(fa, fa_len);
     double t1 = now_s();
     if (rc) { if (init_started) pthread_join(init_th, NULL); fprintf(stderr, "cbc: %s\n", err); return 1; }
-    if (ndev > 1 && !compat && !long_reads) {
-        rc = compress_on_devices(p, devs, ndev, out, verbose);
+    if ((ndev > 1 || want_rccl) && !compat && !long_reads) {
+        rc = compress_on_devices(p, devs, ndev, out, verbose, want_rccl);
         cbc_packed_free(p);
         return rc;
     }
@@ -377,7 +419,7 @@ int cbc_cli_decompress(const char *in, const char *out, const char *ref, const i
 int main(int argc, char **argv)
 {
     const char *files[3] = { 0, 0, 0 };
-    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0, long_reads = 0, device_parse = 0;
+    int nfiles = 0, mode = 0 /* 0 none, 1 compress, 2 decompress */, device = 0, var_length = 0, threads = 0, verbose = 0, compat = 0, long_reads = 0, device_parse = 0, want_rccl = 0;
     int devs[CBC_MAX_DEVICES] = { 0 }, ndev = 0;
     uint32_t block_reads = 0;
     g_main_t0 = now_s();
@@ -401,6 +443,7 @@ int main(int argc, char **argv)
         if (!strcmp(a, "--compat")) { compat = 1; continue; }
         if (!strcmp(a, "--long")) { long_reads = 1; continue; }
         if (!strcmp(a, "--device-parse")) { device_parse = 1; continue; }
+        if (!strcmp(a, "--rccl")) { want_rccl = 1; continue; }       /* the RCCL exchange or nothing (also with one device: a self-send) */
         if (!strcmp(a, "-h") || !strcmp(a, "--help")) { usage(argv[0]); return 0; }
         switch (a[1]) {
         case 'c':
@@ -436,6 +479,6 @@ int main(int argc, char **argv)
         return 1;
     }
     if (ndev == 0) { devs[0] = device; ndev = 1; }
-    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat, devs, ndev, long_reads, device_parse)
+    return mode == 1 ? do_compress(files[0], files[1], files[2], block_reads, device, var_length, threads, verbose, compat, devs, ndev, long_reads, device_parse, want_rccl)
                      : cbc_cli_decompress(files[0], files[1], files[2], devs, ndev);
 }

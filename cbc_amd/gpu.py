@@ -140,6 +140,19 @@ def lib():
         L.cbc_gpu_decode_stream_blocks.restype = ctypes.c_int
         L.cbc_gpu_decode_stream_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32,
                                                    ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        L.cbc_gpu_group_create.restype = ctypes.c_int
+        L.cbc_gpu_group_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.cbc_gpu_group_gather.restype = ctypes.c_int
+        L.cbc_gpu_group_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        L.cbc_gpu_group_destroy.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_group_last_error.restype = ctypes.c_char_p
+        L.cbc_gpu_group_last_error.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_stash_reset.restype = ctypes.c_int
+        L.cbc_gpu_stash_reset.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_stash_bytes.restype = ctypes.c_uint64
+        L.cbc_gpu_stash_bytes.argtypes = [ctypes.c_void_p]
+        L.cbc_gpu_stash_fetch.restype = ctypes.c_int
+        L.cbc_gpu_stash_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         L.cbc_stream_read_length.restype = ctypes.c_uint32
         L.cbc_stream_read_length.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         L.cbc_gpu_tokenise_sam.restype = ctypes.c_int
@@ -202,7 +215,8 @@ EXPORTS = ["cbc_gpu_abi_version", "cbc_gpu_device_count", "cbc_gpu_init", "cbc_g
            "cbc_gpu_long_decode_blocks_device", "cbc_gpu_long_encode_blocks", "cbc_gpu_long_decode_blocks",
            "cbc_gpu_checksum_device", "cbc_gpu_upload_reference_parts", "cbc_gpu_last_e2e", "cbc_gpu_host_register",
            "cbc_gpu_host_unregister", "cbc_gpu_plan_output_caps", "cbc_gpu_reserve_encode",
-           "cbc_gpu_decode_stream_blocks"]
+           "cbc_gpu_decode_stream_blocks", "cbc_gpu_group_create", "cbc_gpu_group_gather", "cbc_gpu_group_destroy", "cbc_gpu_group_last_error",
+           "cbc_gpu_stash_reset", "cbc_gpu_stash_bytes", "cbc_gpu_stash_fetch"]
 
 
 class Encoder:

@@ -176,6 +176,22 @@ int  cbc_gpu_last_e2e(cbc_gpu_ctx *ctx, cbc_e2e_times *out);
 int  cbc_gpu_host_register(cbc_gpu_ctx *ctx, const void *p, uint64_t bytes);
 int  cbc_gpu_host_unregister(cbc_gpu_ctx *ctx, const void *p);
 
+/* ---- several devices in one process: the exchange step -------------------------------------------
+ * cbc_gpu_encode_blocks (and _2bit / _tokenised) with out == NULL keep the compacted bitstreams ON THE DEVICE, appended to the
+ * context's stash (out_offsets are relative to the call, as always).  A group over one context per device then moves every
+ * member's stash to member 0's device with grouped ncclSend / ncclRecv (RCCL over xGMI), checks a checksum taken on the
+ * sending device against one taken on the receiving device, and hands the bytes to the host in member order.  librccl.so is
+ * loaded when the first group is created.  A one-member group sends to itself (self-test of the call sites).
+ * Without RCCL (or with two contexts on one device) cbc_gpu_stash_fetch() brings a member's stash back over PCIe instead. */
+typedef struct cbc_gpu_group cbc_gpu_group;
+int  cbc_gpu_group_create(cbc_gpu_ctx *const *ctxs, int n, cbc_gpu_group **out);       /* CBC_E_ARG when two contexts share a device */
+int  cbc_gpu_group_gather(cbc_gpu_group *g, uint8_t *out, uint64_t out_cap, uint64_t *nbytes /* n */, uint64_t *sums /* n or NULL */);
+void cbc_gpu_group_destroy(cbc_gpu_group *g);
+const char *cbc_gpu_group_last_error(cbc_gpu_group *g);
+int  cbc_gpu_stash_reset(cbc_gpu_ctx *ctx);
+uint64_t cbc_gpu_stash_bytes(cbc_gpu_ctx *ctx);
+int  cbc_gpu_stash_fetch(cbc_gpu_ctx *ctx, uint8_t *out, uint64_t out_cap);
+
 /* Device-pointer entry point (what bench.py and the multi-GPU host use): every pointer is a
  * device address, the launch is asynchronous on `hip_stream`, a hipStream_t used exactly as given
  * (NULL is HIP's null stream, which is what torch's default stream is).  Everything the launch reads

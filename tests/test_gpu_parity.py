@@ -607,3 +607,25 @@ def test_checksum_kernel_equals_host_twin(built):
     """ % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "CHECKSUM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_cli_rccl_exchange_one_member_self_test(built, tmp_path):
+    """`cbc --devices 0 --rccl`: the multi-device path with its RCCL exchange (cbc_gpu_group_gather: grouped ncclSend /
+    ncclRecv, checksums taken on the sending and the receiving device) on the one GPU of this box -- a one-member group sends
+    to itself, which runs every call site.  The container equals the plain one-device container; with two contexts on one
+    device (`--devices 0,0`) no RCCL group can exist and the bitstreams come back over PCIe instead (same container).
+    Real multi-device RCCL runs only on the driver's 8-GPU node."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cbc_amd", "csrc", "cbc")
+    fa, sam, _, _ = synth.dataset(19, [60000, 200000, 90000], [900, 3000, 1400], 100, sub_rate=0.01, indel_frac=0.2)
+    (tmp_path / "in.sam").write_bytes(sam); (tmp_path / "ref.fa").write_bytes(fa)
+    outs = {}
+    for tag, extra in (("plain", []), ("rccl", ["--devices", "0", "--rccl"]), ("dup", ["--devices", "0,0"])):
+        o = tmp_path / ("out_%s.cbc" % tag)
+        r = subprocess.run([exe, "-c", "1", str(tmp_path / "in.sam"), str(o), str(tmp_path / "ref.fa"), "--block-reads", "256", "--verbose"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = (o.read_bytes(), r.stdout)
+    assert outs["plain"][0] == outs["rccl"][0] == outs["dup"][0]
+    assert "exchange: RCCL" in outs["rccl"][1] and "sent == received" in outs["rccl"][1]
+    assert "exchange: one D2H per device" in outs["dup"][1]
