@@ -1588,6 +1588,9 @@ API int cbc_gpu_tokenise_sam(cbc_gpu_ctx *ctx, const char *sam, uint64_t len, ui
     GO(hipMalloc(&d_recof, n_lines * 8 + 16), "hipMalloc"); GO(hipMalloc(&d_seqof, n_lines * 8 + 16), "hipMalloc"); GO(hipMalloc(&d_tokof, n_lines * 8 + 16), "hipMalloc");
     GO(hipMalloc(&d_cnt, 16), "hipMalloc counters");
     GO(hipMemcpyAsync(d_cnt, cnt, 16, hipMemcpyHostToDevice, ctx->stream), "H2D counters");
+    hipLaunchKernelGGL(cbc_tok_split_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)d_sam,
+                       (const uint64_t *)d_ls, n_lines, body_off, (cbc_tok_perline *)d_pl);
+    GO(hipGetLastError(), "launch cbc_tok_split_kernel");
     hipLaunchKernelGGL(cbc_tok_parse_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, ctx->stream, (const uint8_t *)d_sam,
                        (const uint64_t *)d_ls, n_lines, body_off, (cbc_tok_perline *)d_pl, (uint32_t *)d_isrec, (uint32_t *)d_vrl, (uint32_t *)d_vnt);
     GO(hipGetLastError(), "launch cbc_tok_parse_kernel");

@@ -8,9 +8,13 @@
  *   CIGAR scan              src/read_compression.c:308-352       atoi() of the UNCONSUMED segment at every M I D S *
  *   MD scan                 src/read_compression.c:613-701       (gap << 8) | letter per mismatch, '^' runs add to the gap
  *   consistency replay      src/read_compression.c:551-552, 656-659  every MD mismatch must be consumed by the read
+ * A record without an MD / XD field inherits the text of the nearest earlier line that has one (read_line_t.edits persists
+ * across load_sam_line calls: src/sam_file_allocation.c:505-511) -- here: a look-back over the lines already split, at most
+ * CBC_TOK_MD_LOOKBACK of them (cbc_tok_md_source()).
  * What it does NOT do, and reports as CBC_TOK_NEEDS_HOST so that the caller falls back to the host packer: a record
- * whose CIGAR starts with a soft clip (quirk Q6: the reference rewrites that record's MD text in a buffer that
- * persists across records) and a record without an MD/XD field (it inherits the previous record's text).
+ * whose CIGAR starts with a soft clip -- quirk Q6: the reference rewrites that record's MD text IN the buffer that persists
+ * across records and does not terminate what it wrote (read_compression.c:357-468, :460), so the text depends on the
+ * buffer's whole history, which is serial state -- and an MD-less record with no MD within the look-back.
  */
 #ifndef CBC_TOK_CORE_H
 #define CBC_TOK_CORE_H
@@ -24,6 +28,7 @@
 #define CBC_TOK_FN static inline
 #endif
 
+#define CBC_TOK_MD_LOOKBACK 4096u         /* lines an MD-less record looks back for its text (beyond: the host packer) */
 #define CBC_TOK_LINE_MAX 1023u            /* fgets(buffer, 1024, ...): longer lines are refused, as by the host packer */
 
 enum { CBC_TOK_OK = 0, CBC_TOK_SKIP = 1 /* no token on the line */, CBC_TOK_UNMAPPED = 2,
@@ -89,7 +94,22 @@ CBC_TOK_FN void cbc_tok_split(const uint8_t *sam, uint64_t b, uint64_t e, cbc_to
     if (nf == 0) { L->status = CBC_TOK_SKIP; return; }
     if (nf < 11) { L->status = CBC_TOK_E_COLUMNS; return; }
     if ((L->flag & 4u) == 4u) { L->status = CBC_TOK_UNMAPPED; return; }
-    if (!L->has_md) L->status = CBC_TOK_NEEDS_HOST;        /* would inherit the previous record's MD text */
+    /* no MD / XD field: the caller gives the record the text it inherits (cbc_tok_md_source) before cbc_tok_record() */
+}
+/* Where an MD-less record at line k takes its MD text from: get(j) returns line j's split (NULL for a line that is not part
+ * of the body: '@' headers).  An unmapped line's MD counts too -- load_sam_line() has copied it before compress_line() looks
+ * at the FLAG.  *md / *md_len: the text (empty when no earlier body line has one: the buffer starts zeroed). */
+template <class GET>
+CBC_TOK_FN uint32_t cbc_tok_md_source(uint64_t k, GET get, uint64_t *md, uint32_t *md_len)
+{
+    *md = 0; *md_len = 0;
+    for (uint64_t back = 1; back <= k; back++) {
+        const cbc_tok_line *P = get(k - back);
+        if (!P) return CBC_TOK_OK;                           /* reached the header: nothing to inherit */
+        if (P->has_md) { *md = P->md; *md_len = P->md_len; return CBC_TOK_OK; }
+        if (back >= CBC_TOK_MD_LOOKBACK) return CBC_TOK_NEEDS_HOST;
+    }
+    return CBC_TOK_OK;
 }
 
 /* CIGAR + MD of one mapped record -> token words.  `tk` may be NULL (count only).  Returns a CBC_TOK_* status;

@@ -52,17 +52,36 @@ struct cbc_tok_perline {            /* what pass 1 leaves per line: the column s
     cbc_tok_line L;                 /* offsets of the columns the later passes read (CIGAR, SEQ, MD) */
 };
 
+/* pass 1a: the column split of every line (the parse below may look at earlier lines' splits) */
 __global__ void __launch_bounds__(256)
-cbc_tok_parse_kernel(const uint8_t *__restrict__ sam, const uint64_t *__restrict__ line_start, uint64_t n_lines, uint64_t body_off,
-                     cbc_tok_perline *__restrict__ pl, uint32_t *__restrict__ is_rec, uint32_t *__restrict__ v_rl, uint32_t *__restrict__ v_nt)
+cbc_tok_split_kernel(const uint8_t *__restrict__ sam, const uint64_t *__restrict__ line_start, uint64_t n_lines, uint64_t body_off,
+                     cbc_tok_perline *__restrict__ pl)
 {
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n_lines) return;
-    cbc_tok_line L;
+    cbc_tok_perline o;
+    memset(&o, 0, sizeof o);
     const uint64_t b = line_start[k], e = line_start[k + 1];
-    uint32_t status, nt = 0, ev = 0;
-    if (b < body_off) status = CBC_TOK_SKIP;                         /* '@' header lines lie before the body */
-    else { cbc_tok_split(sam, b, e, &L); status = L.status; }
+    if (b < body_off) o.status = CBC_TOK_SKIP;                        /* '@' header lines lie before the body */
+    else { cbc_tok_split(sam, b, e, &o.L); o.status = o.L.status; }
+    pl[k] = o;
+}
+
+__global__ void __launch_bounds__(256)
+cbc_tok_parse_kernel(const uint8_t *__restrict__ sam, const uint64_t *__restrict__ line_start, uint64_t n_lines, uint64_t body_off,
+                     cbc_tok_perline *pl /* in: the splits; out: + status, counts, the inherited MD */, uint32_t *__restrict__ is_rec,
+                     uint32_t *__restrict__ v_rl, uint32_t *__restrict__ v_nt)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_lines) return;
+    cbc_tok_line L = pl[k].L;                                         /* cbc_tok_split_kernel's */
+    const uint64_t b = line_start[k];
+    uint32_t status = pl[k].status, nt = 0, ev = 0;
+    if (status == CBC_TOK_OK && !L.has_md) {                          /* inherits the text of the nearest earlier line that has one */
+        uint64_t md = 0; uint32_t md_len = 0;
+        status = cbc_tok_md_source(k, [&](uint64_t j) -> const cbc_tok_line * { return line_start[j] < body_off ? (const cbc_tok_line *)0 : &pl[j].L; }, &md, &md_len);
+        L.md = md; L.md_len = md_len;
+    }
     if (status == CBC_TOK_OK) status = cbc_tok_record(sam, &L, NULL, &nt, &ev);
     cbc_tok_perline o;
     o.rname = status == CBC_TOK_OK ? L.rname : 0; o.rname_len = status == CBC_TOK_OK ? L.rname_len : 0; o.status = status;

@@ -181,14 +181,23 @@ int emu_tokenise(const uint8_t *sam, uint64_t len, uint64_t body_off, cbc_tok_su
 {
     uint64_t n_lines = 0, n_recs = 0, n_unm = 0, sb = 0, ntok = 0, nchg = 0;
     uint64_t prev_off = 0; uint32_t prev_len = 0; int have_prev = 0;
+    std::vector<cbc_tok_line> split;                       /* every line's column split, as the device keeps it (NULL source: header lines) */
+    std::vector<uint8_t> in_body;
     for (uint64_t b = 0; b < len; n_lines++) {
         uint64_t e = b;
         while (e < len && sam[e] != '\n') e++;
         if (e < len) e++;
         cbc_tok_line L;
+        memset(&L, 0, sizeof L);
         uint32_t st;
         if (b < body_off) st = CBC_TOK_SKIP; else { cbc_tok_split(sam, b, e, &L); st = L.status; }
+        split.push_back(L); in_body.push_back(b >= body_off);
         uint32_t nt = 0, ev = 0;
+        if (st == CBC_TOK_OK && !L.has_md) {
+            uint64_t md = 0; uint32_t md_len = 0;
+            st = cbc_tok_md_source(n_lines, [&](uint64_t j) -> const cbc_tok_line * { return in_body[j] ? &split[j] : (const cbc_tok_line *)0; }, &md, &md_len);
+            L.md = md; L.md_len = md_len;
+        }
         if (st == CBC_TOK_OK) st = cbc_tok_record(sam, &L, tok + ntok, &nt, &ev);
         if (st >= CBC_TOK_NEEDS_HOST) { counts[6] = n_lines; return (int)st; }
         if (st == CBC_TOK_UNMAPPED) n_unm++;

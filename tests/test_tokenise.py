@@ -60,8 +60,7 @@ def test_core_quirks_and_limits(built):
     lines = sam.splitlines(keepends=True)
     import re
     k = next(i for i, ln in enumerate(lines) if re.search(rb"MD:Z:(\d+)[ACGT]", ln) and int(re.search(rb"MD:Z:(\d+)[ACGT]", ln).group(1)) >= 20)
-    for mutate, status in ((lambda f: f[:11], 3),                                             # no MD field
-                           (lambda f: f[:5] + [b"*"] + f[6:], 7),
+    for mutate, status in ((lambda f: f[:5] + [b"*"] + f[6:], 7),
                            (lambda f: f[:9], 4),
                            (lambda f: f[:9] + [f[9][:10]] + f[10:], 9),                       # the MD names a mismatch beyond the SEQ
                            (lambda f: f[:9] + [f[9] * 3] + f[10:], 10)):
@@ -73,6 +72,27 @@ def test_core_quirks_and_limits(built):
         if status != 3:
             with pytest.raises(host.CbcInputError):
                 host.pack_sam(bad, fa, threads=1)
+    # a record without an MD field inherits the text of the nearest earlier line that has one (read_line_t.edits persists):
+    # on the device path too, and an unmapped line's MD counts.  Here: perfect reads made MD-less (they inherit a perfect or an
+    # imperfect neighbour's text -- the latter is refused as inconsistent by both packers unless the texts happen to fit), so
+    # strip MD only where the previous line's MD is a plain number
+    fa3, sam3, _, _ = synth.dataset(12, [80000], [400], 100, sub_rate=0.004, indel_frac=0.0, flags=(0, 16, 4))
+    ls = sam3.splitlines(keepends=True)
+    stripped = 0
+    for i in range(1, len(ls)):
+        f, g = ls[i].rstrip(b"\n").split(b"\t"), ls[i - 1].rstrip(b"\n").split(b"\t")
+        if len(f) > 11 and f[11] == b"MD:Z:100" and len(g) > 11 and g[11] == b"MD:Z:100" and i % 3 == 0:
+            ls[i] = b"\t".join(f[:11] + f[12:]) + b"\n"; stripped += 1
+    assert stripped > 20
+    sam3 = b"".join(ls)
+    _same(_emu_pack(sam3, fa3, block_reads=100), host.pack_sam(sam3, fa3, block_reads=100, threads=1))
+    # ... and with no MD anywhere before it within the look-back, the device path hands the file to the host packer
+    body = [l for l in ls if not l.startswith(b"@") and int(l.split(b"\t")[1]) & 4 == 0 and b"MD:Z:100" in l]
+    no_md_at_all = b"\t".join(body[0].rstrip(b"\n").split(b"\t")[:11]) + b"\n"
+    with pytest.raises(ValueError) as e:
+        blockref.emu_tokenise(body[0] + no_md_at_all * 5000)
+    assert e.value.args[0][0] == 3 and e.value.args[0][1] == 4097
+    blockref.emu_tokenise(body[0] + no_md_at_all * 4096)                              # within the look-back: fine
     long_line = b"".join(lines[:2]) + lines[2].rstrip(b"\n") + b"\tXX:Z:" + b"y" * 900 + b"\n"
     with pytest.raises(ValueError) as e:
         blockref.emu_tokenise(long_line)
@@ -101,6 +121,35 @@ def test_gpu_tokeniser_equals_host_packer(built, kw, L, br):
     for b in range(pd.n_blocks):
         bsam, bfa = blockref.block_alone_inputs(pd, lines, b)
         assert p_dev[b] == oracle.encode(bsam, bfa), "block %d of the device-tokenised batch differs from the oracle" % b
+    enc.tokenise_free(tr)
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tokeniser_md_less_records_stay_on_the_device(built):
+    """Records without an MD field (they inherit the nearest earlier line's text, an unmapped line's included): tokenised on
+    the device, arrays == the host packer's, every block == the oracle on the block's own text."""
+    from oracle import oracle
+    enc = gpu.Encoder(0)
+    fa, sam, _, _ = synth.dataset(12, [80000], [4000], 100, sub_rate=0.004, indel_frac=0.0, flags=(0, 16, 4))
+    ls = sam.splitlines(keepends=True)
+    stripped = 0
+    for i in range(1, len(ls)):
+        f, g = ls[i].rstrip(b"\n").split(b"\t"), ls[i - 1].rstrip(b"\n").split(b"\t")
+        if len(f) > 11 and f[11] == b"MD:Z:100" and len(g) > 11 and g[11] == b"MD:Z:100" and i % 3 == 0:
+            ls[i] = b"\t".join(f[:11] + f[12:]) + b"\n"; stripped += 1
+    assert stripped > 200
+    sam = b"".join(ls)
+    pd, tr = enc.tokenise_sam(sam, fa, fetch=True, block_reads=500)
+    ph = host.pack_sam(sam, fa, block_reads=500)
+    _same(pd, ph)
+    enc.upload_reference(ph.ref)
+    p_dev, r_dev, _, _ = enc.encode_blocks_tokenised(pd, tr)
+    assert (r_dev["status"] == 0).all()
+    lines = blockref.mapped_sam_lines(sam)
+    for b in range(pd.n_blocks):
+        bsam, bfa = blockref.block_alone_inputs(pd, lines, b)
+        assert p_dev[b] == oracle.encode(bsam, bfa), b
     enc.tokenise_free(tr)
     enc.close()
 
