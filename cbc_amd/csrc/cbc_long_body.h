@@ -544,7 +544,92 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
             ecount = 0;
             return n;
         };
-        const uint32_t ne = walk(false);
+        /* The walk, one lane per CIGAR run, 64 runs at a time (fast_walk): where every run starts in the read, in the reference
+         * and in M coordinates comes from three scans over the token lengths; every M lane compares ITS run's bases (a 64-bit
+         * mismatch mask per 64 bases of the run: the loop counter is wave-uniform, so building the mask is two shifts), I / S / D
+         * lanes count their length; a scan of the counts says where each run's edits go in the buffer, and the lanes put them
+         * there -- mismatches bit by bit out of the mask, inserted bases by their index.  The run-by-run walk above cost ~2900
+         * cycles per run (a chain of scalar <-> vector dependencies) and was 72 % of the model wavefront (profiles/r03_ab_kernels.log);
+         * it stays as the fallback for what the lane form does not take: an M run longer than 256 bases, an I / S / D run
+         * longer than 64, more edits than the buffer holds.  0xffffffff = fall back. */
+        auto basepair_v = [&](const V32 &c) -> V32 {
+            return W::select(c == (uint32_t)'A', W::splat(0u), W::select(c == (uint32_t)'C', W::splat(1u),
+                   W::select(c == (uint32_t)'G', W::splat(2u), W::select(c == (uint32_t)'T', W::splat(3u), W::splat(4u)))));
+        };
+        auto fast_walk = [&]() -> uint32_t {
+            uint32_t i0 = 0, j0 = pos - 1u, m0 = 0, n = 0;
+            for (uint32_t ob = 0; ob < n_cig && E.status == CBC_ST_OK; ob += 64u) {
+                const Mask live = (ln + ob) < n_cig;
+                const V32 tk = W::load32(tokb + to + 2u + ob, ln, live, 0u);
+                const V32 op = tk & 15u, len = tk >> 4;
+                const Mask isM = live & (op == CBC_OP_M), isI = live & ((op == CBC_OP_I) | (op == CBC_OP_S)), isD = live & (op == CBC_OP_D);
+                if (W::ballot(live & !(isM | isI | isD))) { E.fail(CBC_ST_UNSUPPORTED); return 0u; }
+                if (W::ballot((isM & (len > 256u)) | ((isI | isD) & (len > 64u)))) return 0xffffffffu;
+                const V32 di = W::select(isM | isI, len, W::splat(0u)), dj = W::select(isM | isD, len, W::splat(0u)), dm = W::select(isM, len, W::splat(0u));
+                const V32 Si = W::scan_incl_add(di), Sj = W::scan_incl_add(dj), Sm = W::scan_incl_add(dm);
+                const V32 io = Si - di + i0, jo = Sj - dj + j0, mo = Sm - dm + m0;       /* no overflow: 64 lengths of <= 256 */
+                const Mask bad = (isM & ((io > rl) | (len > rl - io) | (jo > ref_lim) | (len > ref_lim - jo) | ((ref_lim - jo - len) < 3u))) |
+                                 (isI & ((io > rl) | (len > rl - io))) | (isD & ((jo > ref_lim) | (len > ref_lim - jo)));
+                if (W::ballot(bad)) { E.fail(CBC_ST_ASSERT); return 0u; }
+                /* the 64-bit mismatch mask of segment `sg` (bases 64 sg .. 64 sg + 63) of every M lane's run */
+                auto seg_mask = [&](uint32_t sg, V32 &lo, V32 &hi) {
+                    lo = W::splat(0u); hi = W::splat(0u);
+                    for (uint32_t it = 0; it < 16u; it++) {
+                        const V32 p = W::splat(64u * sg + 4u * it);
+                        const Mask m = isM & (p < len);
+                        if (!W::ballot(m)) break;
+                        const V32 rd = W::load32_bytes(rdb, io + p, m), rf = W::load32_bytes(refb, jo + p, m);
+                        const V32 left = len - p;                               /* >= 1 where m */
+                        V32 x = (rd ^ rf) & W::select(left >= 4u, W::splat(0xffffffffu), (W::splat(1u) << (left * 8u)) - 1u);
+                        x = W::select(m, x, W::splat(0u));
+                        V32 y = x | (x >> 1); y = y | (y >> 2); y = y | (y >> 4);                 /* bit 0 of every byte: the byte is non-zero */
+                        const V32 nz = (((y & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
+                        if (it < 8u) lo = lo | (nz << (4u * it)); else hi = hi | (nz << (4u * (it - 8u)));
+                    }
+                };
+                /* -- counts -- */
+                V32 cnt = W::select(isI | isD, len, W::splat(0u));
+                for (uint32_t sg = 0; sg < 4u; sg++) {
+                    if (!W::ballot(isM & (len > 64u * sg))) break;
+                    V32 lo, hi; seg_mask(sg, lo, hi);
+                    cnt = cnt + W::popc_v(lo) + W::popc_v(hi);
+                }
+                const V32 Sc = W::scan_incl_add(cnt);
+                const uint32_t total = W::readlane(Sc, 63u);
+                if (n + total > CBC_LONG_EDIT_CAP) return 0xffffffffu;
+                V32 w = Sc - cnt + n;                                        /* where this run's next edit goes */
+                /* -- mismatches: out of the masks, lowest position first -- */
+                for (uint32_t sg = 0; sg < 4u; sg++) {
+                    if (!W::ballot(isM & (len > 64u * sg))) break;
+                    V32 lo, hi; seg_mask(sg, lo, hi);
+                    while (W::ballot((lo | hi) != 0u)) {
+                        const Mask has = (lo | hi) != 0u, inlo = lo != 0u;
+                        const V32 b = W::select(inlo, W::ctz_v(lo), W::ctz_v(hi) + 32u);
+                        lo = W::select(inlo, lo & (lo - 1u), lo); hi = W::select(has & !inlo, hi & (hi - 1u), hi);
+                        const V32 p = b + 64u * sg;
+                        const V32 rb = W::load8(rdb, io + p, has), fb = W::load8(refb, jo + p, has);
+                        W::store32_list(ebuf, w, (mo + p) | (basepair_v(rb) << 18) | (basepair_v(fb) << 21), has);
+                        w = w + W::select(has, W::splat(1u), W::splat(0u));
+                    }
+                }
+                /* -- inserted / clipped bases and deleted positions -- */
+                for (uint32_t k = 0; k < 64u; k++) {
+                    const Mask mi = isI & (len > k), md = isD & (len > k);
+                    if (!W::ballot(mi | md)) break;
+                    const V32 rb = W::load8(rdb, io + k, mi);
+                    W::store32_list(ebuf, w, W::select(mi, mo | (1u << 16) | (basepair_v(rb) << 18) | (5u << 21), mo | (2u << 16)), mi | md);
+                    w = w + W::select(mi | md, W::splat(1u), W::splat(0u));
+                }
+                n += total;
+                i0 += W::readlane(Si, 63u); j0 += W::readlane(Sj, 63u); m0 += W::readlane(Sm, 63u);
+                if (n > 0xffffu) { E.fail(CBC_ST_ASSERT); return 0u; }                 /* the edit count is a u16 in the stream */
+            }
+            if (E.status == CBC_ST_OK && i0 != rl) E.fail(CBC_ST_ASSERT);             /* the CIGAR must consume the read exactly */
+            return n;
+        };
+        uint32_t ne = fast_walk();
+        over = 0;
+        if (ne == 0xffffffffu) ne = walk(false);
         const uint32_t walk_again = over;
         if (E.status != CBC_ST_OK) break;
         CBC_TS(2);                                                /* record header + the walk */

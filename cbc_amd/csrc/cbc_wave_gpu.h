@@ -264,6 +264,9 @@ struct WaveGPU {
     static CBC_FN V32 recip_v(V32 n) { float r = __builtin_amdgcn_rcpf((float)n); return __builtin_bit_cast(uint32_t, r); }
     static CBC_FN float lane_float(V32 v, uint32_t k) { return __builtin_bit_cast(float, readlane(v, k)); }
 
+    /* per lane: set bits; index of the lowest set bit (32 for 0) */
+    static CBC_FN V32 popc_v(V32 x) { return (uint32_t)__builtin_popcount(x); }
+    static CBC_FN V32 ctz_v(V32 x) { return x ? (uint32_t)__builtin_ctz(x) : 32u; }
     static CBC_FN uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }       /* x != 0 */
     static CBC_FN uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }     /* x != 0 */
     static CBC_FN uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }

@@ -198,6 +198,8 @@ struct WaveEmu {
     static uint32_t clz32(uint32_t x) { if (!x) emu_oob("clz32(0)"); return (uint32_t)__builtin_clz(x); }
     static uint32_t ctz64(uint64_t x) { if (!x) emu_oob("ctz64(0)"); return (uint32_t)__builtin_ctzll(x); }
     static uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+    static V32 popc_v(const V32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = (uint32_t)__builtin_popcount(x.v[i]); return r; }
+    static V32 ctz_v(const V32 &x) { V32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] ? (uint32_t)__builtin_ctz(x.v[i]) : 32u; return r; }
     static uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 };
 

@@ -115,6 +115,23 @@ def test_full_size_properties(enc, built):
         assert p1[b] == payload and int(r1[b]["n_symbols"]) == int(res["n_symbols"])
 
 
+def test_million_reads_sampled_blocks_vs_the_oracle_text_path(enc, built):
+    """The full-size tests check the GPU against the CPU port, which consumes the packer's own tokens: a packer or generator
+    fault would be common to both sides.  Here, at 1 M reads (245 blocks), every 12th block is also coded by the oracle's TEXT
+    path from the block's own SAM lines and FASTA window -- its tokeniser, not the packer's."""
+    pb, sam, fa = host.synth(0xCBC00002, 248_956_422 // 10, 1_000_000, 150, want_text=True, block_reads=4096)
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_blocks(pb)
+    assert (res["status"] == 0).all()
+    lines = blockref.mapped_sam_lines(sam)
+    assert len(lines) == pb.n_recs
+    which = sorted(set(range(0, pb.n_blocks, 12)) | {pb.n_blocks - 1})
+    for b in which:
+        bsam, bfa = blockref.block_alone_inputs(pb, lines, b)
+        assert payloads[b] == oracle.encode(bsam, bfa), b
+    assert len(which) >= 20
+
+
 def test_variable_read_lengths(enc, built):
     from test_emu_parity import _variable_length_sam
     fa, sam = _variable_length_sam(17)
