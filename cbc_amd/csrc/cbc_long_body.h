@@ -571,54 +571,76 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                 const Mask bad = (isM & ((io > rl) | (len > rl - io) | (jo > ref_lim) | (len > ref_lim - jo) | ((ref_lim - jo - len) < 3u))) |
                                  (isI & ((io > rl) | (len > rl - io))) | (isD & ((jo > ref_lim) | (len > ref_lim - jo)));
                 if (W::ballot(bad)) { E.fail(CBC_ST_ASSERT); return 0u; }
-                /* the 64-bit mismatch mask of segment `sg` (bases 64 sg .. 64 sg + 63) of every M lane's run */
+                /* the 64-bit mismatch mask of segment `sg` (bases 64 sg .. 64 sg + 63) of every M lane's run.  Four dwords per
+                 * step, their eight loads issued before the first is looked at: a step then waits for memory once, not four times
+                 * (the loop counter is wave-uniform, so placing a step's bits in the mask is a shift by a constant) */
                 auto seg_mask = [&](uint32_t sg, V32 &lo, V32 &hi) {
                     lo = W::splat(0u); hi = W::splat(0u);
-                    for (uint32_t it = 0; it < 16u; it++) {
-                        const V32 p = W::splat(64u * sg + 4u * it);
-                        const Mask m = isM & (p < len);
-                        if (!W::ballot(m)) break;
-                        const V32 rd = W::load32_bytes(rdb, io + p, m), rf = W::load32_bytes(refb, jo + p, m);
-                        const V32 left = len - p;                               /* >= 1 where m */
-                        V32 x = (rd ^ rf) & W::select(left >= 4u, W::splat(0xffffffffu), (W::splat(1u) << (left * 8u)) - 1u);
-                        x = W::select(m, x, W::splat(0u));
-                        V32 y = x | (x >> 1); y = y | (y >> 2); y = y | (y >> 4);                 /* bit 0 of every byte: the byte is non-zero */
-                        const V32 nz = (((y & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
-                        if (it < 8u) lo = lo | (nz << (4u * it)); else hi = hi | (nz << (4u * (it - 8u)));
+                    for (uint32_t st = 0; st < 4u; st++) {
+                        const uint32_t p0 = 64u * sg + 16u * st;
+                        if (!W::ballot(isM & (len > p0))) break;
+                        V32 rd[4], rf[4];
+                        for (uint32_t q = 0; q < 4u; q++) {
+                            const Mask m = isM & (len > p0 + 4u * q);
+                            rd[q] = W::load32_bytes(rdb, io + (p0 + 4u * q), m); rf[q] = W::load32_bytes(refb, jo + (p0 + 4u * q), m);
+                        }
+                        V32 bits = W::splat(0u);
+                        for (uint32_t q = 0; q < 4u; q++) {
+                            const uint32_t p = p0 + 4u * q;
+                            const Mask m = isM & (len > p);
+                            const V32 left = len - p;                           /* >= 1 where m */
+                            V32 x = (rd[q] ^ rf[q]) & W::select(left >= 4u, W::splat(0xffffffffu), (W::splat(1u) << (left * 8u)) - 1u);
+                            x = W::select(m, x, W::splat(0u));
+                            V32 y = x | (x >> 1); y = y | (y >> 2); y = y | (y >> 4);             /* bit 0 of every byte: the byte is non-zero */
+                            bits = bits | (((((y & 0x01010101u) * 0x01020408u) >> 24) & 0xfu) << (4u * q));
+                        }
+                        if (st < 2u) lo = lo | (bits << (16u * st)); else hi = hi | (bits << (16u * (st - 2u)));
                     }
                 };
-                /* -- counts -- */
+                /* -- counts (the masks of the runs' first 64 bases are kept: most runs end there) -- */
                 V32 cnt = W::select(isI | isD, len, W::splat(0u));
+                V32 lo0 = W::splat(0u), hi0 = W::splat(0u);
                 for (uint32_t sg = 0; sg < 4u; sg++) {
                     if (!W::ballot(isM & (len > 64u * sg))) break;
                     V32 lo, hi; seg_mask(sg, lo, hi);
+                    if (sg == 0u) { lo0 = lo; hi0 = hi; }
                     cnt = cnt + W::popc_v(lo) + W::popc_v(hi);
                 }
                 const V32 Sc = W::scan_incl_add(cnt);
                 const uint32_t total = W::readlane(Sc, 63u);
                 if (n + total > CBC_LONG_EDIT_CAP) return 0xffffffffu;
                 V32 w = Sc - cnt + n;                                        /* where this run's next edit goes */
-                /* -- mismatches: out of the masks, lowest position first -- */
+                /* -- mismatches: out of the masks, lowest position first, four per step (positions, then their eight byte loads,
+                 *    then the stores) -- */
                 for (uint32_t sg = 0; sg < 4u; sg++) {
                     if (!W::ballot(isM & (len > 64u * sg))) break;
-                    V32 lo, hi; seg_mask(sg, lo, hi);
+                    V32 lo, hi;
+                    if (sg == 0u) { lo = lo0; hi = hi0; } else seg_mask(sg, lo, hi);
                     while (W::ballot((lo | hi) != 0u)) {
-                        const Mask has = (lo | hi) != 0u, inlo = lo != 0u;
-                        const V32 b = W::select(inlo, W::ctz_v(lo), W::ctz_v(hi) + 32u);
-                        lo = W::select(inlo, lo & (lo - 1u), lo); hi = W::select(has & !inlo, hi & (hi - 1u), hi);
-                        const V32 p = b + 64u * sg;
-                        const V32 rb = W::load8(rdb, io + p, has), fb = W::load8(refb, jo + p, has);
-                        W::store32_list(ebuf, w, (mo + p) | (basepair_v(rb) << 18) | (basepair_v(fb) << 21), has);
-                        w = w + W::select(has, W::splat(1u), W::splat(0u));
+                        V32 pp[4], rb[4], fb[4]; Mask hs[4];
+                        for (uint32_t q = 0; q < 4u; q++) {
+                            const Mask has = (lo | hi) != 0u, inlo = lo != 0u;
+                            pp[q] = W::select(inlo, W::ctz_v(lo), W::ctz_v(hi) + 32u) + 64u * sg;
+                            lo = W::select(inlo, lo & (lo - 1u), lo); hi = W::select(has & !inlo, hi & (hi - 1u), hi);
+                            hs[q] = has;
+                            rb[q] = W::load8(rdb, io + pp[q], has); fb[q] = W::load8(refb, jo + pp[q], has);
+                        }
+                        for (uint32_t q = 0; q < 4u; q++) {
+                            W::store32_list(ebuf, w, (mo + pp[q]) | (basepair_v(rb[q]) << 18) | (basepair_v(fb[q]) << 21), hs[q]);
+                            w = w + W::select(hs[q], W::splat(1u), W::splat(0u));
+                        }
                     }
                 }
-                /* -- inserted / clipped bases and deleted positions -- */
-                for (uint32_t k = 0; k < 64u; k++) {
-                    const Mask mi = isI & (len > k), md = isD & (len > k);
-                    if (!W::ballot(mi | md)) break;
-                    const V32 rb = W::load8(rdb, io + k, mi);
-                    W::store32_list(ebuf, w, W::select(mi, mo | (1u << 16) | (basepair_v(rb) << 18) | (5u << 21), mo | (2u << 16)), mi | md);
-                    w = w + W::select(mi | md, W::splat(1u), W::splat(0u));
+                /* -- inserted / clipped bases and deleted positions, four per step -- */
+                for (uint32_t k0 = 0; k0 < 64u; k0 += 4u) {
+                    if (!W::ballot((isI | isD) & (len > k0))) break;
+                    V32 rb[4];
+                    for (uint32_t q = 0; q < 4u; q++) rb[q] = W::load8(rdb, io + (k0 + q), isI & (len > k0 + q));
+                    for (uint32_t q = 0; q < 4u; q++) {
+                        const Mask mi = isI & (len > k0 + q), md = isD & (len > k0 + q);
+                        W::store32_list(ebuf, w, W::select(mi, mo | (1u << 16) | (basepair_v(rb[q]) << 18) | (5u << 21), mo | (2u << 16)), mi | md);
+                        w = w + W::select(mi | md, W::splat(1u), W::splat(0u));
+                    }
                 }
                 n += total;
                 i0 += W::readlane(Si, 63u); j0 += W::readlane(Sj, 63u); m0 += W::readlane(Sm, 63u);
