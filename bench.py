@@ -188,11 +188,21 @@ def issue_picture(root, which, kernel_ms, n_recs):
                  "lds_per_record": round(sq.get("SQ_INSTS_LDS", 0) / n_recs, 2),
                  "waves_per_launch": sq.get("SQ_WAVES")}
         if kcyc:
-            # one scalar unit per CU issues one wave-instruction per cycle; a SIMD issues one VALU wave-instruction per
-            # 2 cycles in wave64 on 32-wide SIMDs (MI355X_MICROARCH.md)
-            issue["salu_busy"] = round(salu / (kcyc * n_cu), 3)
-            issue["valu_busy"] = round(valu * 2 / (kcyc * n_cu * simd_per_cu), 3)
-            issue["inst_per_cycle_per_simd"] = round((salu + valu) / (kcyc * n_cu * simd_per_cu), 3)
+            # What the issue ports sustain was measured on the box (tools/ub3.hip, profiles/r03_ubench_issue.log; whole
+            # wavefront instructions per cycle of a 2.4 GHz clock from the launches' event times, any residency from 2
+            # wavefronts per SIMD up): scalar 0.98 per CU (one scalar unit); vector 0.41 per SIMD for add / and / xor /
+            # mov, 0.24 for shifts, multiplies, compares, DPP, lane reads and three-operand forms -- most of what these
+            # kernels issue; scalar + vector pairs 1.7 per CU together.
+            n_simd = n_cu * simd_per_cu
+            issue["salu_per_cycle_per_cu"] = round(salu / (kcyc * n_cu), 3)
+            issue["valu_per_cycle_per_simd"] = round(valu / (kcyc * n_simd), 3)
+            issue["inst_per_cycle_per_cu"] = round((salu + valu) / (kcyc * n_cu), 3)
+            issue["inst_per_cycle_per_simd"] = round((salu + valu) / (kcyc * n_simd), 3)
+            issue["measured_peaks"] = {"salu_per_cycle_per_cu": 0.98, "valu_per_cycle_per_simd": [0.24, 0.41], "mixed_per_cycle_per_cu": 1.7,
+                                       "source": "profiles/r03_ubench_issue.log"}
+            issue["salu_busy"] = round(salu / (kcyc * n_cu) / 0.98, 3)
+            issue["valu_busy"] = [round(valu / (kcyc * n_simd) / 0.41, 3), round(valu / (kcyc * n_simd) / 0.24, 3)]     # if all were full-rate / all half-rate
+            issue["frac_of_mixed_issue_peak"] = round((salu + valu) / (kcyc * n_cu) / 1.7, 3)
             if sq.get("SQ_WAVE_CYCLES"):
                 issue["mean_waves_per_simd"] = round(sq["SQ_WAVE_CYCLES"] * 4 / (kcyc * n_cu * simd_per_cu), 2)
                 for key, name in (("SQ_WAIT_ANY", "wave_parked_frac"), ("SQ_WAIT_INST_ANY", "wave_issue_stall_frac"),

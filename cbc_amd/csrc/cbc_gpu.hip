@@ -86,17 +86,18 @@ cbc_encode_whole_kernel(cbc_stream_args A)
 __global__ void __launch_bounds__(64)
 cbc_decode_whole_kernel(cbc_dstream_args A) { cbc_decode_whole<WaveGPU>(A, cbc_lds); }
 
-/* long-read format (cbc_long_body.h): one wavefront per block */
+/* long-read format (cbc_long_body.h): encode = three wavefronts per block (model, coder, walker), decode = one */
 #ifndef CBC_LONG_ENC_WAVES
 #define CBC_LONG_ENC_WAVES 7           /* wavefronts per SIMD the register budget is cut for (A/B: profiles/r03_ab_kernels.log) */
 #endif
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CBC_LONG_ENC_WAVES)))
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(CBC_LONG_ENC_WAVES)))
 cbc_long_encode_kernel(cbc_long_args A)
 {
     if (blockIdx.x >= A.n_blocks) return;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wid == 0u) cbc_long_encode<WaveGPU, CBC_ROLE_MODEL>(A, blockIdx.x, cbc_lds);
-    else cbc_long_encode<WaveGPU, CBC_ROLE_CODER>(A, blockIdx.x, cbc_lds);
+    else if (wid == 1u) cbc_long_encode<WaveGPU, CBC_ROLE_CODER>(A, blockIdx.x, cbc_lds);
+    else cbc_long_encode<WaveGPU, CBC_ROLE_WALKER>(A, blockIdx.x, cbc_lds);
 }
 __global__ void __launch_bounds__(64)
 cbc_long_decode_kernel(cbc_dec_args A) { if (blockIdx.x < A.n_blocks) cbc_long_decode<WaveGPU>(A, blockIdx.x, cbc_lds); }
@@ -1334,7 +1335,7 @@ API int cbc_gpu_long_encode_blocks_device(cbc_gpu_ctx *ctx, const cbc_device_bat
     { int rc_ = arena_need(ctx, A_LSCR, (uint64_t)b->n_blocks * CBC_LONG_SCRATCH_WORDS * 4 + 256, "hipMalloc long-read table scratch"); if (rc_) return rc_; }
     A.scratch = (uint32_t *)ctx->arena[A_LSCR].p;
     HIPCHK(hipEventRecord(ctx->ev0, s), "hipEventRecord");
-    hipLaunchKernelGGL(cbc_long_encode_kernel, dim3(b->n_blocks), dim3(128), lds, s, A);
+    hipLaunchKernelGGL(cbc_long_encode_kernel, dim3(b->n_blocks), dim3(192), lds, s, A);
     HIPCHK(hipGetLastError(), "launch cbc_long_encode_kernel");
     HIPCHK(hipEventRecord(ctx->ev1, s), "hipEventRecord");
     ctx->have_timing = 1; ctx->last_variant = 0;

@@ -52,9 +52,11 @@ static inline uint32_t cbc_long_dec_lds_bytes(uint32_t cap_pos) { return 4u * (C
 #define CBC_LSCR_GX     1536u
 #define CBC_LSCR_EDITS  2048u      /* encode: the edits of the read being coded (their count precedes them in the stream) */
 #ifndef CBC_LONG_EDIT_CAP
-#define CBC_LONG_EDIT_CAP 8192u    /* a read with more edits than this is walked twice (count, then code) */
+#define CBC_LONG_EDIT_CAP 8192u    /* a read with more edits than HALF this is walked twice (count, then code) */
 #endif
+#define CBC_LONG_EDIT_HALF (CBC_LONG_EDIT_CAP / 2u)                  /* the buffer is two halves: the walk of read r + 1 fills one while read r is coded from the other */
 #define CBC_LONG_TABLE_WORDS 2048u                                   /* what the decoder needs per block */
+#define CBC_ROLE_WALKER 3u         /* third wavefront of the long-read encoder: finds the edits of the reads, one read ahead */
 #define CBC_LONG_SCRATCH_WORDS (2048u + CBC_LONG_EDIT_CAP)           /* ... and the encoder */
 
 /* gap tables: index 0..7 = 2 * prev_kind + strand; gx: 0..1; sparse lists: 0..3 len, 4..5 ne */
@@ -113,12 +115,17 @@ struct CbcLWin {
     }
 };
 
-/* One block = one stream, coded by TWO wavefronts (round 3; ROLE = CBC_ROLE_MODEL / CBC_ROLE_CODER, as in the block encoder;
- * CBC_ROLE_FUSED = both in one, the CPU emulation): the model wavefront finds the edits (read vs reference along the CIGAR,
- * 256 bases per compare: 4 per lane, the next chunk's loads in flight) and turns them into (cum, count, total) triples of
- * the adaptive models; the coder wavefront runs the range coder and the bit packer over them.  The triples travel through
- * the LDS ring of the block encoder (CbcEnc::publish / pull); the model wavefront ends with a batch flagged LAST that
- * carries its status, the coder takes batches until it has seen it, whatever happens on either side. */
+/* One block = one stream, coded by THREE wavefronts (round 3; CBC_ROLE_FUSED = all in one, the CPU emulation):
+ *   WALKER  finds the edits of every read (read vs reference along the CIGAR, one lane per CIGAR run) and leaves them in the
+ *           block's edit buffer in global memory, one read ahead of the model wavefront (the buffer has two halves);
+ *   MODEL   codes the record headers and turns the edits, 64 at a time, into (cum, count, total) triples of the adaptive models;
+ *   CODER   runs the range coder and the bit packer over the triples.
+ * WALKER -> MODEL: ctl[2] = reads walked (release / acquire like the batch counters), ctl[3] = reads the model wavefront is
+ * done with, ctl[4 + (r & 1)] = edit count of read r | "did not fit" << 31, ctl[6] = the walker's failure (status | read << 16),
+ * ctl[7] = the model wavefront has left.  The walker waits only for a free half (read r - 2 done), the model wavefront only
+ * for read r's walk: no cycle; either side's exit releases the other.  MODEL -> CODER: the LDS ring of the block encoder
+ * (CbcEnc::publish / pull); the model wavefront ends with a batch flagged LAST that carries the status, the coder takes
+ * batches until it has seen it, whatever happens on either side. */
 template <class W, uint32_t ROLE>
 CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
 {
@@ -140,7 +147,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     E.role = ROLE; E.batch_i = 0; E.batch = lds + CBC_LLDS_BATCH; E.ctl = lds + CBC_LLDS_CTL;
     E.b_len = 0; E.b_pos = 0; E.b_stop = 64u; E.b_flags = 0; E.seen_last = 0; E.b_neq = 0;
     if (ROLE != CBC_ROLE_FUSED) {                            /* the only barrier: the hand-off counters start at zero for both */
-        if (ROLE == CBC_ROLE_MODEL) { W::write_uni(E.ctl, 0u, 0u); W::write_uni(E.ctl, 1u, 0u); }
+        if (ROLE == CBC_ROLE_MODEL) for (uint32_t k = 0; k < 8u; k++) W::write_uni(E.ctl, k, 0u);
         W::barrier();
     }
     E.out32 = (uint32_t *)(A.out + out_off);
@@ -182,10 +189,12 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     E.bloom = nullptr; E.var_ev = nullptr; E.nev = E.nev1 = 0; E.cap_var = 0; E.vtab = nullptr; E.p0ev = nullptr;
     E.p0cnt = W::splat(0u); E.p0over = 0;
     uint32_t *scr = A.scratch + (uint64_t)blk * CBC_LONG_SCRATCH_WORDS;
-    for (uint32_t b = 0; b < CBC_LLDS_SP; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());        /* gap symbols 0..63 */
-    if (E.status == CBC_ST_OK) for (uint32_t b = 0; b < CBC_LONG_TABLE_WORDS; b += 64u) W::store32_list(scr, ln + b, W::splat(0u), W::all());   /* the rest, gx */
-    if (ROLE == CBC_ROLE_FUSED) for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
-    W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);
+    if (ROLE != CBC_ROLE_WALKER) {                            /* the tables are the model wavefront's */
+        for (uint32_t b = 0; b < CBC_LLDS_SP; b += 64u) W::store32(lds, ln + b, W::splat(0u), W::all());        /* gap symbols 0..63 */
+        if (E.status == CBC_ST_OK) for (uint32_t b = 0; b < CBC_LONG_TABLE_WORDS; b += 64u) W::store32_list(scr, ln + b, W::splat(0u), W::all());   /* the rest, gx */
+        if (ROLE == CBC_ROLE_FUSED) for (uint32_t b = 0; b < CBC_RING_WORDS; b += 64u) W::store32(E.ring, ln + b, W::splat(0u), W::all());
+        W::write_uni(E.pos_val, 0u, 0xffffffffu); W::write_uni(E.pos_occ, 0u, 1u);
+    }
     E.snps_n = 0; E.indels_n = 0; E.pos_card = 1u;
     E.fkey = W::splat(0u); E.fexc = W::splat(0u); E.fcount = 0;
     E.hkey = W::splat(0u); E.hexc = W::splat(0u);
@@ -287,7 +296,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
      * COUNTING model (no total can reach the rescale point inside it -- checked, else the batch goes the serial way): the
      * (cum, count, total) a symbol sees = the tables before the batch + what the lower lanes of the batch add, which
      * gathers, ballots and one 64-step compare loop give to all lanes at once.  The serial form of this -- three model
-     * calls per edit on wave-uniform values -- kept the CU's one scalar unit 55 % busy (profiles/r03_e_long_encode_pmc.json:
+     * calls per edit on wave-uniform values -- kept the CU's one scalar unit 55 % busy (profiles/r03_ab_kernels.log:
      * 106 scalar + 80 vector instructions per coded symbol).  An edit word: M coordinate | kind << 16 | read base << 18 |
      * chars row << 21; carry_end / carry_pk: M coordinate after, and kind of, the previous edit of the read. ---- */
     V32 eb = W::splat(0u); uint32_t ecount = 0, carry_end = 0, carry_pk = 3u;
@@ -420,7 +429,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
         carry_end = next_end; carry_pk = next_pk;
     };
 
-    if (E.status == CBC_ST_OK) { code_int(CBC_LONG_MAGIC); code_int(8u); E.drain(); }
+    if (ROLE != CBC_ROLE_WALKER && E.status == CBC_ST_OK) { code_int(CBC_LONG_MAGIC); code_int(8u); E.drain(); }
 
     const uint4 *recs4 = (const uint4 *)(A.recs + rec_base);
     const uint8_t *seqb = A.seq + seq_base;
@@ -447,37 +456,44 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
     }
     for (uint32_t r = 0; r < n_reads && E.status == CBC_ST_OK; r++) {
         E.cur_read = r;
-        if (E.q_len >= 32u) E.drain();
-        if (r == 0u) {
-            E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
-            for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
-                uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
-                E.rname_code(E.prevChar, ch);
-                if ((q & 31u) == 31u) E.drain();
-                if (ch == 0u) break;
-                E.prevChar = ch;
-            }
-            E.drain();
-        } else E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
         const uint32_t pos = W::readlane(r_pos, r), flw = W::readlane(r_fl, r), rl = flw >> 16, strand = (flw >> 4) & 1u;
         const uint32_t so = W::readlane(r_seq, r), to = W::readlane(r_tok, r);
         const uint8_t *rdb = seqb + so;
-        for (uint32_t k = 0; k < 4u; k++) sp_code(CBC_LS_LEN + k, (rl >> (8u * (3u - k))) & 0xffu, r);
-        /* -- pos: the reference's model (compress_pos read_compression.c:113-159), any 31-bit step -- */
-        if (pos < E.prevPos) { E.fail(CBC_ST_ASSERT); break; }
-        E.pos_lit_code(pos - E.prevPos + 1u, pos_n);
-        E.prevPos = pos;
-        E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);
-        if (E.status != CBC_ST_OK) break;
+        if (ROLE == CBC_ROLE_WALKER) {
+            /* the half read r's edits go to is free once the model wavefront is done with read r - 2 */
+            uint32_t gone = 0;
+            while (r >= 2u && W::ctl_load(E.ctl + 3) + 2u <= r && !(gone = W::ctl_load(E.ctl + 7))) W::nap();
+            if (gone) break;
+        } else {
+            if (E.q_len >= 32u) E.drain();
+            if (r == 0u) {
+                E.small_code(CBC_LT_SAMEREF, 2u, 10u, 1u);
+                for (uint32_t q = 0; E.status == CBC_ST_OK; q++) {
+                    uint32_t ch = (name_off + q < A.names_bytes) ? W::read_uni8(A.names, name_off + q) : 0u;
+                    E.rname_code(E.prevChar, ch);
+                    if ((q & 31u) == 31u) E.drain();
+                    if (ch == 0u) break;
+                    E.prevChar = ch;
+                }
+                E.drain();
+            } else E.small_code(CBC_LT_SAMEREF, 2u, 10u, 0u);
+            for (uint32_t k = 0; k < 4u; k++) sp_code(CBC_LS_LEN + k, (rl >> (8u * (3u - k))) & 0xffu, r);
+            /* -- pos: the reference's model (compress_pos read_compression.c:113-159), any 31-bit step -- */
+            if (pos < E.prevPos) { E.fail(CBC_ST_ASSERT); break; }
+            E.pos_lit_code(pos - E.prevPos + 1u, pos_n);
+            E.prevPos = pos;
+            E.regsparse_code(E.fkey, E.fexc, 0u, CBC_CAP_FLAG, E.fcount, flag_n, 65536u, 8u, flw & 0xffffu, CBC_ST_CAP_FLAG);
+            if (E.status != CBC_ST_OK) break;
+        }
 
         const uint32_t hdr = W::read_uni(tokb, to), n_cig = hdr & 0xffffu;
         if (to + 2u + n_cig > n_tok_blk) { E.fail(CBC_ST_ASSERT); break; }
 
-        /* -- the edits, in read order.  ONE walk along the CIGAR collects them (read and reference come through register
-         *    windows: no memory access per CIGAR run), 64 at a time into the block's edit buffer in global memory; their
-         *    number, which the stream carries first, is then known, and the buffer is read back a batch at a time into
-         *    flush_edits().  A read with more edits than the buffer holds is walked a second time instead. -- */
-        uint32_t *ebuf = scr + CBC_LSCR_EDITS;
+        /* -- the edits, in read order.  ONE walk along the CIGAR (the walker wavefront's) collects them into a half of the
+         *    block's edit buffer in global memory; their number, which the stream carries first, is then known, and the
+         *    model wavefront reads the half back a batch at a time into flush_edits().  A read with more edits than a half
+         *    holds is walked a second time by the model wavefront itself, coding as it goes. -- */
+        uint32_t *ebuf = scr + CBC_LSCR_EDITS + (r & 1u) * CBC_LONG_EDIT_HALF;
         CbcLWin<W> rw, fw;
         uint32_t over = 0;                                        /* first walk: the buffer is full, it only counts from there */
         auto walk = [&](const bool second) -> uint32_t {
@@ -489,8 +505,8 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                 if (over) return;
                 eb = W::select(ln == ecount, W::splat(mc | (kind << 16) | (base << 18) | (row << 21)), eb);
                 if (++ecount < 64u) return;
-                if (second) flush_edits(strand);
-                else if (stored + 64u <= CBC_LONG_EDIT_CAP) { W::store32_list(ebuf, ln + stored, eb, W::all()); stored += 64u; ecount = 0; }
+                if (second) { if (ROLE != CBC_ROLE_WALKER) flush_edits(strand); }
+                else if (stored + 64u <= CBC_LONG_EDIT_HALF) { W::store32_list(ebuf, ln + stored, eb, W::all()); stored += 64u; ecount = 0; }
                 else { over = 1u; ecount = 0; }
             };
             V32 tokv = W::splat(0u);
@@ -539,7 +555,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                 if (n > 0xffffu) { E.fail(CBC_ST_ASSERT); break; }                    /* the edit count is a u16 in the stream */
             }
             if (E.status == CBC_ST_OK && i != rl) E.fail(CBC_ST_ASSERT);              /* the CIGAR must consume the read exactly */
-            if (second) { flush_edits(strand); return n; }
+            if (second) { if (ROLE != CBC_ROLE_WALKER) flush_edits(strand); return n; }
             if (!over && ecount) { W::store32_list(ebuf, ln + stored, eb, ln < ecount); stored += ecount; }
             ecount = 0;
             return n;
@@ -608,7 +624,7 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                 }
                 const V32 Sc = W::scan_incl_add(cnt);
                 const uint32_t total = W::readlane(Sc, 63u);
-                if (n + total > CBC_LONG_EDIT_CAP) return 0xffffffffu;
+                if (n + total > CBC_LONG_EDIT_HALF) return 0xffffffffu;
                 V32 w = Sc - cnt + n;                                        /* where this run's next edit goes */
                 /* -- mismatches: out of the masks, lowest position first, four per step (positions, then their eight byte loads,
                  *    then the stores) -- */
@@ -649,15 +665,32 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
             if (E.status == CBC_ST_OK && i0 != rl) E.fail(CBC_ST_ASSERT);             /* the CIGAR must consume the read exactly */
             return n;
         };
-        uint32_t ne = fast_walk();
-        over = 0;
-        if (ne == 0xffffffffu) ne = walk(false);
-        const uint32_t walk_again = over;
-        if (E.status != CBC_ST_OK) break;
-        CBC_TS(2);                                                /* record header + the walk */
+        uint32_t ne = 0, walk_again = 0;
+        if (ROLE == CBC_ROLE_MODEL) {
+            CBC_TS(2);                                            /* record header */
+            while (W::ctl_load(E.ctl + 2) <= r) W::nap();         /* acquire: read r has been walked (or the walker has failed) */
+            CBC_TS(4);                                            /* waiting for the walker */
+            const uint32_t wst = W::read_uni(E.ctl, 6u);
+            if (wst) { if (E.status == CBC_ST_OK) { E.status = wst & 0xffffu; E.fail_read = wst >> 16; } break; }
+            const uint32_t w = W::read_uni(E.ctl, 4u + (r & 1u));
+            ne = w & 0x7fffffffu; walk_again = w >> 31;
+        } else {
+            ne = fast_walk();
+            over = 0;
+            if (ne == 0xffffffffu) ne = walk(false);
+            walk_again = over;
+            if (E.status != CBC_ST_OK) break;
+        }
+        if (ROLE == CBC_ROLE_WALKER) {
+            W::list_fence();                                      /* release: the edits are in memory before the count says so */
+            W::write_uni(E.ctl, 4u + (r & 1u), ne | (walk_again << 31));
+            W::ctl_store(E.ctl + 2, r + 1u);
+            continue;
+        }
+        if (ROLE == CBC_ROLE_FUSED) CBC_TS(2);                    /* record header + the walk */
         sp_code(CBC_LS_NE, ne >> 8, r); sp_code(CBC_LS_NE + 1u, ne & 0xffu, r);
         carry_end = 0; carry_pk = 3u;
-        if (walk_again) (void)walk(true);                         /* more edits than the buffer holds: collect and code in one go */
+        if (walk_again) (void)walk(true);                         /* more edits than a half holds: collect and code in one go */
         else {
             W::list_fence();
             for (uint32_t k = 0; k < ne && E.status == CBC_ST_OK; k += 64u) {
@@ -666,7 +699,14 @@ CBC_FN void cbc_long_encode(const cbc_long_args &A, uint32_t blk, uint32_t *lds)
                 flush_edits(strand);
             }
         }
+        if (ROLE == CBC_ROLE_MODEL) W::ctl_store(E.ctl + 3, r + 1u);     /* the half is free again */
     }
+    if (ROLE == CBC_ROLE_WALKER) {
+        /* a failure here reaches the model wavefront through the mailbox; it waits for nothing else of this wavefront */
+        if (E.status != CBC_ST_OK) { W::write_uni(E.ctl, 6u, E.status | (E.fail_read << 16)); W::ctl_store(E.ctl + 2, 0x7fffffffu); }
+        return;
+    }
+    if (ROLE == CBC_ROLE_MODEL) W::ctl_store(E.ctl + 7, 1u);     /* the walker must not wait for a half any more */
     if (E.status == CBC_ST_OK) {
         E.cur_read = n_reads;
         if (E.q_len >= 32u) E.drain();

@@ -22,7 +22,15 @@ CASES = [
     (11, 100_000, 150, 200, 0.0),                   # no edits at all
     (15, 400_000, 12, 30_000, 0.45),                # ~13 k edits per read: more than the encoder's edit buffer holds (the read is walked twice)
     (13, 1_500_000, 300, 4_000, 0.002),             # sparse edits: most gaps beyond the 64 symbols held in LDS, many with the two gx bytes
+    (17, 300_000, 20, 12_000, 0.45),                # ~5 k edits per read: more than one half of the edit buffer, less than both
 ]
+
+
+def _break_a_cigar(pb, blk, read):
+    """The CIGAR of one read no longer consumes the read (its first run is one base longer): what the walk must refuse."""
+    b = pb.blocks[blk]
+    t = int(b["tok_base"]) + int(pb.recs[int(b["rec_base"]) + read]["tok_off"]) + 2
+    pb.tok[t] += 1 << 4
 
 
 def _reads(sam):
@@ -98,6 +106,15 @@ def test_long_soft_clips_and_out_full(built):
     assert (small["status"] == 1).all() and (small["nbytes"] == 0).all()
 
 
+def test_long_walk_failure_is_the_blocks_status(built):
+    pb, sam, fa = host.synth_long(23, 1_500_000, 150, 8_000, 0.05, want_text=True, threads=2)
+    assert pb.n_blocks >= 2
+    _break_a_cigar(pb, 1, 5)
+    _, res = blockref.emu_long_encode(pb)
+    assert res["status"][1] != 0 and res["nbytes"][1] == 0 and res["fail_read"][1] == 5
+    assert (np.delete(res["status"], 1) == 0).all()
+
+
 # ----------------------------------------------------------------------------------------- on the GPU
 @pytest.fixture(scope="module")
 def enc():
@@ -122,6 +139,19 @@ def test_gpu_long_encode_decode(enc, built, args):
     assert (dres["status"] == 0).all() and (dres["n_symbols"] == res["n_symbols"]).all()
     assert plan.text(recs, seq) == _reads(sam)
     assert (recs["pos"] == pb.recs["pos"]).all() and (recs["flag"] == pb.recs["flag"]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_long_walk_failure_reaches_the_result_and_every_wavefront_leaves(enc, built):
+    """A failure of the walker wavefront travels walker -> model -> coder -> results; the other blocks are coded as ever."""
+    pb, sam, fa = host.synth_long(23, 1_500_000, 150, 8_000, 0.05, want_text=True, threads=2)
+    ref_payloads, _ = oracle.cpu_encode_blocks(pb, return_payloads=True, long_reads=True)
+    _break_a_cigar(pb, 1, 5)
+    enc.upload_reference(pb.ref)
+    payloads, res, offs, flat = enc.encode_long_blocks(pb)
+    assert res["status"][1] != 0 and res["nbytes"][1] == 0 and res["fail_read"][1] == 5
+    assert (np.delete(res["status"], 1) == 0).all()
+    assert [p for k, p in enumerate(payloads) if k != 1] == [p for k, p in enumerate(ref_payloads) if k != 1]
 
 
 @pytest.mark.gpu

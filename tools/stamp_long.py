@@ -1,4 +1,4 @@
-# per-section s_memtime sums of the long-read encoder's two wavefronts from a -DCBC_STAMP build (scratch/abl/lib_stamp.so):
+# per-section s_memtime sums of the long-read encoder's model and coder wavefronts from a -DCBC_STAMP build (scratch/abl/lib_stamp.so):
 #   hipcc -O3 --offload-arch=gfx950 -fPIC -fvisibility=hidden -ffp-contract=off -DCBC_STAMP -shared -o scratch/abl/lib_stamp.so cbc_amd/csrc/cbc_gpu.hip
 import sys, os, ctypes
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R)
@@ -23,9 +23,9 @@ cod=np.zeros(16); mod=np.zeros(16)
 for b in range(pb.n_blocks):
     o=int(blocks[b]['out_off']); cod+=out[o:o+128].view(np.uint64).astype(np.float64); mod+=out[o+128:o+256].view(np.uint64).astype(np.float64)
 nb=pb.n_blocks
-mn={0:'walk (collect edits)',1:'batch model arithmetic',2:'record header + pass 0',3:'tail',5:'until the hand-off wait',6:'WAITING for a free slot',7:'hand-over of triples'}
+mn={0:'reading a batch back',1:'batch model arithmetic',2:'record header',3:'tail',4:'WAITING for the walker',5:'until the hand-off wait',6:'WAITING for a free slot',7:'hand-over of triples'}
 cn={9:'coding',10:'WAITING for a batch'}
-print('model wavefront, cycles per block (100 MHz s_memtime ticks x 24 = shader cycles at 2.4 GHz):')
+print('model wavefront, s_memtime ticks (= shader cycles) per block:')
 for k,v in enumerate(mod):
     if v: print('  %-28s %12.0f ticks  %5.1f%%'%(mn.get(k,str(k)), v/nb, 100*v/mod.sum()))
 print('coder wavefront:')
