@@ -51,8 +51,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CHR1_LEN = 248_956_422          # human chr1-sized contig
-KERNEL_SOURCES = ["cbc_gpu.hip", "cbc_encode_body.h", "cbc_decode_body.h", "cbc_stream_body.h", "cbc_long_body.h",
-                  "cbc_tok_core.h", "cbc_tokenise.h", "cbc_plan.h", "cbc_wave_gpu.h"]
+# what each measured kernel is compiled from (the kernels are separate functions of one translation unit: a change to the
+# long-read body does not touch the block kernels' code)
+_BLOCK_SOURCES = ["cbc_gpu.hip", "cbc_encode_body.h", "cbc_decode_body.h", "cbc_plan.h", "cbc_wave_gpu.h"]
+KERNEL_SOURCES = {"encode": _BLOCK_SOURCES, "decode": _BLOCK_SOURCES,
+                  "long_encode": _BLOCK_SOURCES + ["cbc_long_body.h"], "long_decode": _BLOCK_SOURCES + ["cbc_long_body.h"]}
 
 
 def parse_args(argv=None):
@@ -151,10 +154,11 @@ def spawn_ranks(args):
     return 0
 
 
-def kernel_source_sha():
-    """sha256 over the kernel sources libcbc_gpu.so is built from: ties a committed counter pass to a kernel build."""
+def kernel_source_sha(leg):
+    """sha256 over the sources the leg's kernel (encode | decode | long_encode | long_decode) is built from: ties a
+    committed counter pass to a kernel build."""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES[leg]:
         with open(os.path.join(ROOT, "cbc_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -172,7 +176,7 @@ def issue_picture(root, which, kernel_ms, n_recs):
     except Exception:
         return None, None, None
     src = os.path.relpath(path, root)
-    if pm.get("kernel_source_sha") != kernel_source_sha():
+    if pm.get("kernel_source_sha") != kernel_source_sha(which[:-4]):
         return None, src + " (stale: taken from other kernel sources)", None
     sq = pm.get("SQ_per_launch") or {}
     issue = None
@@ -626,7 +630,7 @@ def run_rank(args, R):
                          "kernel": ("cbc_long_%s_kernel" % args.mode) if long_fmt else
                                    "cbc_%s_blocks_kernel%s" % (args.mode, "_w6" if args.mode == "encode" and my_blocks > 10 * n_cus else ""),
                          "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_source_sha": kernel_source_sha(), "issue": issue},
+                         "kernel_source_sha": kernel_source_sha(("long_" if long_fmt else "") + args.mode), "issue": issue},
             "cpu_baseline": cpu,
         }
         if e2e is not None:

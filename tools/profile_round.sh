@@ -44,7 +44,7 @@ for f in glob.glob(O + "/pmc_%s_%s_*/**/*counter_collection.csv" % (tag, leg), r
         if name.startswith(kern):                            # both register budgets of the encode kernel (.._w6) count
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
             info = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "SGPR_Count") if k in row}
-res = {"kernel": kern, "kernel_source_sha": bench.kernel_source_sha(), "FETCH_SIZE": agg.pop("FETCH_SIZE", []), "WRITE_SIZE": agg.pop("WRITE_SIZE", []),
+res = {"kernel": kern, "kernel_source_sha": bench.kernel_source_sha(leg), "FETCH_SIZE": agg.pop("FETCH_SIZE", []), "WRITE_SIZE": agg.pop("WRITE_SIZE", []),
        "dispatch_info": info, "SQ_per_launch": {k: sum(v) / len(v) for k, v in sorted(agg.items())}}
 try:
     ks = list(csv.DictReader(open(O + "/%s_%s_kernel_stats.csv" % (tag, leg))))
