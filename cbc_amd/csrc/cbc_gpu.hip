@@ -88,7 +88,7 @@ cbc_decode_whole_kernel(cbc_dstream_args A) { cbc_decode_whole<WaveGPU>(A, cbc_l
 
 /* long-read format (cbc_long_body.h): encode = three wavefronts per block (model, coder, walker), decode = one */
 #ifndef CBC_LONG_ENC_WAVES
-#define CBC_LONG_ENC_WAVES 7           /* wavefronts per SIMD the register budget is cut for (A/B: profiles/r03_ab_kernels.log) */
+#define CBC_LONG_ENC_WAVES 8           /* wavefronts per SIMD the register budget is cut for (A/B: profiles/r03_ab_kernels.log) */
 #endif
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(CBC_LONG_ENC_WAVES)))
 cbc_long_encode_kernel(cbc_long_args A)
