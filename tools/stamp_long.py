@@ -25,7 +25,7 @@ for b in range(pb.n_blocks):
 nb=pb.n_blocks
 mn={0:'reading a batch back',1:'batch model arithmetic',2:'record header',3:'tail',4:'WAITING for the walker',5:'until the hand-off wait',6:'WAITING for a free slot',7:'hand-over of triples'}
 cn={9:'coding',10:'WAITING for a batch'}
-print('model wavefront, s_memtime ticks (= shader cycles) per block:')
+print('model wavefront, s_memtime ticks per block:')
 for k,v in enumerate(mod):
     if v: print('  %-28s %12.0f ticks  %5.1f%%'%(mn.get(k,str(k)), v/nb, 100*v/mod.sum()))
 print('coder wavefront:')
